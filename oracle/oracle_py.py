@@ -1,0 +1,221 @@
+"""TEST INFRASTRUCTURE -- ctypes bindings for oracle/libqr_oracle.so (our CPU
+restatement) and oracle/_ref/libqr_ref.so (the reference's vendored qpOASES /
+QuadProg++ compiled from /root/reference; optional).
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f = np.float32
+_d = np.float64
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _fp(a):
+    return _ptr(a, C.c_float)
+
+
+def _dp(a):
+    return _ptr(a, C.c_double)
+
+
+def _ip(a):
+    return _ptr(a, C.c_int)
+
+
+def build(force=False):
+    """Compile libqr_oracle.so (and _ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "libqr_oracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-j4", "all"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/quadruped/extern/qpOASES/src") and (
+            force or not os.path.exists(os.path.join(_HERE, "_ref", "libqr_ref.so"))):
+        subprocess.check_call(["make", "-C", _HERE, "-j4", "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(os.path.join(_HERE, "libqr_oracle.so"))
+        _lib.qro_tick_batch.restype = C.c_double
+    return _lib
+
+
+def ref():
+    """The compiled reference solvers, or None when oracle/_ref was not built."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(_HERE, "_ref", "libqr_ref.so")
+        if not os.path.exists(p):
+            build()
+        if not os.path.exists(p):
+            return None
+        _ref = C.CDLL(p)
+        _ref.ref_quadprog.restype = C.c_double
+    return _ref
+
+
+# ----------------------------------------------------------------------------- packed layouts
+def pack_mpc_cfg(dt=0.06, mu=0.45, fmax=13 * 9.81, mass=13.0, inertia=(0.24, 0.80, 1.0),
+                 weights=(10, 10, 5, 40, 60, 100, 0, 0, 0.5, 5, 5, 1), alpha=4e-6):
+    return np.array([dt, mu, fmax, mass, *inertia, *weights, alpha], dtype=_f)
+
+
+A1_GEOM = np.array([0.08505, 0.2, 0.2], dtype=_f)
+A1_MODEL = np.array([0.08505, 0.2, 0.2, 0.267, 0.194, 0.114], dtype=_f)
+LITE3_GEOM = np.array([0.0985, 0.20, 0.20], dtype=_f)
+LITE3_MODEL = np.array([0.0985, 0.20, 0.20, 0.349, 0.124, 0.15], dtype=_f)
+
+
+# ----------------------------------------------------------------------------- QP
+def qp_solve(G, g0, CE, ce0, CI, ci0):
+    """min 1/2 x'Gx+g0'x, CE'x+ce0=0, CI'x+ci0>=0 (QuadProg++ convention).  -> x, lambda, stats, rc"""
+    G = np.ascontiguousarray(G, _d); g0 = np.ascontiguousarray(g0, _d)
+    n = g0.size
+    CE = np.ascontiguousarray(CE, _d).reshape(n, -1) if CE is not None and np.size(CE) else np.zeros((n, 0))
+    CI = np.ascontiguousarray(CI, _d).reshape(n, -1) if CI is not None and np.size(CI) else np.zeros((n, 0))
+    ce0 = np.ascontiguousarray(ce0, _d) if ce0 is not None else np.zeros(0)
+    ci0 = np.ascontiguousarray(ci0, _d) if ci0 is not None else np.zeros(0)
+    p, m = CE.shape[1], CI.shape[1]
+    x = np.zeros(n); lam = np.zeros(max(m, 1)); st = np.zeros(4, np.int32); obj = C.c_double(0)
+    rc = lib().qro_qp_solve(n, _dp(G), _dp(g0), p, _dp(CE), _dp(ce0), m, _dp(CI), _dp(ci0), _dp(x), _dp(lam), _ip(st), C.byref(obj))
+    return x, lam[:m], dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3]), obj=obj.value), rc
+
+
+def ref_quadprog(G, g0, CE, ce0, CI, ci0):
+    r = ref()
+    G = np.ascontiguousarray(G, _d).copy(); g0 = np.ascontiguousarray(g0, _d).copy()
+    n = g0.size
+    CE = np.ascontiguousarray(CE, _d).reshape(n, -1); CI = np.ascontiguousarray(CI, _d).reshape(n, -1)
+    ce0 = np.ascontiguousarray(ce0, _d); ci0 = np.ascontiguousarray(ci0, _d)
+    x = np.zeros(n)
+    f = r.ref_quadprog(n, CE.shape[1], CI.shape[1], _dp(G), _dp(g0), _dp(CE), _dp(ce0), _dp(CI), _dp(ci0), _dp(x))
+    return x, f
+
+
+def ref_qpoases_mpc(H, g, A, lbA, ubA, nWSR=100):
+    """Exactly the reference's solver call (qr_mpc_interface.cpp:428-438).  -> x, info"""
+    r = ref()
+    H = np.ascontiguousarray(H, _d); g = np.ascontiguousarray(g, _d); A = np.ascontiguousarray(A, _d)
+    lbA = np.ascontiguousarray(lbA, _d); ubA = np.ascontiguousarray(ubA, _d)
+    n, m = g.size, lbA.size
+    x = np.zeros(n); nw = C.c_int(0); prc = C.c_int(0); obj = C.c_double(0)
+    rc = r.ref_qpoases_mpc(n, m, _dp(H), _dp(g), _dp(A), _dp(lbA), _dp(ubA), int(nWSR), _dp(x), C.byref(nw), C.byref(prc), C.byref(obj))
+    return x, dict(init_rc=rc, nWSR=nw.value, primal_rc=prc.value, obj=obj.value)
+
+
+def mpc_constraint_matrix(horizon, mu=0.45):
+    """fmat of ResizeQPMats (qr_mpc_interface.cpp:230-240) as float32 -> float64, 20h x 12h."""
+    im = np.float32(1.0) / np.float32(mu)
+    blk = np.array([[im, 0, 1], [-im, 0, 1], [0, im, 1], [0, -im, 1], [0, 0, 1]], dtype=_f)
+    A = np.zeros((20 * horizon, 12 * horizon), dtype=_f)
+    for i in range(4 * horizon):
+        A[5 * i:5 * i + 5, 3 * i:3 * i + 3] = blk
+    return A.astype(_d)
+
+
+# ----------------------------------------------------------------------------- MPC
+def mpc_assemble(cfg, horizon, state28, traj, gait, literal=False):
+    n, m = 12 * horizon, 20 * horizon
+    H = np.zeros((n, n), _f); g = np.zeros(n, _f); ub = np.zeros(m, _f)
+    state28 = np.ascontiguousarray(state28, _f); traj = np.ascontiguousarray(traj, _f); gait = np.ascontiguousarray(gait, _f)
+    lib().qro_mpc_assemble(_fp(cfg), horizon, _fp(state28), _fp(traj), _fp(gait), int(literal), _fp(H), _fp(g), _fp(ub))
+    return H, g, ub
+
+
+def mpc_solve(cfg, horizon, state28, traj, gait, literal=False):
+    n = 12 * horizon
+    u = np.zeros(n); st = np.zeros(4, np.int32)
+    state28 = np.ascontiguousarray(state28, _f); traj = np.ascontiguousarray(traj, _f); gait = np.ascontiguousarray(gait, _f)
+    rc = lib().qro_mpc_solve(_fp(cfg), horizon, _fp(state28), _fp(traj), _fp(gait), int(literal), _dp(u), _ip(st))
+    return u, dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])), rc
+
+
+def mpc_force_to_torque(geom, quat, q12, f12):
+    tau = np.zeros(12, _f)
+    lib().qro_mpc_force_to_torque(_fp(np.ascontiguousarray(geom, _f)), _fp(np.ascontiguousarray(quat, _f)),
+                                  _fp(np.ascontiguousarray(q12, _f)), _dp(np.ascontiguousarray(f12, _d)), _fp(tau))
+    return tau
+
+
+def foot_positions(geom, hip_offset12, q12):
+    out = np.zeros(12, _f)
+    lib().qro_foot_positions(_fp(np.ascontiguousarray(geom, _f)), _fp(np.ascontiguousarray(hip_offset12, _f)),
+                             _fp(np.ascontiguousarray(q12, _f)), _fp(out))
+    return out
+
+
+def leg_jacobian(geom, q3, leg):
+    J = np.zeros(9, _f)
+    lib().qro_leg_jacobian(_fp(np.ascontiguousarray(geom, _f)), _fp(np.ascontiguousarray(q3, _f)), int(leg), _fp(J))
+    return J.reshape(3, 3)
+
+
+def rpy_to_quat(rpy):
+    q = np.zeros(4, _f)
+    lib().qro_rpy_to_quat(_fp(np.ascontiguousarray(rpy, _f)), _fp(q))
+    return q
+
+
+# ----------------------------------------------------------------------------- dynamics / WBC
+def fb_compute(model, state37, dtype=_f):
+    t = dtype
+    H = np.zeros((18, 18), t); G = np.zeros(18, t); Cq = np.zeros(18, t)
+    Jc = np.zeros((4, 3, 18), t); Jcd = np.zeros((4, 3), t); p = np.zeros((4, 3), t); v = np.zeros((4, 3), t)
+    s = np.ascontiguousarray(state37, t)
+    conv = _fp if t == _f else _dp
+    fn = lib().qro_fb_compute_f32 if t == _f else lib().qro_fb_compute_f64
+    fn(_fp(np.ascontiguousarray(model, _f)), conv(s), conv(H), conv(G), conv(Cq), conv(Jc), conv(Jcd), conv(p), conv(v))
+    return dict(H=H, G=G, C=Cq, Jc=Jc, Jcdqd=Jcd, pGC=p, vGC=v)
+
+
+def wbc_run(model, state37, cmd67, prev_ori_vel=None, dtype=_f):
+    t = dtype
+    conv = _fp if t == _f else _dp
+    s = np.ascontiguousarray(state37, t); c = np.ascontiguousarray(cmd67, t)
+    prev = np.zeros(3, t) if prev_ori_vel is None else np.ascontiguousarray(prev_ori_vel, t).copy()
+    tau = np.zeros(12, t); qdes = np.zeros(12, t); qddes = np.zeros(12, t); fr = np.zeros(12, t); qdd = np.zeros(18, t)
+    st = np.zeros(4, np.int32)
+    fn = lib().qro_wbc_run_f32 if t == _f else lib().qro_wbc_run_f64
+    rc = fn(_fp(np.ascontiguousarray(model, _f)), conv(s), conv(c), conv(prev), conv(tau), conv(qdes), conv(qddes), conv(fr), conv(qdd), _ip(st))
+    return dict(tau=tau, qdes=qdes, qddes=qddes, fr=fr, qddot=qdd, prev_ori_vel=prev, rc=rc,
+                qp=dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])))
+
+
+def pinv(A, thr):
+    A = np.ascontiguousarray(A, _f)
+    out = np.zeros((A.shape[1], A.shape[0]), _f)
+    lib().qro_pinv_f32(A.shape[0], A.shape[1], _fp(A), float(thr), _fp(out))
+    return out
+
+
+def lu_inverse(A):
+    A = np.ascontiguousarray(A, _f)
+    out = np.zeros_like(A)
+    lib().qro_lu_inverse_f32(A.shape[0], _fp(A), _fp(out))
+    return out
+
+
+def tick_batch(mode, cfg, horizon, geom, model, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori_vel, nthreads=1):
+    """Robot-major (AoS) batched tick on host threads.  -> force[n,12], tau[n,12], status[n], seconds"""
+    n = mpc_state.shape[0]
+    force = np.zeros((n, 12), _f); tau = np.zeros((n, 12), _f); status = np.zeros(n, np.int32)
+    arrs = [np.ascontiguousarray(a, _f) for a in (mpc_state, traj, gait, fb_state, wbc_cmd)]
+    prev = np.ascontiguousarray(prev_ori_vel, _f)
+    sec = lib().qro_tick_batch(n, int(nthreads), int(mode), _fp(cfg), horizon, _fp(np.ascontiguousarray(geom, _f)),
+                               _fp(np.ascontiguousarray(model, _f)), _fp(arrs[0]), _fp(arrs[1]), _fp(arrs[2]), _fp(arrs[3]),
+                               _fp(arrs[4]), _fp(prev), _fp(force), _fp(tau), _ip(status))
+    return force, tau, status, sec, prev

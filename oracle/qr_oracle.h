@@ -1,0 +1,195 @@
+// ============================================================================
+//  qr_oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+//  Plain-C++ CPU restatement of the convex-MPC + WBC hot path of
+//  TopHillRobotics/quadruped-robot (reference files cited per function as
+//  "QS/..." = quadruped/src/..., "QI/..." = quadruped/include/quadruped/...).
+//  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+//  load this library; libqrgpu.so never links or calls it.
+//
+//  Parity status: the reference has NO tests / golden vectors for this path
+//  (SURVEY.md 4).  The QP solvers are pinned against the reference's own
+//  vendored qpOASES 3.2.0 / QuadProg++ compiled from /root/reference
+//  (oracle/_ref, tests/golden/*).  The Eigen glue around them (fp32 assembly,
+//  rigid-body dynamics) cannot be compiled here (Eigen/ROS absent) and is
+//  pinned only by analytic invariants and float64 numpy cross-checks:
+//  "parity unpinned" at the Eigen boundary.
+// ============================================================================
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <cassert>
+
+namespace qro {
+
+// ---------------------------------------------------------------------------
+// Tiny dense row-major matrix (stands in for Eigen DMat<T>/DVec<T>).
+// All arithmetic is done in T with plain, left-to-right accumulation.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Mat {
+    int r = 0, c = 0;
+    std::vector<T> d;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, T(0)) {}
+    static Mat Identity(int n) { Mat m(n, n); for (int i = 0; i < n; ++i) m(i, i) = T(1); return m; }
+    static Mat Zero(int r_, int c_) { return Mat(r_, c_); }
+    T &operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    const T &operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+    T &operator[](int i) { return d[i]; }                 // vector access
+    const T &operator[](int i) const { return d[i]; }
+    int rows() const { return r; }
+    int cols() const { return c; }
+    int size() const { return r * c; }
+    void setZero() { std::fill(d.begin(), d.end(), T(0)); }
+    Mat t() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); return m; }
+    Mat block(int i0, int j0, int nr, int nc) const {
+        Mat m(nr, nc);
+        for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) m(i, j) = (*this)(i0 + i, j0 + j);
+        return m;
+    }
+    void setBlock(int i0, int j0, const Mat &b) {
+        for (int i = 0; i < b.r; ++i) for (int j = 0; j < b.c; ++j) (*this)(i0 + i, j0 + j) = b(i, j);
+    }
+};
+
+template <typename T> Mat<T> operator*(const Mat<T> &a, const Mat<T> &b) {
+    assert(a.c == b.r);
+    Mat<T> m(a.r, b.c);
+    for (int i = 0; i < a.r; ++i)
+        for (int j = 0; j < b.c; ++j) {
+            T s = T(0);
+            for (int k = 0; k < a.c; ++k) s += a(i, k) * b(k, j);
+            m(i, j) = s;
+        }
+    return m;
+}
+template <typename T> Mat<T> operator+(const Mat<T> &a, const Mat<T> &b) {
+    assert(a.r == b.r && a.c == b.c);
+    Mat<T> m(a.r, a.c);
+    for (int i = 0; i < a.size(); ++i) m.d[i] = a.d[i] + b.d[i];
+    return m;
+}
+template <typename T> Mat<T> operator-(const Mat<T> &a, const Mat<T> &b) {
+    assert(a.r == b.r && a.c == b.c);
+    Mat<T> m(a.r, a.c);
+    for (int i = 0; i < a.size(); ++i) m.d[i] = a.d[i] - b.d[i];
+    return m;
+}
+template <typename T> Mat<T> operator-(const Mat<T> &a) {
+    Mat<T> m(a.r, a.c);
+    for (int i = 0; i < a.size(); ++i) m.d[i] = -a.d[i];
+    return m;
+}
+template <typename T> Mat<T> operator*(T s, const Mat<T> &a) {
+    Mat<T> m(a.r, a.c);
+    for (int i = 0; i < a.size(); ++i) m.d[i] = s * a.d[i];
+    return m;
+}
+
+// ------------------------- small fixed-size helpers ------------------------
+template <typename T> struct V3 { T v[3]; T &operator[](int i) { return v[i]; } const T &operator[](int i) const { return v[i]; } };
+template <typename T> struct M3 { T m[3][3]; T *operator[](int i) { return m[i]; } const T *operator[](int i) const { return m[i]; } };
+template <typename T> struct Q4 { T q[4]; T &operator[](int i) { return q[i]; } const T &operator[](int i) const { return q[i]; } };  // (w,x,y,z)
+
+// QI/utils/qr_se3.h restatements (qr_oracle_math.cpp)
+template <typename T> M3<T> coordinateRotation(int axis, T theta);               // :72-89 (returns the TRANSPOSED / coordinate-transform matrix)
+template <typename T> M3<T> rpyToRotMat(const V3<T> &rpy);                       // :109-116
+template <typename T> Q4<T> rotationMatrixToQuaternion(const M3<T> &r1);         // :139-172
+template <typename T> M3<T> quaternionToRotationMatrix(const Q4<T> &q);          // :186-203 (world->body)
+template <typename T> Q4<T> rpyToQuat(const V3<T> &rpy);                         // :229-235
+template <typename T> Q4<T> quatProduct(const Q4<T> &a, const Q4<T> &b);         // :291-302
+template <typename T> V3<T> quaternionToso3(const Q4<T> &q);                     // :383-397
+template <typename T> M3<T> mul(const M3<T> &a, const M3<T> &b);
+template <typename T> V3<T> mul(const M3<T> &a, const V3<T> &b);
+template <typename T> M3<T> transpose(const M3<T> &a);
+
+// QI/utils/qr_algebra.h:119-141 -- SVD pseudo-inverse with strict '>' threshold.
+template <typename T> void pseudoInverse(const Mat<T> &m, double sigmaThreshold, Mat<T> &inv);
+// Thin SVD  A = U diag(s) V^T  by one-sided (Hestenes) Jacobi; stands in for Eigen::JacobiSVD.
+template <typename T> void jacobiSVD(const Mat<T> &A, Mat<T> &U, std::vector<T> &s, Mat<T> &V);
+// Partial-pivot LU inverse; stands in for Eigen dynamic .inverse() (qr_wholebody_impulse_ctrl.cpp:55).
+template <typename T> Mat<T> luInverse(const Mat<T> &A);
+
+// ---------------------------------------------------------------------------
+// Dense strictly-convex QP, Goldfarb-Idnani dual active set, double precision.
+//   min 1/2 x'Gx + g0'x   s.t.  CE'x + ce0 = 0,  CI'x + ci0 >= 0
+// (the QuadProg++ convention, QX/QuadProgpp/src/QuadProg++.hh:8-23; CE is n x p,
+// CI is n x m, row-major).  Returns 0 ok, 1 infeasible, 2 iteration cap.
+// ---------------------------------------------------------------------------
+struct QpStats { int iters = 0, adds = 0, drops = 0, n_active = 0; double obj = 0; };
+int qp_solve_gi(int n, const double *G, const double *g0, int p, const double *CE, const double *ce0,
+                int m, const double *CI, const double *ci0, double *x, double *lambda_ineq /*m or null*/,
+                QpStats *st, int max_iter = 0);
+
+// ---------------------------------------------------------------------------
+// MPC (K1-K7).  QS/controllers/mpc/qr_mpc_interface.cpp, qr_mpc_stance_leg_controller.cpp
+// ---------------------------------------------------------------------------
+constexpr int kMaxHorizon = 16;   // K_MAX_GAIT_SEGMENTS, QI/controllers/mpc/qr_mpc_interface.h:33
+
+struct MpcConfig {                // ProblemConfig + body inertia (qr_mpc_interface.h:104-144)
+    float dt = 0.06f; int horizon = 10; float mu = 0.45f; float fmax = 13.f * 9.81f;
+    float mass = 13.f; float inertia[3] = {0.24f, 0.80f, 1.0f};
+    float weights[12] = {10, 10, 5, 40, 60, 100, 0, 0, 0.5f, 5, 5, 1}; float alpha = 4e-6f;
+};
+struct MpcInput {                 // arguments of SolveMPCKernel (qr_mpc_interface.h:200)
+    float p[3], v[3], quat[4] /*wxyz*/, w[3], r[12] /*3x4 column-major: r[3*leg+axis]*/, rpy[3];
+    float traj[12 * kMaxHorizon]; float gait[4 * kMaxHorizon];
+};
+struct MpcAssembly {              // fp32 QP data exactly as SolveMPC builds it (:359-425)
+    int n = 0, m = 0;
+    std::vector<float> H, g;      // n*n row-major, n
+    std::vector<float> ub;        // m (lb = 0)
+    float invmu = 0;
+};
+void mpc_assemble(const MpcConfig &cfg, const MpcInput &in, MpcAssembly &out);
+// Literal variant of ConvertToDiscreteQP (:257-293): fp32 Pade expm + repeated products.
+// Used only to quantify how far the closed form is from a literal evaluation.
+void mpc_assemble_literal(const MpcConfig &cfg, const MpcInput &in, MpcAssembly &out);
+// Solve the assembled QP (double, own GI solver on the swing-eliminated problem).
+int mpc_solve_qp(const MpcAssembly &a, const float *gait, int horizon, double *u_out /*n*/, QpStats *st);
+// K7: force -> (f_ff, torque).  qr_mpc_stance_leg_controller.cpp:402-409,139-153; QS/robots/qr_robot.cpp:148-172,241-251
+struct LegGeom { float hip_l = 0.08505f, upper_l = 0.2f, lower_l = 0.2f; };
+void mpc_force_to_torque(const LegGeom &geo, const float quat[4], const float q[12], const double f_world[12], float tau[12]);
+void analytical_leg_jacobian(const LegGeom &geo, const float q[3], int leg, float J[9] /*row-major*/);
+void foot_positions_in_base_frame(const LegGeom &geo, const float hipOffset[12], const float q[12], float out[12]); // QS/robots/qr_robot.cpp:127-146,175-184
+
+// ---------------------------------------------------------------------------
+// Floating-base model (K8-K10).  QS/dynamics/floating_base_model.cpp, QI/dynamics/spatial.hpp,
+// constants QS/robots/qr_robot_a1_sim.cpp:176-343
+// ---------------------------------------------------------------------------
+struct ModelDesc {                // what BuildDynamicModel hard-codes / reads from YAML
+    float hip_l = 0.08505f, upper_l = 0.2f, lower_l = 0.2f;
+    float body_size[3] = {0.267f, 0.194f, 0.114f};
+};
+template <typename T> struct FBModel;          // defined in qr_oracle_fbmodel.cpp
+template <typename T> struct FBState { T quat[4]; T pos[3]; T bodyVel[6]; T q[12]; T qd[12]; };
+template <typename T> struct FBResult {
+    Mat<T> H{18, 18}; Mat<T> G{18, 1}; Mat<T> C{18, 1};
+    Mat<T> Jc[4]; Mat<T> Jcdqd[4]; T pGC[4][3]; T vGC[4][3];   // feet only (ids 9,11,13,15)
+    T totalNonRotorMass = 0;
+};
+template <typename T> void fb_compute(const ModelDesc &md, const FBState<T> &st, FBResult<T> &out);
+
+// ---------------------------------------------------------------------------
+// WBC (K11-K14).  QS/controllers/wbc/*.cpp
+// ---------------------------------------------------------------------------
+template <typename T> struct WbcCmd {          // qrWbcCtrlData, QI/controllers/qr_state_dataflow.h:133-192
+    T pBody_des[3], vBody_des[3], aBody_des[3], pBody_RPY_des[3], vBody_Ori_des[3];
+    T pFoot_des[4][3], vFoot_des[4][3], aFoot_des[4][3], Fr_des[4][3];
+    int contact[4];
+};
+template <typename T> struct WbcOut {
+    T tau[12];        // jointTorqueCmd
+    T qdes[12], qddes[12];   // desiredJPos / desiredJVel (K12)
+    T fr[12];         // optimalFr, stance feet in contact order, zero padded
+    T qddot[18];
+    int qp_status; QpStats qp;
+};
+// prev_ori_vel: in/out, TK::desiredVel of the orientation task from the previous call (quirk 4).
+template <typename T> void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd,
+                                   T prev_ori_vel[3], WbcOut<T> &out);
+
+}  // namespace qro

@@ -1,0 +1,176 @@
+"""Deterministic synthetic per-tick inputs for batches of quadrupeds.
+
+Pure numpy host code.  Produces, robot-major (AoS, shape [n, k], float32):
+  mpc_state[n,28] = p, v_world, quat_wxyz, w_world, r (3x4 col-major: foot - CoM, world aligned), rpy
+                    -- the arguments of SolveMPCKernel (qr_mpc_interface.h:200) as
+                    SolveDenseMPC prepares them (qr_mpc_stance_leg_controller.cpp:385-399)
+  traj[n,12h]      -- trajAll of UpdateMPC (qr_mpc_stance_leg_controller.cpp:361-376)
+  gait[n,4h]       -- mpcTable, row-major h x 4 (:283-303)
+  fb_state[n,37]   = quat_wxyz, pos, [omega_body, v_body], q, qd  (FBModelState, floating_base_model.hpp:29-44)
+  wbc_cmd[n,67]    = qrWbcCtrlData fields (qr_state_dataflow.h:133-192), contact as 0/1 floats
+The device API takes the transposed (SoA, [k, n]) arrays: see qrgpu.to_soa().
+"""
+import numpy as np
+
+f32 = np.float32
+
+ROBOTS = {
+    # Q/config/a1_sim/a1_sim.yaml, stance_leg_controller.yaml; SURVEY.md 8 "Constants"
+    "a1": dict(type_id=0, mass=13.0, inertia=(0.24, 0.80, 1.0),
+               weights=(10, 10, 5, 40, 60, 100, 0, 0, 0.5, 5, 5, 1),
+               hip_l=0.08505, upper_l=0.2, lower_l=0.2, body_size=(0.267, 0.194, 0.114),
+               com_offset=(-0.008, 0.005, 0.0),
+               hip_offset=((0.1805, -0.047, 0.0), (0.1805, 0.047, 0.0), (-0.1805, -0.047, 0.0), (-0.1805, 0.047, 0.0))),
+    # Q/config/lite3_sim/robot.yaml, stance_leg_controller.yaml
+    "lite3": dict(type_id=1, mass=8.742, inertia=(0.24, 0.8, 1.0),
+                  weights=(20, 20, 10, 40, 40, 150, 0.5, 1, 1, 5, 5, 10),
+                  hip_l=0.0985, upper_l=0.20, lower_l=0.20, body_size=(0.349, 0.124, 0.15),
+                  com_offset=(-0.012, 0.0, 0.0),
+                  hip_offset=((0.175, -0.062, 0.0), (0.175, 0.062, 0.0), (-0.175, -0.062, 0.0), (-0.175, 0.062, 0.0))),
+}
+DT_MPC = 0.06      # qr_mpc_stance_leg_controller.cpp:43
+MU_MPC = 0.45      # :90
+ALPHA = 4e-6       # :85
+
+
+def mpc_cfg(robot="a1"):
+    """Packed float32[20]: dt, mu, fmax, mass, inertia[3], weights[12], alpha (SetupProblem arguments, :83-90)."""
+    r = ROBOTS[robot]
+    return np.array([DT_MPC, MU_MPC, r["mass"] * 9.81, r["mass"], *r["inertia"], *r["weights"], ALPHA], dtype=f32)
+
+
+def model_desc(robot="a1"):
+    """Packed float32[6]: hip_l, upper_l, lower_l, body_size[3] (the YAML-dependent part of BuildDynamicModel)."""
+    r = ROBOTS[robot]
+    return np.array([r["hip_l"], r["upper_l"], r["lower_l"], *r["body_size"]], dtype=f32)
+
+
+def _rot_body_to_world(rpy):
+    """R = Rz(yaw) Ry(pitch) Rx(roll), batched [n,3,3]."""
+    cr, sr = np.cos(rpy[:, 0]), np.sin(rpy[:, 0])
+    cp, sp = np.cos(rpy[:, 1]), np.sin(rpy[:, 1])
+    cy, sy = np.cos(rpy[:, 2]), np.sin(rpy[:, 2])
+    R = np.empty((rpy.shape[0], 3, 3))
+    R[:, 0, 0] = cy * cp; R[:, 0, 1] = cy * sp * sr - sy * cr; R[:, 0, 2] = cy * sp * cr + sy * sr
+    R[:, 1, 0] = sy * cp; R[:, 1, 1] = sy * sp * sr + cy * cr; R[:, 1, 2] = sy * sp * cr - cy * sr
+    R[:, 2, 0] = -sp;     R[:, 2, 1] = cp * sr;                R[:, 2, 2] = cp * cr
+    return R
+
+
+def _quat_from_rpy(rpy):
+    """(w,x,y,z) of R = Rz Ry Rx."""
+    hr, hp, hy = rpy[:, 0] / 2, rpy[:, 1] / 2, rpy[:, 2] / 2
+    cr, sr, cp, sp, cy, sy = np.cos(hr), np.sin(hr), np.cos(hp), np.sin(hp), np.cos(hy), np.sin(hy)
+    q = np.stack([cr * cp * cy + sr * sp * sy,
+                  sr * cp * cy - cr * sp * sy,
+                  cr * sp * cy + sr * cp * sy,
+                  cr * cp * sy - sr * sp * cy], axis=1)
+    return q
+
+
+def _foot_positions_base(r, q):
+    """qrRobot::FootPositionsInBaseFrame (QS/robots/qr_robot.cpp:127-146,175-184), batched [n,4,3]."""
+    n = q.shape[0]
+    out = np.empty((n, 4, 3))
+    lu, ll = r["upper_l"], r["lower_l"]
+    for leg in range(4):
+        tab, thip, tknee = q[:, 3 * leg], q[:, 3 * leg + 1], q[:, 3 * leg + 2]
+        sh = r["hip_l"] * (-1.0) ** (leg + 1)
+        ld = np.sqrt(lu * lu + ll * ll + 2 * lu * ll * np.cos(tknee))
+        eff = thip + tknee / 2
+        ox, oz, oy = -ld * np.sin(eff), -ld * np.cos(eff), sh
+        out[:, leg, 0] = ox + r["hip_offset"][leg][0]
+        out[:, leg, 1] = np.cos(tab) * oy - np.sin(tab) * oz + r["hip_offset"][leg][1]
+        out[:, leg, 2] = np.sin(tab) * oy + np.cos(tab) * oz + r["hip_offset"][leg][2]
+    return out
+
+
+def make_batch(n, horizon=10, robot="a1", seed=0xA1, frac_all_stance=0.05, frac_three_leg=0.05, excite=1.0):
+    """n robots of one type.  Returns a dict of float32 AoS arrays (see module docstring).
+
+    excite scales the tracking errors the MPC has to remove (roll/pitch, angular rate,
+    velocity mismatch, vertical velocity).  excite=1.0 is SURVEY.md 8d's full range, under
+    which a good share of the QPs need more than qpOASES' nWSR=100 working-set changes (the
+    reference then returns a non-optimal point); excite=0.3 keeps trot QPs
+    inside that cap and is the default of the bench workload."""
+    r = ROBOTS[robot]
+    rng = np.random.default_rng(seed)
+    U = rng.uniform
+    h = horizon
+    # base state
+    e = float(excite)
+    rpy = np.stack([e * U(-0.15, 0.15, n), e * U(-0.15, 0.15, n), U(-np.pi, np.pi, n)], axis=1)
+    R = _rot_body_to_world(rpy)
+    quat = _quat_from_rpy(rpy)
+    pos = np.stack([U(-1, 1, n), U(-1, 1, n), 0.27 + U(-0.03, 0.03, n)], axis=1)
+    v_w = np.stack([U(-0.5, 0.5, n), U(-0.5, 0.5, n), e * U(-0.1, 0.1, n)], axis=1)
+    w_w = e * U(-0.5, 0.5, (n, 3))
+    # joints: stand pose (0, 0.8+-0.2, -1.6+-0.3), abad U(-0.2,0.2)
+    q = np.empty((n, 12)); qd = U(-1, 1, (n, 12))
+    for leg in range(4):
+        q[:, 3 * leg] = U(-0.2, 0.2, n)
+        q[:, 3 * leg + 1] = 0.8 + U(-0.2, 0.2, n)
+        q[:, 3 * leg + 2] = -1.6 + U(-0.3, 0.3, n)
+    foot_b = _foot_positions_base(r, q)                                   # [n,4,3]
+    r_w = np.einsum("nij,nlj->nli", R, foot_b - np.asarray(r["com_offset"]))   # R (foot - comOffset)
+    # gait table: trot, duty 0.6, random phase; dPhase = 1/(numHorizonL*h), numHorizonL = 2  (:50,:284)
+    duty = 0.6
+    phase0 = U(0, 1, n)
+    offs = np.array([0.0, 0.5, 0.5, 0.0])
+    dphase = 1.0 / (2 * h)
+    ph = (phase0[:, None, None] + offs[None, None, :] + dphase * np.arange(h)[None, :, None]) % 1.0
+    gait = (ph < duty).astype(np.float64)                                  # [n,h,4]
+    kind = U(0, 1, n)
+    all_st = kind < frac_all_stance
+    three = (kind >= frac_all_stance) & (kind < frac_all_stance + frac_three_leg)
+    gait[all_st] = 1.0
+    sw_leg = rng.integers(0, 4, n)
+    for i in np.nonzero(three)[0]:
+        gait[i] = 1.0
+        gait[i, :, sw_leg[i]] = 0.0
+    contact = gait[:, 0, :].copy()
+    # reference trajectory (UpdateMPC :361-376)
+    vdes_b = np.stack([U(-0.5, 1.0, n), U(-0.3, 0.3, n), np.zeros(n)], axis=1)
+    v_b_now = np.einsum("nji,nj->ni", R, v_w)
+    vdes_b[:, :2] = v_b_now[:, :2] + e * (vdes_b[:, :2] - v_b_now[:, :2])     # e=1: independent command
+    vdes_w = np.einsum("nij,nj->ni", R, vdes_b)
+    yaw_rate = w_w[:, 2] + e * (U(-0.5, 0.5, n) - w_w[:, 2])
+    yaw_des = rpy[:, 2] + U(-0.05, 0.05, n)
+    x0 = pos[:, 0] + U(-0.05, 0.05, n); y0 = pos[:, 1] + U(-0.05, 0.05, n)
+    height = np.full(n, 0.27)
+    traj = np.zeros((n, h, 12))
+    traj[:, :, 5] = height[:, None]
+    traj[:, :, 8] = yaw_rate[:, None]
+    traj[:, :, 9] = vdes_w[:, 0:1]; traj[:, :, 10] = vdes_w[:, 1:2]
+    k = np.arange(h)[None, :]
+    traj[:, :, 2] = yaw_des[:, None] + DT_MPC * k * yaw_rate[:, None]
+    traj[:, :, 3] = x0[:, None] + DT_MPC * k * vdes_w[:, 0:1]
+    traj[:, :, 4] = y0[:, None] + DT_MPC * k * vdes_w[:, 1:2]
+    # MPC state
+    mpc_state = np.concatenate([pos, v_w, quat, w_w, r_w.reshape(n, 12), rpy], axis=1)
+    # floating-base state (body-frame velocities)
+    w_b = np.einsum("nji,nj->ni", R, w_w); v_b = np.einsum("nji,nj->ni", R, v_w)
+    fb_state = np.concatenate([quat, pos, w_b, v_b, q, qd], axis=1)
+    # WBC command
+    foot_w = pos[:, None, :] + np.einsum("nij,nlj->nli", R, foot_b)
+    pBody = np.stack([x0, y0, height + U(-0.01, 0.01, n)], axis=1)
+    cmd = np.zeros((n, 67))
+    cmd[:, 0:3] = pBody
+    cmd[:, 3:6] = np.stack([vdes_w[:, 0], vdes_w[:, 1], np.zeros(n)], axis=1)
+    cmd[:, 9:12] = np.stack([np.zeros(n), np.zeros(n), yaw_des], axis=1)
+    cmd[:, 12:15] = np.stack([np.zeros(n), np.zeros(n), yaw_rate], axis=1)
+    cmd[:, 15:27] = (foot_w + U(-0.05, 0.05, (n, 4, 3))).reshape(n, 12)
+    cmd[:, 27:39] = U(-0.5, 0.5, (n, 12))
+    cmd[:, 39:51] = U(-2.0, 2.0, (n, 12))
+    nst = np.maximum(contact.sum(axis=1), 1.0)
+    cmd[:, 51:63] = (contact[:, :, None] * np.array([0.0, 0.0, 1.0]) * (r["mass"] * 9.81 / nst)[:, None, None]).reshape(n, 12)
+    cmd[:, 63:67] = contact
+    return dict(robot=robot, horizon=h, n=n,
+                mpc_state=mpc_state.astype(f32), traj=traj.reshape(n, 12 * h).astype(f32),
+                gait=gait.reshape(n, 4 * h).astype(f32), fb_state=fb_state.astype(f32), wbc_cmd=cmd.astype(f32),
+                prev_ori_vel=np.zeros((n, 3), f32))
+
+
+def to_soa(a):
+    """[n,k] robot-major -> [k,n] field-major contiguous (robot index fastest: coalesced device loads)."""
+    return np.ascontiguousarray(np.asarray(a).T)
