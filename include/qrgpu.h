@@ -1,0 +1,148 @@
+/* ============================================================================
+ * qrgpu.h -- C ABI of libqrgpu.so: batched convex-MPC + WBC control ticks for
+ * quadrupeds on AMD MI355X (gfx950).  Plain pointers and sizes only; no C++,
+ * torch or HIP types appear in any signature (the stream is passed as void*).
+ *
+ * Each entry point replaces one seam of TopHillRobotics/quadruped-robot
+ * ("QI/" = quadruped/include/quadruped/, "QS/" = quadruped/src/):
+ *
+ *   qrgpu_mpc_setup        <- Quadruped::SetupProblem          QI/controllers/mpc/qr_mpc_interface.h:157
+ *   qrgpu_mpc_solve1       <- Quadruped::SolveMPCKernel + 12x GetMPCSolution   :200, :215
+ *   qrgpu_mpc_solve_batch  <- the same, for n independent robots (MPCStanceLegController::SolveDenseMPC
+ *                             + GetAction torque map, QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:385-410,129-156)
+ *   qrgpu_wbc_setup        <- qrRobot*::BuildDynamicModel + qrWbcLocomotionController ctor gains
+ *                             QS/robots/qr_robot_a1_sim.cpp:176-343, QS/controllers/wbc/qr_wbc_locomotion_controller.cpp:29-77
+ *   qrgpu_wbc_run1         <- qrWbcLocomotionController<float>::Run   QI/controllers/wbc/qr_wbc_locomotion_controller.hpp:59
+ *   qrgpu_wbc_run_batch    <- the same, for n robots
+ *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
+ *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
+ *
+ * Error behaviour mirrors the reference: no exceptions; the reference prints
+ * "failed to solve!" and carries on (qr_mpc_interface.cpp:440-442) -- here every
+ * robot gets a status word instead and every call returns a qrgpu_error.
+ *
+ * All computation runs in hand-written HIP kernels.  There is NO CPU fallback:
+ * without a usable gfx950 device qrgpu_create fails with QRGPU_ERR_NO_DEVICE.
+ *
+ * Batched layouts are structure-of-arrays, [field][robot] with the robot index
+ * fastest (array element (f, i) at f*n + i), float32, device memory:
+ *   mpc_state [28][n] : p[3], v_world[3], quat_wxyz[4], w_world[3], r[12] (3x4 column-major:
+ *                       r[3*leg+axis], foot - CoM in the world-aligned frame), rpy[3]
+ *   traj      [12h][n]: desired state per horizon step (rpy, xyz, omega, v), step-major
+ *   gait      [4h][n] : contact table, step-major (row-major h x 4, as mpcTable)
+ *   fb_state  [37][n] : quat_wxyz[4], pos[3], omega_body[3], v_body[3], q[12], qd[12]   (FBModelState)
+ *   wbc_cmd   [67][n] : pBody_des[3], vBody_des[3], aBody_des[3], pBody_RPY_des[3], vBody_Ori_des[3],
+ *                       pFoot_des[12], vFoot_des[12], aFoot_des[12], Fr_des[12], contact[4] (0/1)  (qrWbcCtrlData)
+ *   prev_ori  [3][n]  : in/out, desiredVel of the body-orientation task from the previous WBC call
+ *                       (stateful quirk of task_set/qr_task_body_orientation.cpp:68 vs :73)
+ *   force     [12][n] : MPC ground-reaction forces of horizon step 0, world frame (= wbcData.Fr_des)
+ *   tau       [12][n] : joint torques
+ * ========================================================================== */
+#ifndef QRGPU_H
+#define QRGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QRGPU_MAX_HORIZON 16      /* K_MAX_GAIT_SEGMENTS, QI/controllers/mpc/qr_mpc_interface.h:33 */
+#define QRGPU_MAX_TYPES   4       /* robot types (parameter sets) per context */
+
+typedef struct qrgpu_ctx qrgpu_ctx;
+
+typedef enum {
+    QRGPU_OK = 0,
+    QRGPU_ERR_NO_DEVICE = 1,      /* no gfx950 device / HIP runtime failure at create */
+    QRGPU_ERR_BAD_ARG = 2,
+    QRGPU_ERR_NOT_SETUP = 3,      /* solve before setup */
+    QRGPU_ERR_LAUNCH = 4,         /* kernel launch or runtime error (see qrgpu_last_error) */
+    QRGPU_ERR_ALLOC = 5
+} qrgpu_error;
+
+/* Per-robot status word written by the kernels (bit field). */
+#define QRGPU_ST_OK            0
+#define QRGPU_ST_MPC_MAXITER   0x1    /* active-set iteration cap reached            */
+#define QRGPU_ST_MPC_INFEAS    0x2    /* QP reported infeasible (cannot happen: u=0 is feasible) */
+#define QRGPU_ST_MPC_OVERFLOW  0x4    /* working set outgrew its LDS allotment       */
+#define QRGPU_ST_MPC_NOTSPD    0x8    /* Hessian pivot <= 0                          */
+#define QRGPU_ST_WBC_MAXITER   0x10
+#define QRGPU_ST_WBC_INFEAS    0x20
+
+/* What BuildDynamicModel reads from YAML plus what the WBC controller hard-codes.
+ * Defaults (qrgpu_model_desc_default) are the A1 values. */
+typedef struct {
+    float hip_l, upper_l, lower_l;        /* robot_params.hip_l / upper_l / lower_l          */
+    float body_size[3];                   /* robot_params.body_size (unused by the torque path) */
+    float kp_body_pos, kd_body_pos;       /* 100 / 10   qr_wbc_locomotion_controller.cpp:62-63 */
+    float kp_body_ori, kd_body_ori;       /* 100 / 10   :66-67 */
+    float kp_foot, kd_foot;               /* 500 / 10   :70-71 */
+    float weight_fb, weight_fr;           /* 0.1 / 1    :44-45 */
+    float mu;                             /* 0.4        QS/controllers/wbc/qr_single_contact.cpp:34 */
+} qrgpu_model_desc;
+
+void qrgpu_model_desc_default(qrgpu_model_desc *d);
+
+/* ---- lifetime -------------------------------------------------------------- */
+/* device_id: HIP device ordinal.  max_batch: largest n of any batched call. */
+int  qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out);
+void qrgpu_destroy(qrgpu_ctx *ctx);
+/* Launch on this hipStream_t (NULL = the default stream). */
+int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
+const char *qrgpu_last_error(const qrgpu_ctx *ctx);
+/* Device facts for reports: returns CU count, writes name (<= len). */
+int  qrgpu_device_info(const qrgpu_ctx *ctx, char *name, int len, int *lds_per_cu_bytes);
+
+/* ---- setup (SetupProblem / BuildDynamicModel) ------------------------------- */
+int qrgpu_mpc_setup(qrgpu_ctx *ctx, int type_id, float dt, int horizon, float mu, float fmax, float mass,
+                    const float inertia[3], const float weights[12], float alpha);
+int qrgpu_wbc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_model_desc *desc);
+
+/* ---- batched device-pointer API (the measured path) -------------------------- */
+/* d_type_id may be NULL (all robots type 0).  d_q: joint angles [12][n] (needed by the
+ * J^T f torque map; pass fb_state + 13*n to reuse the WBC state).  d_status may be NULL. */
+int qrgpu_mpc_solve_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_mpc_state,
+                          const float *d_traj, const float *d_gait, const float *d_q,
+                          float *d_force, float *d_tau_mpc, int *d_status);
+int qrgpu_wbc_run_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_fb_state,
+                        const float *d_wbc_cmd, float *d_prev_ori, float *d_tau,
+                        float *d_qdes /* [24][n]: desiredJPos, desiredJVel; may be NULL */, int *d_status);
+/* Full tick: MPC, then WBC with Fr_des := that MPC's forces (the Fr_des rows of d_wbc_cmd are ignored).
+ * d_tau receives the WBC torque on stance legs and the MPC J^T f torque on swing legs
+ * (UpdateLegCMD only overwrites stance legs, qr_wbc_locomotion_controller.cpp:205-219). */
+int qrgpu_tick_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_mpc_state,
+                     const float *d_traj, const float *d_gait, const float *d_fb_state,
+                     const float *d_wbc_cmd, float *d_prev_ori, float *d_force, float *d_tau, int *d_status);
+
+/* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */
+int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float v[3], const float quat_wxyz[4],
+                     const float w[3], const float r_3x4_colmajor[12], const float rpy[3],
+                     const float *traj /*12h*/, const float *gait /*4h*/, const float q[12] /*may be NULL*/,
+                     double f_out[12], float tau_out[12] /*may be NULL*/, int *status);
+int qrgpu_wbc_run1(qrgpu_ctx *ctx, int type_id, const float fb_state[37], const float wbc_cmd[67],
+                   float prev_ori_vel[3], float tau_out[12], float qdes_out[12], float qddes_out[12], int *status);
+
+/* ---- inspection (parity tests): the fp32 QP data the MPC kernel assembled ----- */
+/* d_H: [n][12h*12h] row-major per robot, d_g: [n][12h]; entries that involve a swing
+ * (eliminated) variable are left untouched. */
+int qrgpu_mpc_assemble_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_mpc_state,
+                             const float *d_traj, const float *d_gait, float *d_H, float *d_g);
+/* Rigid-body quantities the WBC kernel computed: d_out [n][QRGPU_FB_DEBUG_FLOATS]
+ * = H(324) G(18) C(18) Jc(4*54) Jcdqd(12) pGC(12) vGC(12). */
+#define QRGPU_FB_DEBUG_FLOATS (324 + 18 + 18 + 216 + 12 + 12 + 12)
+int qrgpu_fb_debug_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_fb_state, float *d_out);
+
+/* ---- plumbing ------------------------------------------------------------------ */
+int  qrgpu_sync(qrgpu_ctx *ctx);                       /* hipStreamSynchronize on the context stream */
+/* Mean device time (ms) of the kernels launched by the last `calls` batched calls,
+ * measured with hipEvents on the context stream; kernel: 0 = MPC, 1 = WBC. */
+int  qrgpu_enable_timing(qrgpu_ctx *ctx, int on);
+int  qrgpu_get_timing(qrgpu_ctx *ctx, int kernel, double *mean_ms, int *count);
+void *qrgpu_malloc(qrgpu_ctx *ctx, unsigned long long bytes);   /* hipMalloc on the context device */
+void qrgpu_free(qrgpu_ctx *ctx, void *p);
+int  qrgpu_memcpy_h2d(qrgpu_ctx *ctx, void *dst, const void *src, unsigned long long bytes);
+int  qrgpu_memcpy_d2h(qrgpu_ctx *ctx, void *dst, const void *src, unsigned long long bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QRGPU_H */

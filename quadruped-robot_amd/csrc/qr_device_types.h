@@ -1,0 +1,67 @@
+// Shared host/device plain structs for the qrgpu kernels (gfx950).
+#pragma once
+#include <stdint.h>
+
+namespace qrgpu {
+
+#define QR_QH 96                  // hard cap on the MPC working-set size (rows of S^-1 held in LDS)
+#define QR_MAX_TYPES 4
+
+// status bits (mirror include/qrgpu.h)
+#define QRGPU_ST_MPC_MAXITER_D  0x1
+#define QRGPU_ST_MPC_INFEAS_D   0x2
+#define QRGPU_ST_MPC_OVERFLOW_D 0x4
+#define QRGPU_ST_MPC_NOTSPD_D   0x8
+#define QRGPU_ST_WBC_MAXITER_D  0x10
+#define QRGPU_ST_WBC_INFEAS_D   0x20
+
+// SetupProblem arguments (QI/controllers/mpc/qr_mpc_interface.h:157) + leg geometry for J^T f.
+struct MpcType {
+    float dt, mu, fmax, mass;
+    float inertia[3];
+    float weights[12];
+    float alpha;
+    float hip_l, upper_l, lower_l;
+};
+
+struct MpcLaunch {
+    MpcType type[QR_MAX_TYPES];
+    int n;
+    int horizon;
+    int lds_bytes;
+};
+
+// Bytes of LDS in front of the packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
+static inline size_t mpc_lds_fixed_bytes(int h)
+{
+    const size_t NV = 12 * (size_t)h, NL = 4 * (size_t)h;
+    size_t b = 8 * (4 * NV + 3 * QR_QH + NL);                    // xv wv zv yv dv rv uv fmk
+    b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);          // sT sU sSt sTraj sGait sV
+    b += 4 * (NL + QR_QH);                                       // sLs sAct
+    b += 2 * (6 * NL + ((6 * NL) & 1));                          // sPos
+    b += 4 * 4;                                                  // sMisc
+    return (b + 7) & ~(size_t)7;
+}
+
+// WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)
+// reduced to rigid-body parameters, plus the controller gains (include/qrgpu.h qrgpu_model_desc).
+// rb[k] = {m, h[3] (= m*com), Ibar[6] (about the link origin: xx yy zz xy xz yz)}.
+#define QR_RB_BASE      0   // floating base link
+#define QR_RB_BASE_EFF  1   // + the four abad rotors (constant in the base frame)
+#define QR_RB_ABAD      2   // +side: 0 = right legs (mirrored), 1 = left legs
+#define QR_RB_ABAD_EFF  4   // + hip rotor
+#define QR_RB_HIP       6
+#define QR_RB_HIP_EFF   8   // + knee rotor
+#define QR_RB_KNEE      10  // same link inertia on both sides (:322 leaves it unmirrored)
+struct WbcConst {
+    double rb[11][10];
+    double abad_loc[3];           // (0.1805, 0.047, 0) before leg signs
+    double hip_l, upper_l, lower_l, foot_y;
+    double k_rot;                 // rotor rotational inertia = Srot' Irot Srot (gear ratio 1)
+    double hiprot_ex, hiprot_ey;  // E_rot^T e_y of the hip rotor frame (Rz(pi))
+    double max_fz;                // totalNonRotorMass() * 9.81   (qr_single_contact.cpp:31)
+    double kp_pos, kd_pos, kp_ori, kd_ori, kp_foot, kd_foot;
+    double w_fb, w_fr, mu;
+};
+
+}  // namespace qrgpu

@@ -1,0 +1,856 @@
+// ============================================================================
+// Whole-body-control tick for a batch of quadrupeds: one 64-lane wavefront
+// (= one workgroup) per robot, all matrices LDS-resident, fp64 arithmetic on the
+// fp32 inputs.  gfx950 (MI355X) only.
+//
+// Replaces, per robot (reference: TopHillRobotics/quadruped-robot, QS/ = quadruped/src/):
+//   K8  FloatingBaseModel::forwardKinematics / biasAccelerations   QS/dynamics/floating_base_model.cpp:469-524,587-600
+//   K9  compositeInertias / massMatrix / generalizedGravityForce / generalizedCoriolisForce   :750-806,607-665
+//   K10 contactJacobians                                            :541-580
+//   K11 task_set/*.cpp UpdateTask, qrSingleContact::UpdateContactSpec, ContactTaskUpdate
+//       (QS/controllers/wbc/qr_wbc_locomotion_controller.cpp:172-201)
+//   K12 qrMultitaskProjection::FindConfiguration                    QS/controllers/wbc/qr_multitask_projection.cpp:38-106
+//   K13 qrWholeBodyImpulseCtrl::GetModelRes / MakeTorque            QS/controllers/wbc/qr_wholebody_impulse_ctrl.cpp:50-299
+//   K14 UpdateLegCMD (stance legs take the WBC torque)              qr_wbc_locomotion_controller.cpp:205-219
+//
+// Structure: lanes 0-3 walk one leg each through the kinematic tree with 3-vector
+// / rigid-body-inertia (m, h, Ibar) algebra instead of generic 6x6 products; the
+// 18x18 / n x 18 dense algebra (A^-1 by symmetric sweep, null-space recursions,
+// Gram-matrix pseudo-inverses with an eigenvalue guard + Jacobi fallback that
+// reproduces pseudoInverse()'s singular-value cut, the relaxation QP by a
+// Schur-complement Goldfarb-Idnani) runs lane-parallel over matrix elements.
+// Rotor bodies (1e-8 kg, gear 1): their constant isotropic inertia is folded into the
+// parent link on the host, the +k on H(j,j) and the k*axis coupling term are kept,
+// their gravity term is exactly zero and their Coriolis term (<= 1e-7 N m) is dropped.
+// ============================================================================
+#include <hip/hip_runtime.h>
+#include "qr_device_types.h"
+
+namespace qrgpu {
+
+typedef double real;
+
+struct v3 { real x, y, z; };
+__device__ __forceinline__ v3 mk(real x, real y, real z) { v3 r = {x, y, z}; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(real s, v3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ real dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+struct m3 { real m[3][3]; };
+__device__ __forceinline__ v3 mul(const m3 &A, v3 b)
+{
+    return mk(A.m[0][0] * b.x + A.m[0][1] * b.y + A.m[0][2] * b.z, A.m[1][0] * b.x + A.m[1][1] * b.y + A.m[1][2] * b.z,
+              A.m[2][0] * b.x + A.m[2][1] * b.y + A.m[2][2] * b.z);
+}
+__device__ __forceinline__ v3 mulT(const m3 &A, v3 b)
+{
+    return mk(A.m[0][0] * b.x + A.m[1][0] * b.y + A.m[2][0] * b.z, A.m[0][1] * b.x + A.m[1][1] * b.y + A.m[2][1] * b.z,
+              A.m[0][2] * b.x + A.m[1][2] * b.y + A.m[2][2] * b.z);
+}
+__device__ __forceinline__ m3 mul(const m3 &A, const m3 &B)
+{
+    m3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return C;
+}
+__device__ __forceinline__ m3 transpose(const m3 &A)
+{
+    m3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[j][i];
+    return C;
+}
+// coordinateRotation (QI/utils/qr_se3.h:72-89): the coordinate-transform (transposed) matrix.
+__device__ __forceinline__ m3 coord_rot(int axis, real th)
+{
+    real s, c;
+    sincos(th, &s, &c);
+    m3 R;
+    if (axis == 0)      { R = {{{1, 0, 0}, {0, c, s}, {0, -s, c}}}; }
+    else if (axis == 1) { R = {{{c, 0, -s}, {0, 1, 0}, {s, 0, c}}}; }
+    else                { R = {{{c, s, 0}, {-s, c, 0}, {0, 0, 1}}}; }
+    return R;
+}
+// quaternionToRotationMatrix (:186-203): world -> body.
+__device__ __forceinline__ m3 quat_to_rot_wb(const real *q)
+{
+    const real e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];
+    m3 R;
+    R.m[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); R.m[1][0] = 2 * (e1 * e2 - e0 * e3); R.m[2][0] = 2 * (e1 * e3 + e0 * e2);
+    R.m[0][1] = 2 * (e1 * e2 + e0 * e3); R.m[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); R.m[2][1] = 2 * (e2 * e3 - e0 * e1);
+    R.m[0][2] = 2 * (e1 * e3 - e0 * e2); R.m[1][2] = 2 * (e2 * e3 + e0 * e1); R.m[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    return R;
+}
+
+// Rigid-body spatial inertia [[Ibar, [h]x],[[h]x^T, m 1]] as (m, h, Ibar sym: xx yy zz xy xz yz).
+struct rbi { real m; v3 h; real I[6]; };
+__device__ __forceinline__ rbi rbi_load(const real *p) { rbi r; r.m = p[0]; r.h = mk(p[1], p[2], p[3]); for (int i = 0; i < 6; ++i) r.I[i] = p[4 + i]; return r; }
+__device__ __forceinline__ v3 rbi_Iw(const rbi &a, v3 w)
+{
+    return mk(a.I[0] * w.x + a.I[3] * w.y + a.I[4] * w.z, a.I[3] * w.x + a.I[1] * w.y + a.I[5] * w.z, a.I[4] * w.x + a.I[5] * w.y + a.I[2] * w.z);
+}
+__device__ __forceinline__ rbi rbi_add(const rbi &a, const rbi &b)
+{
+    rbi r; r.m = a.m + b.m; r.h = a.h + b.h;
+    for (int i = 0; i < 6; ++i) r.I[i] = a.I[i] + b.I[i];
+    return r;
+}
+// Express a child-frame inertia in the parent frame: X^T I X with X = (E, r)  (createSXform(E, r)).
+__device__ __forceinline__ rbi rbi_to_parent(const rbi &a, const m3 &E, v3 r)
+{
+    rbi o;
+    o.m = a.m;
+    const v3 hr = mulT(E, a.h);                    // E^T h
+    o.h = hr + a.m * r;
+    // Ibar' = E^T Ibar E - [r]x[hr]x - [h']x[r]x
+    m3 I; I.m[0][0] = a.I[0]; I.m[1][1] = a.I[1]; I.m[2][2] = a.I[2];
+    I.m[0][1] = I.m[1][0] = a.I[3]; I.m[0][2] = I.m[2][0] = a.I[4]; I.m[1][2] = I.m[2][1] = a.I[5];
+    m3 Ir = mul(transpose(E), mul(I, E));
+    // -[a]x[b]x = (a.b) 1 - b a^T
+    auto add_outer = [&](v3 a_, v3 b_) {
+        const real ab = dot(a_, b_);
+        const real av[3] = {a_.x, a_.y, a_.z}, bv[3] = {b_.x, b_.y, b_.z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Ir.m[i][j] += (i == j ? ab : 0.0) - bv[i] * av[j];
+    };
+    add_outer(r, hr);
+    add_outer(o.h, r);
+    o.I[0] = Ir.m[0][0]; o.I[1] = Ir.m[1][1]; o.I[2] = Ir.m[2][2];
+    o.I[3] = 0.5 * (Ir.m[0][1] + Ir.m[1][0]); o.I[4] = 0.5 * (Ir.m[0][2] + Ir.m[2][0]); o.I[5] = 0.5 * (Ir.m[1][2] + Ir.m[2][1]);
+    return o;
+}
+struct sv6 { v3 a, l; };      // spatial vector (angular; linear)
+__device__ __forceinline__ sv6 xmotion(const m3 &E, v3 r, sv6 v) { sv6 o; o.a = mul(E, v.a); o.l = mul(E, v.l - cross(r, v.a)); return o; }   // X v
+__device__ __forceinline__ sv6 xforceT(const m3 &E, v3 r, sv6 f) { sv6 o; o.l = mulT(E, f.l); o.a = mulT(E, f.a) + cross(r, o.l); return o; }   // X^T f
+__device__ __forceinline__ sv6 rbi_mul(const rbi &I, sv6 v) { sv6 o; o.a = rbi_Iw(I, v.a) + cross(I.h, v.l); o.l = I.m * v.l - cross(I.h, v.a); return o; }
+__device__ __forceinline__ sv6 crf(sv6 v, sv6 f) { sv6 o; o.a = cross(v.a, f.a) + cross(v.l, f.l); o.l = cross(v.a, f.l); return o; }   // v x* f
+__device__ __forceinline__ sv6 crm(sv6 v, sv6 u) { sv6 o; o.a = cross(v.a, u.a); o.l = cross(v.a, u.l) + cross(v.l, u.a); return o; }   // v x u
+
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ real wsum(real v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// C(m x n) = alpha * op(A)(m x k) * op(B)(k x n) + beta * C0 ; lane-parallel over outputs, ends with wsync.
+// tA: A stored k x m (use A^T);  tB: B stored n x k (use B^T).
+__device__ __forceinline__ void gemm(int lane, real *C, int ldc, const real *A, int lda, bool tA, const real *B, int ldb, bool tB,
+                                     int m, int n, int k, real alpha = 1.0, real beta = 0.0, const real *C0 = nullptr, int ldc0 = 0)
+{
+    for (int e = lane; e < m * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        real acc = 0.0;
+        for (int t = 0; t < k; ++t) acc += (tA ? A[t * lda + i] : A[i * lda + t]) * (tB ? B[j * ldb + t] : B[t * ldb + j]);
+        real v = alpha * acc;
+        if (C0) v += beta * C0[i * ldc0 + j];
+        C[i * ldc + j] = v;
+    }
+    wsync();
+}
+
+// In-place inverse of a symmetric positive definite n x n matrix (full storage, ld) by symmetric sweeps.
+// col: scratch n.  Returns (uniform) the smallest pivot seen.
+__device__ __forceinline__ real spd_inverse(int lane, real *A, int ld, int n, real *col)
+{
+    real minpiv = 1e300;
+    for (int k = 0; k < n; ++k) {
+        for (int i = lane; i < n; i += 64) col[i] = A[i * ld + k];
+        wsync();
+        const real piv = col[k];
+        minpiv = piv < minpiv ? piv : minpiv;
+        const real ip = 1.0 / piv;
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            real v;
+            if (i == k) v = (j == k) ? -ip : col[j] * ip;
+            else if (j == k) v = col[i] * ip;
+            else v = A[i * ld + j] - col[i] * col[j] * ip;
+            A[i * ld + j] = v;
+        }
+        wsync();
+    }
+    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * ld + j] = -A[i * ld + j]; }
+    wsync();
+    return minpiv;
+}
+
+// pseudoInverse() of a symmetric PSD matrix W (n x n, n <= 12) with eigenvalue cut `thr`
+// (QI/utils/qr_algebra.h:119-141: singular values <= thr are dropped; strict '>').
+// Fast path: plain inverse when every eigenvalue provably exceeds thr; otherwise Jacobi
+// eigen-decomposition on lane 0.  Winv may not alias W.  scr: >= n*n + n doubles.
+__device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real thr, real *Winv, real *scr)
+{
+    if (n == 1) {   // 1x1 special case compares the entry itself (quirk 7)
+        if (lane == 0) Winv[0] = (W[0] > thr) ? 1.0 / W[0] : 0.0;
+        wsync();
+        return;
+    }
+    for (int e = lane; e < n * n; e += 64) Winv[e] = W[e];
+    wsync();
+    const real minpiv = spd_inverse(lane, Winv, n, n, scr);
+    real fro = 0.0;
+    for (int e = lane; e < n * n; e += 64) fro += Winv[e] * Winv[e];
+    fro = wsum(fro);
+    // lambda_min >= 1/||W^-1||_2 >= 1/||W^-1||_F
+    const bool full_rank = (minpiv > 0.0) && (fro == fro) && (1.0 > thr * __builtin_sqrt(fro));
+    if (full_rank) return;
+    // Rank-revealing path (rare: kinematic singularities).  Cyclic Jacobi on lane 0.
+    if (lane == 0) {
+        real *Am = scr;            // n*n working copy
+        real *V = Winv;            // eigenvectors accumulate here
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) { Am[i * n + j] = 0.5 * (W[i * n + j] + W[j * n + i]); V[i * n + j] = (i == j) ? 1.0 : 0.0; }
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            real off = 0.0;
+            for (int p = 0; p < n; ++p) for (int q2 = p + 1; q2 < n; ++q2) off += Am[p * n + q2] * Am[p * n + q2];
+            if (off < 1e-40) break;
+            for (int p = 0; p < n - 1; ++p)
+                for (int q2 = p + 1; q2 < n; ++q2) {
+                    const real apq = Am[p * n + q2];
+                    if (apq == 0.0) continue;
+                    const real th = (Am[q2 * n + q2] - Am[p * n + p]) / (2.0 * apq);
+                    const real t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + __builtin_sqrt(th * th + 1.0));
+                    const real c = 1.0 / __builtin_sqrt(t * t + 1.0), s = t * c;
+                    for (int k = 0; k < n; ++k) { const real akp = Am[k * n + p], akq = Am[k * n + q2]; Am[k * n + p] = c * akp - s * akq; Am[k * n + q2] = s * akp + c * akq; }
+                    for (int k = 0; k < n; ++k) { const real apk = Am[p * n + k], aqk = Am[q2 * n + k]; Am[p * n + k] = c * apk - s * aqk; Am[q2 * n + k] = s * apk + c * aqk; }
+                    for (int k = 0; k < n; ++k) { const real vkp = V[k * n + p], vkq = V[k * n + q2]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q2] = s * vkp + c * vkq; }
+                }
+        }
+        // Winv = V diag(1/l if l > thr) V^T   (singular values of a PSD matrix are |eigenvalues|)
+        real *ev = scr + n * n;
+        for (int i = 0; i < n; ++i) { const real l = fabs(Am[i * n + i]); ev[i] = (l > thr) ? 1.0 / Am[i * n + i] : 0.0; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Am[i * n + j] = V[i * n + j] * ev[j];      // V D
+        real *tmp = scr + n * n + n;   // n*n more
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { real a = 0; for (int k = 0; k < n; ++k) a += Am[i * n + k] * V[j * n + k]; tmp[i * n + j] = a; }
+        for (int e = 0; e < n * n; ++e) Winv[e] = tmp[e];
+    }
+    wsync();
+}
+
+#define QR_WBC_LDS_DOUBLES 4608
+
+__global__ __launch_bounds__(64)
+void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
+                   const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
+                   float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
+                   float *__restrict__ g_dbg, int merge_tau, int status_or)
+{
+    const int rid = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (rid >= n) return;
+    const WbcConst &K = types[type_id ? type_id[rid] : 0];
+
+    __shared__ real sm[QR_WBC_LDS_DOUBLES];
+    real *A = sm;                  // 324  mass matrix
+    real *Ai = A + 324;            // 324  A^-1
+    real *Np = Ai + 324;           // 324  null-space projector
+    real *T1 = Np + 324;           // 324
+    real *T2 = T1 + 324;           // 324
+    real *JcA = T2 + 324;          // 4 x 54   foot Jacobians (3x18 each)
+    real *JC = JcA + 216;          // 12 x 18  stacked contact Jacobian
+    real *JB = JC + 216;           // 18 x 12  JcBar / pinv
+    real *Jt = JB + 216;           // 3 x 18
+    real *JtP = Jt + 54;           // 3 x 18
+    real *JtB = JtP + 54;          // 18 x 3
+    real *lam = JtB + 54;          // 144
+    real *lamI = lam + 144;        // 144
+    real *scr = lamI + 144;        // 144*2 + 16 = 304
+    real *st = scr + 304;          // 37 state
+    real *cm = st + 40;            // 67 cmd
+    real *Gv = cm + 68;            // 18
+    real *Cv = Gv + 18;            // 18
+    real *qdd = Cv + 18;           // 18
+    real *tv = qdd + 18;           // 18 scratch vector
+    real *tv2 = tv + 18;           // 18
+    real *Jcd = tv2 + 18;          // 12 Jcdqd
+    real *pGC = Jcd + 12;          // 12
+    real *vGC = pGC + 12;          // 12
+    real *tkX = vGC + 12;          // 6 tasks x 3: xddot
+    real *tkE = tkX + 18;          // posErr
+    real *tkV = tkE + 18;          // desiredVel
+    real *legB = tkV + 18;         // 4 x 16: per-leg contributions to the base (rbi 10, fvp 6)
+    real *dq1 = legB + 64;         // 18 delta_q
+    real *dq2 = dq1 + 18;          // 18 qdot
+    real *Nq = dq2 + 18;           // 30 x 18 QP constraint normals
+    real *Sq = Nq + 540;           // 18 x 18 S^-1
+    real *qd_ = Sq + 324;          // 32 d
+    real *qr_ = qd_ + 32;          // 32 r
+    real *qu_ = qr_ + 32;          // 32 u
+    real *qc0 = qu_ + 32;          // 32 constraint offsets
+    real *qx = qc0 + 32;           // 18 z
+    real *qw = qx + 18;            // 18
+    real *qz = qw + 18;            // 18
+    __shared__ int sI[64];         // task kinds / active list
+
+    // ---------------- load ----------------
+    if (lane < 37) st[lane] = (real)g_state[(size_t)lane * n + rid];
+    if (g_tau) for (int i = lane; i < 67; i += 64) cm[i] = (real)g_cmd[(size_t)i * n + rid];
+    for (int e = lane; e < 324; e += 64) A[e] = 0.0;
+    for (int e = lane; e < 216; e += 64) JcA[e] = 0.0;
+    wsync();
+    const real *quat = st, *pos = st + 4, *bv = st + 7, *qj = st + 13, *qdj = st + 25;
+    const m3 Rwb = quat_to_rot_wb(quat);        // world -> body  (E of Xup[5])
+
+    // ---------------- K8-K10 per leg (lanes 0-3) ----------------
+    if (lane < 4) {
+        const int leg = lane, side = leg & 1;   // side 0: right (legs 0,2; sideSign<0), 1: left
+        const real sx = (leg < 2) ? 1.0 : -1.0, sy = side ? 1.0 : -1.0;
+        const v3 r_a = mk(sx * K.abad_loc[0], sy * K.abad_loc[1], K.abad_loc[2]);
+        const v3 r_h = mk(0.0, sy * K.hip_l, 0.0);
+        const v3 r_k = mk(0.0, 0.0, -K.upper_l);
+        const v3 loc = mk(0.0, side ? -K.foot_y : K.foot_y, -K.lower_l);
+        const real q0 = qj[3 * leg], q1 = qj[3 * leg + 1], q2 = qj[3 * leg + 2];
+        const real d0 = qdj[3 * leg], d1 = qdj[3 * leg + 1], d2 = qdj[3 * leg + 2];
+        const m3 Ea = coord_rot(0, q0), Eh = coord_rot(1, q1), Ek = coord_rot(1, q2);
+        const v3 ex = mk(1, 0, 0), ey = mk(0, 1, 0);
+        // velocities, bias accelerations
+        sv6 v5; v5.a = mk(bv[0], bv[1], bv[2]); v5.l = mk(bv[3], bv[4], bv[5]);
+        sv6 va = xmotion(Ea, r_a, v5); sv6 vJa; vJa.a = d0 * ex; vJa.l = mk(0, 0, 0); va.a = va.a + vJa.a;
+        sv6 ca = crm(va, vJa);
+        sv6 vh = xmotion(Eh, r_h, va); sv6 vJh; vJh.a = d1 * ey; vJh.l = mk(0, 0, 0); vh.a = vh.a + vJh.a;
+        sv6 ch = crm(vh, vJh);
+        sv6 vk = xmotion(Ek, r_k, vh); sv6 vJk; vJk.a = d2 * ey; vJk.l = mk(0, 0, 0); vk.a = vk.a + vJk.a;
+        sv6 ck = crm(vk, vJk);
+        sv6 aa = ca;
+        sv6 ah = xmotion(Eh, r_h, aa); ah.a = ah.a + ch.a; ah.l = ah.l + ch.l;
+        sv6 ak = xmotion(Ek, r_k, ah); ak.a = ak.a + ck.a; ak.l = ak.l + ck.l;
+        // absolute rotations (world -> link) and link origins in the world
+        const m3 Eabs_a = mul(Ea, Rwb), Eabs_h = mul(Eh, Eabs_a), Eabs_k = mul(Ek, Eabs_h);
+        // Foot position / velocity exactly as forwardKinematics does it (:506-521): through the bottom-left
+        // block of Xa and invertSXform / sXFormPoint, which use E^T as E^-1.  With the float-rounded (not
+        // exactly unit) quaternion of the state this differs from the textbook sum of offsets by O(|q|^2-1) * 1 m,
+        // which the foot task's Kp = 500 would turn into 1e-5 N m.
+        {
+            auto skewm = [](v3 r) { m3 S = {{{0, -r.z, r.y}, {r.z, 0, -r.x}, {-r.y, r.x, 0}}}; return S; };
+            auto neg = [](const m3 &A_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = -A_.m[i][j]; return C_; };
+            auto addm = [](const m3 &A_, const m3 &B_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = A_.m[i][j] + B_.m[i][j]; return C_; };
+            auto unskew = [](const m3 &M_) { return mk(0.5 * (M_.m[2][1] - M_.m[1][2]), 0.5 * (M_.m[0][2] - M_.m[2][0]), 0.5 * (M_.m[1][0] - M_.m[0][1])); };   // matToSkewVec
+            const v3 p5 = mk(pos[0], pos[1], pos[2]);
+            const m3 B5 = neg(mul(Rwb, skewm(p5)));                                              // createSXform(R, pos) bottom-left
+            const m3 Ba = addm(mul(neg(mul(Ea, skewm(r_a))), Rwb), mul(Ea, B5));                 // Xup[a] * Xa[5]
+            const m3 Bh = addm(mul(neg(mul(Eh, skewm(r_h))), Eabs_a), mul(Eh, Ba));
+            const m3 Bk = addm(mul(neg(mul(Ek, skewm(r_k))), Eabs_h), mul(Ek, Bh));
+            const m3 E = Eabs_k, Et = transpose(Eabs_k);
+            const v3 r1 = (-1.0) * unskew(mul(Et, Bk));                                          // invertSXform: r
+            const v3 Er1 = mul(E, r1);
+            const m3 BLi = mul(Et, skewm(Er1));                                                  // Xai bottom-left = -E^T [-E r]x
+            const v3 rp = (-1.0) * unskew(mul(E, BLi));                                          // translationFromSXform(Xai)
+            const v3 pf = mul(Et, loc - rp);                                                     // sXFormPoint
+            const v3 wS = mul(Et, vk.a);
+            const v3 vS = mul(BLi, vk.a) + mul(Et, vk.l);
+            const v3 vf = vS + cross(wS, pf);                                                    // spatialToLinearVelocity
+            pGC[3 * leg] = pf.x; pGC[3 * leg + 1] = pf.y; pGC[3 * leg + 2] = pf.z;
+            vGC[3 * leg] = vf.x; vGC[3 * leg + 1] = vf.y; vGC[3 * leg + 2] = vf.z;
+        }
+        // Jcdqd = Rai [ (a_lin + a_ang x loc) + w x (v_lin + w x loc) ]
+        {
+            const v3 t = (ak.l + cross(ak.a, loc)) + cross(vk.a, vk.l + cross(vk.a, loc));
+            const v3 jd = mulT(Eabs_k, t);
+            Jcd[3 * leg] = jd.x; Jcd[3 * leg + 1] = jd.y; Jcd[3 * leg + 2] = jd.z;
+        }
+        // contact Jacobian columns: world velocity of the foot per unit generalized velocity
+        {
+            real *J = JcA + 54 * leg;
+            const v3 lk = loc;                               // foot in knee frame
+            const v3 lh = r_k + mulT(Ek, lk);                // foot in hip frame
+            const v3 la = r_h + mulT(Eh, lh);                // foot in abad frame
+            const v3 lb = r_a + mulT(Ea, la);                // foot in base frame
+            const v3 ck_ = mulT(Eabs_k, cross(ey, lk)), ch_ = mulT(Eabs_h, cross(ey, lh)), ca_ = mulT(Eabs_a, cross(ex, la));
+            const int c0 = 6 + 3 * leg;
+            J[0 * 18 + c0] = ca_.x; J[1 * 18 + c0] = ca_.y; J[2 * 18 + c0] = ca_.z;
+            J[0 * 18 + c0 + 1] = ch_.x; J[1 * 18 + c0 + 1] = ch_.y; J[2 * 18 + c0 + 1] = ch_.z;
+            J[0 * 18 + c0 + 2] = ck_.x; J[1 * 18 + c0 + 2] = ck_.y; J[2 * 18 + c0 + 2] = ck_.z;
+            // base: angular columns Rbw (e_i x lb), linear columns Rbw e_i
+            const v3 e[3] = {mk(1, 0, 0), mk(0, 1, 0), mk(0, 0, 1)};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const v3 ang = mulT(Rwb, cross(e[i], lb)), lin = mulT(Rwb, e[i]);
+                J[0 * 18 + i] = ang.x; J[1 * 18 + i] = ang.y; J[2 * 18 + i] = ang.z;
+                J[0 * 18 + 3 + i] = lin.x; J[1 * 18 + 3 + i] = lin.y; J[2 * 18 + 3 + i] = lin.z;
+            }
+        }
+        // composite inertias (rotor constants are folded into the *_eff parents on the host)
+        const rbi Ik = rbi_load(K.rb[QR_RB_KNEE]);
+        const rbi Ih = rbi_load(K.rb[QR_RB_HIP + side]), Ih_e = rbi_load(K.rb[QR_RB_HIP_EFF + side]);
+        const rbi Ia = rbi_load(K.rb[QR_RB_ABAD + side]), Ia_e = rbi_load(K.rb[QR_RB_ABAD_EFF + side]);
+        const rbi ICk = Ik;
+        const rbi ICh = rbi_add(Ih_e, rbi_to_parent(ICk, Ek, r_k));
+        const rbi ICa = rbi_add(Ia_e, rbi_to_parent(ICh, Eh, r_h));
+        const rbi ICa_b = rbi_to_parent(ICa, Ea, r_a);
+        real *LB = legB + 16 * leg;
+        LB[0] = ICa_b.m; LB[1] = ICa_b.h.x; LB[2] = ICa_b.h.y; LB[3] = ICa_b.h.z;
+        for (int i = 0; i < 6; ++i) LB[4 + i] = ICa_b.I[i];
+        // mass-matrix columns (massMatrix :774-806)
+        const real kr = K.k_rot;
+        const int ja = 6 + 3 * leg, jh = ja + 1, jk = ja + 2;
+        auto base_col = [&](int j, sv6 f) {     // f expressed in the base frame
+            const real fv[6] = {f.a.x, f.a.y, f.a.z, f.l.x, f.l.y, f.l.z};
+            for (int i = 0; i < 6; ++i) { A[i * 18 + j] = fv[i]; A[j * 18 + i] = fv[i]; }
+        };
+        {   // knee
+            sv6 S; S.a = ey; S.l = mk(0, 0, 0);
+            sv6 f = rbi_mul(ICk, S);
+            A[jk * 18 + jk] = f.a.y + kr;
+            f = xforceT(Ek, r_k, f); f.a.y += kr;                 // + Xuprot^T (Irot Srot): knee rotor, E_rot = 1
+            A[jh * 18 + jk] = A[jk * 18 + jh] = f.a.y;
+            f = xforceT(Eh, r_h, f);
+            A[ja * 18 + jk] = A[jk * 18 + ja] = f.a.x;
+            f = xforceT(Ea, r_a, f);
+            base_col(jk, f);
+        }
+        {   // hip
+            sv6 S; S.a = ey; S.l = mk(0, 0, 0);
+            sv6 f = rbi_mul(ICh, S);
+            A[jh * 18 + jh] = f.a.y + kr;
+            f = xforceT(Eh, r_h, f); f.a.x += kr * K.hiprot_ex; f.a.y += kr * K.hiprot_ey;   // hip rotor: E_rot = Rz(pi)
+            A[ja * 18 + jh] = A[jh * 18 + ja] = f.a.x;
+            f = xforceT(Ea, r_a, f);
+            base_col(jh, f);
+        }
+        {   // abad
+            sv6 S; S.a = ex; S.l = mk(0, 0, 0);
+            sv6 f = rbi_mul(ICa, S);
+            A[ja * 18 + ja] = f.a.x + kr;
+            f = xforceT(Ea, r_a, f); f.a.x += kr;
+            base_col(ja, f);
+        }
+        // gravity (:607-626): ag_i = [0; E_abs_i g], G[i] = -S_i . (IC_i ag_i) = -axis . (h_i x a_i)
+        {
+            const v3 gw = mk(0, 0, -9.81);
+            const v3 g_a = mul(Eabs_a, gw), g_h = mul(Eabs_h, gw), g_k = mul(Eabs_k, gw);
+            Gv[ja] = -cross(ICa.h, g_a).x;
+            Gv[jh] = -cross(ICh.h, g_h).y;
+            Gv[jk] = -cross(ICk.h, g_k).y;
+        }
+        // Coriolis (:633-665) with link inertias
+        {
+            sv6 fk = rbi_mul(Ik, ak); { sv6 c = crf(vk, rbi_mul(Ik, vk)); fk.a = fk.a + c.a; fk.l = fk.l + c.l; }
+            sv6 fh = rbi_mul(Ih, ah); { sv6 c = crf(vh, rbi_mul(Ih, vh)); fh.a = fh.a + c.a; fh.l = fh.l + c.l; }
+            sv6 fa = rbi_mul(Ia, aa); { sv6 c = crf(va, rbi_mul(Ia, va)); fa.a = fa.a + c.a; fa.l = fa.l + c.l; }
+            Cv[jk] = fk.a.y;
+            { sv6 t = xforceT(Ek, r_k, fk); fh.a = fh.a + t.a; fh.l = fh.l + t.l; }
+            Cv[jh] = fh.a.y;
+            { sv6 t = xforceT(Eh, r_h, fh); fa.a = fa.a + t.a; fa.l = fa.l + t.l; }
+            Cv[ja] = fa.a.x;
+            sv6 t = xforceT(Ea, r_a, fa);
+            LB[10] = t.a.x; LB[11] = t.a.y; LB[12] = t.a.z; LB[13] = t.l.x; LB[14] = t.l.y; LB[15] = t.l.z;
+        }
+    }
+    wsync();
+    // ---------------- base block (lane 0) ----------------
+    if (lane == 0) {
+        rbi IC5 = rbi_load(K.rb[QR_RB_BASE_EFF]);
+        sv6 fb; fb.a = mk(0, 0, 0); fb.l = mk(0, 0, 0);
+        for (int l = 0; l < 4; ++l) {
+            const real *LB = legB + 16 * l;
+            rbi c = rbi_load(LB);
+            IC5 = rbi_add(IC5, c);
+            fb.a = fb.a + mk(LB[10], LB[11], LB[12]); fb.l = fb.l + mk(LB[13], LB[14], LB[15]);
+        }
+        // H[0:6,0:6] = IC5 as a 6x6
+        const real I6[3][3] = {{IC5.I[0], IC5.I[3], IC5.I[4]}, {IC5.I[3], IC5.I[1], IC5.I[5]}, {IC5.I[4], IC5.I[5], IC5.I[2]}};
+        const real hx[3][3] = {{0, -IC5.h.z, IC5.h.y}, {IC5.h.z, 0, -IC5.h.x}, {-IC5.h.y, IC5.h.x, 0}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                A[i * 18 + j] = I6[i][j];
+                A[i * 18 + 3 + j] = hx[i][j];
+                A[(3 + i) * 18 + j] = hx[j][i];
+                A[(3 + i) * 18 + 3 + j] = (i == j) ? IC5.m : 0.0;
+            }
+        // G[0:6] = -IC5 [0; a5],  a5 = Rwb g
+        const v3 a5 = mul(Rwb, mk(0, 0, -9.81));
+        const v3 gt = cross(IC5.h, a5);
+        Gv[0] = -gt.x; Gv[1] = -gt.y; Gv[2] = -gt.z; Gv[3] = -IC5.m * a5.x; Gv[4] = -IC5.m * a5.y; Gv[5] = -IC5.m * a5.z;
+        // C[0:6] = fvp5 + sum of leg contributions; fvp5 = v5 x* (I5 v5)  (avp5 = 0)
+        const rbi I5 = rbi_load(K.rb[QR_RB_BASE]);
+        sv6 v5; v5.a = mk(bv[0], bv[1], bv[2]); v5.l = mk(bv[3], bv[4], bv[5]);
+        const sv6 c5 = crf(v5, rbi_mul(I5, v5));
+        Cv[0] = c5.a.x + fb.a.x; Cv[1] = c5.a.y + fb.a.y; Cv[2] = c5.a.z + fb.a.z;
+        Cv[3] = c5.l.x + fb.l.x; Cv[4] = c5.l.y + fb.l.y; Cv[5] = c5.l.z + fb.l.z;
+    }
+    wsync();
+    if (g_dbg) {
+        float *o = g_dbg + (size_t)rid * (324 + 18 + 18 + 216 + 36);
+        for (int e = lane; e < 324; e += 64) o[e] = (float)A[e];
+        if (lane < 18) { o[324 + lane] = (float)Gv[lane]; o[342 + lane] = (float)Cv[lane]; }
+        for (int e = lane; e < 216; e += 64) o[360 + e] = (float)JcA[e];
+        if (lane < 12) { o[576 + lane] = (float)Jcd[lane]; o[588 + lane] = (float)pGC[lane]; o[600 + lane] = (float)vGC[lane]; }
+        if (!g_tau) return;
+    }
+
+    // ---------------- K13 GetModelRes: A^-1 ----------------
+    for (int e = lane; e < 324; e += 64) Ai[e] = A[e];
+    wsync();
+    spd_inverse(lane, Ai, 18, 18, tv);
+
+    // ---------------- K11 tasks and contacts ----------------
+    // task list: 0 = body orientation, 1 = body position, then swing feet in leg order; contacts: stance feet.
+    int nc = 0, nt = 2;
+    int cleg[4], tleg[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { if (cm[63 + l] != 0.0) cleg[nc++] = l; else tleg[nt++ - 2] = l; }
+    if (lane == 0) {
+        const m3 RotT = transpose(Rwb);
+        // --- orientation task (qr_task_body_orientation.cpp:43-81)
+        {
+            // quatDes = rpyToQuat(pBody_RPY_des): rotationMatrixToQuaternion(rpyToRotMat(rpy))
+            const m3 Rr = mul(mul(coord_rot(0, cm[9]), coord_rot(1, cm[10])), coord_rot(2, cm[11]));
+            const m3 r = transpose(Rr);
+            real qd4[4];
+            const real tr = r.m[0][0] + r.m[1][1] + r.m[2][2];
+            if (tr > 0.0) {
+                const real S = __builtin_sqrt(tr + 1.0) * 2.0;
+                qd4[0] = 0.25 * S; qd4[1] = (r.m[2][1] - r.m[1][2]) / S; qd4[2] = (r.m[0][2] - r.m[2][0]) / S; qd4[3] = (r.m[1][0] - r.m[0][1]) / S;
+            } else if ((r.m[0][0] > r.m[1][1]) && (r.m[0][0] > r.m[2][2])) {
+                const real S = __builtin_sqrt(1.0 + r.m[0][0] - r.m[1][1] - r.m[2][2]) * 2.0;
+                qd4[0] = (r.m[2][1] - r.m[1][2]) / S; qd4[1] = 0.25 * S; qd4[2] = (r.m[0][1] + r.m[1][0]) / S; qd4[3] = (r.m[0][2] + r.m[2][0]) / S;
+            } else if (r.m[1][1] > r.m[2][2]) {
+                const real S = __builtin_sqrt(1.0 + r.m[1][1] - r.m[0][0] - r.m[2][2]) * 2.0;
+                qd4[0] = (r.m[0][2] - r.m[2][0]) / S; qd4[1] = (r.m[0][1] + r.m[1][0]) / S; qd4[2] = 0.25 * S; qd4[3] = (r.m[1][2] + r.m[2][1]) / S;
+            } else {
+                const real S = __builtin_sqrt(1.0 + r.m[2][2] - r.m[0][0] - r.m[1][1]) * 2.0;
+                qd4[0] = (r.m[1][0] - r.m[0][1]) / S; qd4[1] = (r.m[0][2] + r.m[2][0]) / S; qd4[2] = (r.m[1][2] + r.m[2][1]) / S; qd4[3] = 0.25 * S;
+            }
+            // ori_err = quatProduct(ori_cmd, conj(link_ori))
+            const real r1 = qd4[0], r2 = quat[0];
+            const v3 v1 = mk(qd4[1], qd4[2], qd4[3]), v2 = mk(-quat[1], -quat[2], -quat[3]);
+            real e0 = r1 * r2 - dot(v1, v2);
+            v3 ev = r1 * v2 + r2 * v1 + cross(v1, v2);
+            if (e0 < 0.0) { e0 = -e0; ev = (-1.0) * ev; }
+            // quaternionToso3 (qr_se3.h:383-397)
+            v3 so3 = ev;
+            const real theta = 2.0 * asin(__builtin_sqrt(dot(so3, so3)));
+            if (fabs(theta) < 0.0000001) so3 = mk(0, 0, 0);
+            else { const real sn = sin(theta / 2.0); so3 = (1.0 / sn) * so3; so3 = theta * so3; }
+            // vel_err = Rot^T (desiredVel_prev - omega_body)   (quirk 4)
+            const v3 pv = mk((real)g_prev[(size_t)0 * n + rid], (real)g_prev[(size_t)1 * n + rid], (real)g_prev[(size_t)2 * n + rid]);
+            const v3 ve = mul(RotT, pv - mk(bv[0], bv[1], bv[2]));
+            const real so[3] = {so3.x, so3.y, so3.z}, vev[3] = {ve.x, ve.y, ve.z};
+            for (int i = 0; i < 3; ++i) {
+                tkE[i] = so[i];
+                tkV[i] = cm[12 + i];
+                real x = K.kp_ori * so[i] + K.kd_ori * vev[i] + 0.0;
+                tkX[i] = fmin(fmax(x, -10.0), 10.0);
+                g_prev[(size_t)i * n + rid] = (float)cm[12 + i];
+            }
+        }
+        // --- position task (qr_task_body_position.cpp:43-67)
+        {
+            const v3 vw = mul(RotT, mk(bv[3], bv[4], bv[5]));
+            const real vwv[3] = {vw.x, vw.y, vw.z};
+            for (int i = 0; i < 3; ++i) {
+                const real pe = cm[i] - pos[i];
+                tkE[3 + i] = pe;
+                tkV[3 + i] = cm[3 + i];
+                real x = K.kp_pos * pe + K.kd_pos * (cm[3 + i] - vwv[i]) + cm[6 + i];
+                tkX[3 + i] = fmin(fmax(x, -10.0), 10.0);
+            }
+        }
+        // --- swing-foot tasks (qr_task_link_position.cpp:45-68), no clamp
+        for (int t = 2; t < nt; ++t) {
+            const int l = tleg[t - 2];
+            for (int i = 0; i < 3; ++i) {
+                const real pe = cm[15 + 3 * l + i] - pGC[3 * l + i];
+                tkE[3 * t + i] = pe;
+                tkV[3 * t + i] = cm[27 + 3 * l + i];
+                tkX[3 * t + i] = K.kp_foot * pe + K.kd_foot * (cm[27 + 3 * l + i] - vGC[3 * l + i]) + cm[39 + 3 * l + i];
+            }
+        }
+    }
+    // stacked contact Jacobian
+    for (int e = lane; e < 54 * nc; e += 64) { const int k = e / 54; JC[e] = JcA[54 * cleg[k] + (e - 54 * k)]; }
+    wsync();
+    const int dimFr = 3 * nc;
+    const m3 RotT = transpose(Rwb);
+    // task Jacobian loader: Jt <- task t
+    auto load_Jt = [&](int t) {
+        for (int e = lane; e < 54; e += 64) {
+            const int i = e / 18, j = e - 18 * i;
+            real v = 0.0;
+            if (t == 0) { if (j < 3) v = RotT.m[i][j]; }
+            else if (t == 1) { if (j >= 3 && j < 6) v = RotT.m[i][j - 3]; }
+            else { v = (j < 6) ? 0.0 : JcA[54 * tleg[t - 2] + e]; }        // virtualDepend = false: base columns zeroed
+            Jt[e] = v;
+        }
+        wsync();
+    };
+
+    // ---------------- K12 kinematic multitask projection (only when its outputs are requested) ----------------
+    if (g_qdes) {
+        const real thr2 = 1e-6;       // singular value > 1e-3  <=>  eigenvalue of J J^T > 1e-6
+        // Nc = I - pinv(Jc) Jc
+        if (nc > 0) {
+            gemm(lane, lam, dimFr, JC, 18, false, JC, 18, true, dimFr, dimFr, 18);          // Jc Jc^T
+            psd_pinv(lane, lam, dimFr, thr2, lamI, scr);
+            gemm(lane, JB, dimFr, JC, 18, true, lamI, dimFr, false, 18, dimFr, dimFr);        // pinv = Jc^T W^+
+            gemm(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
+            for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
+            wsync();
+        } else {
+            for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
+            wsync();
+        }
+        for (int t = 0; t < nt; ++t) {
+            load_Jt(t);
+            gemm(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                   // JtPre = Jt N_pre
+            gemm(lane, lam, 3, JtP, 18, false, JtP, 18, true, 3, 3, 18);
+            psd_pinv(lane, lam, 3, thr2, lamI, scr);
+            gemm(lane, JtB, 3, JtP, 18, true, lamI, 3, false, 18, 3, 3);                    // pinv(JtPre) 18x3
+            // delta_q = prev + pinv (posErr - Jt prev),  qdot likewise
+            if (lane < 6) {
+                const int which = lane / 3, i = lane - 3 * which;
+                const real *prevv = which ? dq2 : dq1;
+                const real *tgt = which ? (tkV + 3 * t) : (tkE + 3 * t);
+                real acc = tgt[i];
+                if (t > 0) for (int k = 0; k < 18; ++k) acc -= Jt[i * 18 + k] * prevv[k];
+                tv[lane] = acc;
+            }
+            wsync();
+            if (lane < 36) {
+                const int which = lane / 18, i = lane - 18 * which;
+                real *vec = which ? dq2 : dq1;
+                real acc = (t > 0) ? vec[i] : 0.0;
+                for (int k = 0; k < 3; ++k) acc += JtB[i * 3 + k] * tv[3 * which + k];
+                scr[lane] = acc;
+            }
+            wsync();
+            if (lane < 36) { if (lane < 18) dq1[lane] = scr[lane]; else dq2[lane - 18] = scr[lane]; }
+            wsync();
+            if (t < nt - 1) {
+                // N_pre <- N_pre (I - pinv JtPre)
+                gemm(lane, T1, 18, JtB, 3, false, JtP, 18, false, 18, 18, 3, -1.0);
+                for (int i = lane; i < 18; i += 64) T1[i * 18 + i] += 1.0;
+                wsync();
+                gemm(lane, T2, 18, Np, 18, false, T1, 18, false, 18, 18, 18);
+                for (int e = lane; e < 324; e += 64) Np[e] = T2[e];
+                wsync();
+            }
+        }
+        if (lane < 12) {
+            g_qdes[(size_t)lane * n + rid] = (float)(qj[lane] + dq1[6 + lane]);
+            g_qdes[(size_t)(12 + lane) * n + rid] = (float)dq2[6 + lane];
+        }
+        wsync();
+    }
+
+    // ---------------- K13 MakeTorque: prioritized acceleration recursion ----------------
+    const real thrW = 1e-4;       // WeightedInverse default threshold (qr_wholebody_impulse_ctrl.hpp:110)
+    if (dimFr > 0) {
+        gemm(lane, T1, dimFr, Ai, 18, false, JC, 18, true, 18, dimFr, 18);               // temp = Ainv Jc^T   (18 x dimFr)
+        gemm(lane, lam, dimFr, JC, 18, false, T1, dimFr, false, dimFr, dimFr, 18);       // lambda = Jc temp
+        psd_pinv(lane, lam, dimFr, thrW, lamI, scr);
+        gemm(lane, JB, dimFr, T1, dimFr, false, lamI, dimFr, false, 18, dimFr, dimFr);   // JcBar
+        if (lane < 18) { real acc = 0.0; for (int k = 0; k < dimFr; ++k) acc -= JB[lane * dimFr + k] * Jcd[3 * cleg[k / 3] + k % 3]; qdd[lane] = acc; }
+        gemm(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
+        for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
+        wsync();
+    } else {
+        if (lane < 18) qdd[lane] = 0.0;
+        for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
+        wsync();
+    }
+    for (int t = 0; t < nt; ++t) {
+        load_Jt(t);
+        gemm(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                    // JtPre = Jt Npre
+        gemm(lane, T1, 3, Ai, 18, false, JtP, 18, true, 18, 3, 18);                      // temp = Ainv JtPre^T (18x3)
+        gemm(lane, lam, 3, JtP, 18, false, T1, 3, false, 3, 3, 18);
+        psd_pinv(lane, lam, 3, thrW, lamI, scr);
+        gemm(lane, JtB, 3, T1, 3, false, lamI, 3, false, 18, 3, 3);                      // JtBar
+        if (lane < 3) {
+            real acc = tkX[3 * t + lane] - ((t >= 2) ? Jcd[3 * tleg[t - 2] + lane] : 0.0);
+            for (int k = 0; k < 18; ++k) acc -= Jt[lane * 18 + k] * qdd[k];
+            tv[lane] = acc;
+        }
+        wsync();
+        if (lane < 18) qdd[lane] += JtB[lane * 3] * tv[0] + JtB[lane * 3 + 1] * tv[1] + JtB[lane * 3 + 2] * tv[2];
+        wsync();
+        if (t < nt - 1) {
+            gemm(lane, T1, 18, JtB, 3, false, JtP, 18, false, 18, 18, 3, -1.0);
+            for (int i = lane; i < 18; i += 64) T1[i * 18 + i] += 1.0;
+            wsync();
+            gemm(lane, T2, 18, Np, 18, false, T1, 18, false, 18, 18, 18);
+            for (int e = lane; e < 324; e += 64) Np[e] = T2[e];
+            wsync();
+        }
+    }
+
+    // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
+    //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
+    //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
+    //   inequalities    :  Uf (Fr_des + z_f) - ineqVec >= 0
+    const int nz = 6 + dimFr, np_ = 6, mi = 6 * nc;
+    // gen (tv) = A qdd + C + G - Jc^T Fr_des  (all 18 rows; rows 6.. are reused for the torque)
+    if (lane < 18) {
+        real acc = Cv[lane] + Gv[lane];
+        for (int k = 0; k < 18; ++k) acc += A[lane * 18 + k] * qdd[k];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * cleg[k / 3] + k % 3];
+        tv[lane] = acc;
+    }
+    // constraint normals Nq[c][0:nz], offsets qc0[c]
+    for (int e = lane; e < (np_ + mi) * nz; e += 64) {
+        const int c = e / nz, j = e - c * nz;
+        real v = 0.0;
+        if (c < 6) v = (j < 6) ? A[c * 18 + j] : -JC[(j - 6) * 18 + c];
+        else {
+            const int u = c - 6, k = u / 6, tt = u - 6 * k;      // Uf row tt of contact k
+            if (j >= 6 && (j - 6) / 3 == k) {
+                const int ax = (j - 6) - 3 * k;
+                // Uf rows: [0 0 1] [1 0 mu] [-1 0 mu] [0 1 mu] [0 -1 mu] [0 0 -1]   (qr_single_contact.cpp:40-62)
+                if (tt == 0) v = (ax == 2) ? 1.0 : 0.0;
+                else if (tt == 5) v = (ax == 2) ? -1.0 : 0.0;
+                else { const int a2 = (tt - 1) >> 1; v = (ax == a2) ? (((tt - 1) & 1) ? -1.0 : 1.0) : ((ax == 2) ? (real)K.mu : 0.0); }
+            }
+        }
+        Nq[c * 18 + j] = v;
+    }
+    wsync();
+    if (lane < np_ + mi) {
+        const int c = lane;
+        real v;
+        if (c < 6) v = tv[c];
+        else {
+            const int u = c - 6, k = u / 6, tt = u - 6 * k;
+            real acc = 0.0;
+            for (int ax = 0; ax < 3; ++ax) acc += Nq[c * 18 + 6 + 3 * k + ax] * cm[51 + 3 * cleg[k] + ax];     // Uf Fr_des
+            v = acc - ((tt == 5) ? -(real)K.max_fz : 0.0);                                                    // - ineqVec
+        }
+        qc0[c] = v;
+    }
+    if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
+    wsync();
+    int stw = 0;
+    {
+        // Goldfarb-Idnani, Schur-complement form, M = W^-1 diagonal, dense normals.
+        int q = 0;
+        auto Minv = [&](int j) -> real { return (j < 6) ? 1.0 / (real)K.w_fb : 1.0 / (real)K.w_fr; };
+        // one "add constraint c" attempt; returns 0 added, 1 dropped-one-and-retry, 2 failure/infeasible, 3 dependent
+        int iter = 0;
+        const int maxit = 200;
+        bool fail = false;
+        int *act = sI;             // active ids
+        int *posi = sI + 32;       // constraint -> position or -1
+        if (lane < 32) posi[lane] = -1;
+        wsync();
+        int next_eq = 0;
+        while (!fail) {
+            int p;
+            if (next_eq < np_) p = next_eq;
+            else {
+                real bs = -1e-10; int bc = 0x7fffffff;
+                if (lane >= 6 && lane < np_ + mi && posi[lane] < 0) {
+                    real s = qc0[lane];
+                    for (int j = 0; j < nz; ++j) s += Nq[lane * 18 + j] * qx[j];
+                    if (s < bs) { bs = s; bc = lane; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const real os = __shfl_xor(bs, m, 64); const int oc = __shfl_xor(bc, m, 64);
+                    if (os < bs || (os == bs && oc < bc)) { bs = os; bc = oc; }
+                }
+                if (bc == 0x7fffffff) break;
+                p = bc;
+            }
+            real up = 0.0;
+            for (;;) {
+                if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
+                if (lane < nz) qw[lane] = Minv(lane) * Nq[p * 18 + lane];
+                wsync();
+                real delta = 0.0;
+                for (int j = 0; j < nz; ++j) delta += Nq[p * 18 + j] * qw[j];
+                if (lane < q) { real acc = 0.0; for (int j = 0; j < nz; ++j) acc += Nq[act[lane] * 18 + j] * qw[j]; qd_[lane] = acc; }
+                wsync();
+                real dr = 0.0;
+                if (lane < q) { real acc = 0.0; for (int j = 0; j < q; ++j) acc += Sq[lane * 18 + j] * qd_[j]; qr_[lane] = acc; dr = acc * qd_[lane]; }
+                dr = wsum(dr);
+                wsync();
+                const real zc = delta - dr;
+                real t1 = __builtin_inf(); int lpos = 0x7fffffff;
+                if (lane < q && act[lane] >= np_) { const real rj = qr_[lane]; if (rj > 0.0) { t1 = qu_[lane] / rj; lpos = lane; } }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const real ot = __shfl_xor(t1, m, 64); const int ol = __shfl_xor(lpos, m, 64);
+                    if (ot < t1 || (ot == t1 && ol < lpos)) { t1 = ot; lpos = ol; }
+                }
+                real sp = qc0[p];
+                for (int j = 0; j < nz; ++j) sp += Nq[p * 18 + j] * qx[j];
+                const bool have_z = zc > 1e-13 * delta;
+                const bool is_eq = p < np_;
+                const real t2 = have_z ? -sp / zc : __builtin_inf();
+                if (is_eq && !have_z) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }     // dependent equalities
+                const real t = is_eq ? t2 : (t1 < t2 ? t1 : t2);        // equalities take the full (signed) step
+                if (!is_eq && !(t < __builtin_inf())) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
+                if (have_z) {
+                    // z = w - M N r ; x += t z
+                    if (lane < nz) {
+                        real acc = 0.0;
+                        for (int j = 0; j < q; ++j) acc += Nq[act[j] * 18 + lane] * qr_[j];
+                        qz[lane] = qw[lane] - Minv(lane) * acc;
+                        qx[lane] += t * qz[lane];
+                    }
+                }
+                if (lane < q) qu_[lane] -= t * qr_[lane];
+                up += t;
+                wsync();
+                if (have_z && (is_eq || t == t2)) {
+                    const real isg = 1.0 / zc;
+                    for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; }
+                    if (lane < q) { Sq[q * 18 + lane] = -qr_[lane] * isg; Sq[lane * 18 + q] = -qr_[lane] * isg; }
+                    if (lane == 0) { Sq[q * 18 + q] = isg; act[q] = p; posi[p] = q; qu_[q] = up; }
+                    ++q;
+                    wsync();
+                    break;
+                }
+                // drop lpos
+                {
+                    const int l = lpos, last = q - 1;
+                    if (lane < q) qd_[lane] = Sq[lane * 18 + l];
+                    wsync();
+                    const real isl = 1.0 / qd_[l];
+                    for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; }
+                    wsync();
+                    if (l != last) {
+                        if (lane < last) qr_[lane] = (lane == l) ? Sq[last * 18 + last] : Sq[last * 18 + lane];
+                        wsync();
+                        if (lane < last) { Sq[l * 18 + lane] = qr_[lane]; Sq[lane * 18 + l] = qr_[lane]; }
+                    }
+                    if (lane == 0) {
+                        posi[act[l]] = -1;
+                        if (l != last) { act[l] = act[last]; qu_[l] = qu_[last]; posi[act[l]] = l; }
+                    }
+                    --q;
+                    wsync();
+                }
+            }
+            if (next_eq < np_) ++next_eq;
+        }
+    }
+
+    // ---------------- GetSolution (:210-228) + store ----------------
+    // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
+    if (lane < 12) {
+        const int row = 6 + lane;
+        real acc = tv[row];                                  // (A qdd_cmd + C + G - Jc^T Fr_des)[row]
+        for (int k = 0; k < 6; ++k) acc += A[row * 18 + k] * qx[k];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + row] * qx[6 + k];
+        const int leg = lane / 3;
+        if (!merge_tau || cm[63 + leg] != 0.0) g_tau[(size_t)lane * n + rid] = (float)acc;
+    }
+    if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
+}
+
+}  // namespace qrgpu

@@ -1,0 +1,475 @@
+// ============================================================================
+// libqrgpu.so host side: the C ABI of include/qrgpu.h on top of the HIP runtime.
+// No torch, no CPU compute path: every solve is a kernel launch on gfx950.
+// ============================================================================
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qrgpu.h"
+#include "qr_device_types.h"
+
+namespace qrgpu {
+__global__ void qr_mpc_kernel(MpcLaunch P, const int *type_id, const float *g_state, const float *g_traj, const float *g_gait,
+                              const float *g_q, float *g_force, float *g_tau, int *g_status, float *dbgH, float *dbgG,
+                              float *g_force_wbc, int force_stride);
+__global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
+                              float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or);
+}
+using namespace qrgpu;
+
+struct qrgpu_ctx {
+    int device = 0;
+    int max_batch = 0;
+    int horizon_max = 0;
+    hipStream_t stream = nullptr;
+    MpcLaunch mpc{};
+    bool mpc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    bool wbc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    WbcConst wbc_host[QR_MAX_TYPES];
+    WbcConst *d_wbc = nullptr;
+    bool wbc_dirty = true;
+    // scratch for the single-robot calls and the fused tick
+    float *d_in1 = nullptr;       // staging: single-robot inputs
+    float *d_out1 = nullptr;      // staging: single-robot outputs
+    int *d_st1 = nullptr;
+    float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
+    int lds_per_cu = 0, num_cu = 0;
+    std::string name;
+    std::string err;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    size_t ev_used[2] = {0, 0};
+};
+
+#define HIPCHK(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return QRGPU_ERR_LAUNCH;                                                         \
+        }                                                                                    \
+    } while (0)
+
+static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h)
+{
+    // Packed inverse Hessian for the all-stance worst case plus room for S^-1; two workgroups
+    // per CU when that fits in half the LDS, otherwise the whole CU.
+    const size_t fixed = mpc_lds_fixed_bytes(h);
+    const size_t nmax = 12 * (size_t)h;
+    const size_t mp = 8 * (nmax * (nmax + 1) / 2);
+    const size_t want = fixed + mp + 8 * (size_t)(24 * 25 / 2);     // at least a 24-row S^-1 in the worst case
+    const size_t cu = (size_t)ctx->lds_per_cu;
+    if (want <= cu / 2) return (int)(cu / 2);
+    return (int)cu;
+}
+
+struct TimerScope {
+    qrgpu_ctx *c; int k; bool on;
+    TimerScope(qrgpu_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->timing)
+    {
+        if (!on) return;
+        if (c->ev_used[k] == c->ev[k].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            c->ev[k].push_back({a, b});
+        }
+        hipEventRecord(c->ev[k][c->ev_used[k]].first, c->stream);
+    }
+    ~TimerScope()
+    {
+        if (!on) return;
+        hipEventRecord(c->ev[k][c->ev_used[k]].second, c->stream);
+        c->ev_used[k]++;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343; the Lite3 file is a literal copy) reduced
+// to rigid-body parameters.  Literals are the reference's float literals, evaluated in double.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RB { double m, h[3], I[6]; };     // I: xx yy zz xy xz yz about the frame origin
+RB make_rb(double m, const double c[3], const double Ic[9])
+{   // SpatialInertia(mass, com, inertia), QI/dynamics/spatial.hpp:390-398: Ibar = I + m [c]x[c]x^T
+    RB r; r.m = m;
+    for (int i = 0; i < 3; ++i) r.h[i] = m * c[i];
+    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    double Ib[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ib[i][j] = Ic[3 * i + j] + m * ((i == j ? cc : 0.0) - c[i] * c[j]);
+    r.I[0] = Ib[0][0]; r.I[1] = Ib[1][1]; r.I[2] = Ib[2][2]; r.I[3] = Ib[0][1]; r.I[4] = Ib[0][2]; r.I[5] = Ib[1][2];
+    return r;
+}
+RB flip_y(const RB &a)
+{   // flipAlongAxis(Y), spatial.hpp:505-534: mirror y
+    RB r = a;
+    r.h[1] = -a.h[1];
+    r.I[3] = -a.I[3];
+    r.I[5] = -a.I[5];
+    return r;
+}
+RB add_rb(const RB &a, const RB &b)
+{
+    RB r; r.m = a.m + b.m;
+    for (int i = 0; i < 3; ++i) r.h[i] = a.h[i] + b.h[i];
+    for (int i = 0; i < 6; ++i) r.I[i] = a.I[i] + b.I[i];
+    return r;
+}
+void store_rb(double *dst, const RB &r)
+{
+    dst[0] = r.m; dst[1] = r.h[0]; dst[2] = r.h[1]; dst[3] = r.h[2];
+    for (int i = 0; i < 6; ++i) dst[4 + i] = r.I[i];
+}
+void build_wbc_const(const qrgpu_model_desc &d, WbcConst &K)
+{
+    auto F = [](double x) { return (double)(float)x; };      // the reference's literals are floats
+    const double u = F(1e-6);
+    const double abadI[9] = {F(469.2) * u, F(-9.4) * u, F(-0.342) * u, F(-9.4) * u, F(807.5) * u, F(-0.466) * u, F(-0.342) * u, F(-0.466) * u, F(552.9) * u};
+    const double abadC[3] = {F(-0.0033), 0, 0};
+    const double hipI[9] = {F(5529) * u, F(4.825) * u, F(343.9) * u, F(4.825) * u, F(5139.3) * u, F(22.4) * u, F(343.9) * u, F(22.4) * u, F(1367.8) * u};
+    const double hipC[3] = {F(-0.003237), F(-0.022327), F(-0.027326)};
+    const double kneeI[9] = {F(2998) * u, 0, F(-141.2) * u, 0, F(3014) * u, 0, F(-141.2) * u, 0, F(32.4) * u};
+    const double kneeC[3] = {F(0.006435), 0, F(-0.107)};
+    const double bodyI[9] = {F(15853) * u, 0, 0, 0, F(37799) * u, 0, 0, 0, F(45654) * u};
+    const double zero3[3] = {0, 0, 0};
+    const double m_abad = F(0.696), m_hip = F(1.013), m_knee = F(0.166), m_body = 6.0;
+    const RB abadL = make_rb(m_abad, abadC, abadI), hipL = make_rb(m_hip, hipC, hipI), knee = make_rb(m_knee, kneeC, kneeI);
+    const RB abadR = flip_y(abadL), hipR = flip_y(hipL);
+    const RB base = make_rb(m_body, zero3, bodyI);
+    // rotors (:193-198, :244-247): mass 1e-8, inertia (1e-2 * 1e-6) * identity  (setIdentity() overrides 33/33/63)
+    const double k_rot = (double)(float)(F(1e-2) * 1e-6), m_rot = F(1e-8);
+    auto rotor_at = [&](double x, double y, double z) {
+        const double c[3] = {x, y, z};
+        const double I[9] = {k_rot, 0, 0, 0, k_rot, 0, 0, 0, k_rot};
+        return make_rb(m_rot, c, I);
+    };
+    RB base_eff = base;
+    const double arx = F(0.14), ary = F(0.047);
+    for (int leg = 0; leg < 4; ++leg) base_eff = add_rb(base_eff, rotor_at((leg < 2 ? 1 : -1) * arx, ((leg & 1) ? 1 : -1) * ary, 0.0));
+    const double hry = F(0.04);
+    const RB abadR_eff = add_rb(abadR, rotor_at(0, -hry, 0)), abadL_eff = add_rb(abadL, rotor_at(0, hry, 0));
+    const RB hipR_eff = add_rb(hipR, rotor_at(0, 0, 0)), hipL_eff = add_rb(hipL, rotor_at(0, 0, 0));
+    store_rb(K.rb[QR_RB_BASE], base);          store_rb(K.rb[QR_RB_BASE_EFF], base_eff);
+    store_rb(K.rb[QR_RB_ABAD + 0], abadR);     store_rb(K.rb[QR_RB_ABAD + 1], abadL);
+    store_rb(K.rb[QR_RB_ABAD_EFF + 0], abadR_eff); store_rb(K.rb[QR_RB_ABAD_EFF + 1], abadL_eff);
+    store_rb(K.rb[QR_RB_HIP + 0], hipR);       store_rb(K.rb[QR_RB_HIP + 1], hipL);
+    store_rb(K.rb[QR_RB_HIP_EFF + 0], hipR_eff); store_rb(K.rb[QR_RB_HIP_EFF + 1], hipL_eff);
+    store_rb(K.rb[QR_RB_KNEE], knee);
+    K.abad_loc[0] = F(0.1805); K.abad_loc[1] = F(0.047); K.abad_loc[2] = 0.0;
+    K.hip_l = d.hip_l; K.upper_l = d.upper_l; K.lower_l = d.lower_l; K.foot_y = F(0.004);
+    K.k_rot = k_rot;
+    const double pi_f = (double)(float)M_PI;                   // coordinateRotation(Z, float(M_PI)) (:299)
+    K.hiprot_ex = -std::sin(pi_f); K.hiprot_ey = std::cos(pi_f);
+    const double total = m_body + 4.0 * (m_abad + m_hip + m_knee);                  // totalNonRotorMass()
+    K.max_fz = (double)(float)total * (double)9.81f;
+    K.kp_pos = d.kp_body_pos; K.kd_pos = d.kd_body_pos; K.kp_ori = d.kp_body_ori; K.kd_ori = d.kd_body_ori;
+    K.kp_foot = d.kp_foot; K.kd_foot = d.kd_foot;
+    K.w_fb = d.weight_fb; K.w_fr = d.weight_fr; K.mu = d.mu;
+}
+}  // namespace
+
+extern "C" {
+
+void qrgpu_model_desc_default(qrgpu_model_desc *d)
+{
+    d->hip_l = 0.08505f; d->upper_l = 0.2f; d->lower_l = 0.2f;
+    d->body_size[0] = 0.267f; d->body_size[1] = 0.194f; d->body_size[2] = 0.114f;
+    d->kp_body_pos = 100.f; d->kd_body_pos = 10.f; d->kp_body_ori = 100.f; d->kd_body_ori = 10.f;
+    d->kp_foot = 500.f; d->kd_foot = 10.f; d->weight_fb = 0.1f; d->weight_fr = 1.f; d->mu = 0.4f;
+}
+
+int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
+{
+    if (!out || max_batch <= 0 || horizon_max <= 0 || horizon_max > QRGPU_MAX_HORIZON) return QRGPU_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return QRGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return QRGPU_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return QRGPU_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return QRGPU_ERR_NO_DEVICE;     // kernels are built for gfx950 only
+    qrgpu_ctx *c = new qrgpu_ctx();
+    c->device = device_id; c->max_batch = max_batch; c->horizon_max = horizon_max;
+    c->name = prop.name; c->num_cu = prop.multiProcessorCount;
+    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
+    const size_t in1 = 28 + 12 * QRGPU_MAX_HORIZON + 4 * QRGPU_MAX_HORIZON + 12 + 37 + 67 + 3;
+    if (hipMalloc(&c->d_in1, in1 * sizeof(float)) != hipSuccess || hipMalloc(&c->d_out1, 64 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&c->d_st1, 4 * sizeof(int)) != hipSuccess || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
+        hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess) {
+        qrgpu_destroy(c);
+        return QRGPU_ERR_ALLOC;
+    }
+    memset(&c->mpc, 0, sizeof(c->mpc));
+    memset(c->wbc_host, 0, sizeof(c->wbc_host));
+    *out = c;
+    return QRGPU_OK;
+}
+
+void qrgpu_destroy(qrgpu_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (int k = 0; k < 2; ++k) for (auto &e : c->ev[k]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (c->d_in1) hipFree(c->d_in1);
+    if (c->d_out1) hipFree(c->d_out1);
+    if (c->d_st1) hipFree(c->d_st1);
+    if (c->d_wbc) hipFree(c->d_wbc);
+    if (c->d_cmd_tick) hipFree(c->d_cmd_tick);
+    delete c;
+}
+
+int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; return QRGPU_OK; }
+const char *qrgpu_last_error(const qrgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
+int qrgpu_device_info(const qrgpu_ctx *c, char *name, int len, int *lds)
+{
+    if (!c) return 0;
+    if (name && len > 0) { strncpy(name, c->name.c_str(), len - 1); name[len - 1] = 0; }
+    if (lds) *lds = c->lds_per_cu;
+    return c->num_cu;
+}
+
+int qrgpu_mpc_setup(qrgpu_ctx *c, int type_id, float dt, int horizon, float mu, float fmax, float mass,
+                    const float inertia[3], const float weights[12], float alpha)
+{
+    if (!c || type_id < 0 || type_id >= QR_MAX_TYPES || !inertia || !weights) return QRGPU_ERR_BAD_ARG;
+    if (horizon <= 0 || horizon > c->horizon_max) return QRGPU_ERR_BAD_ARG;
+    // one horizon per context (the reference has one global problem size, qr_mpc_interface.cpp:35-104)
+    for (int t = 0; t < QR_MAX_TYPES; ++t) if (t != type_id && c->mpc_ready[t] && c->mpc.horizon != horizon) return QRGPU_ERR_BAD_ARG;
+    MpcType &T = c->mpc.type[type_id];
+    T.dt = dt; T.mu = mu; T.fmax = fmax; T.mass = mass; T.alpha = alpha;
+    for (int i = 0; i < 3; ++i) T.inertia[i] = inertia[i];
+    for (int i = 0; i < 12; ++i) T.weights[i] = weights[i];
+    if (!c->wbc_ready[type_id]) { T.hip_l = 0.08505f; T.upper_l = 0.2f; T.lower_l = 0.2f; }
+    c->mpc.horizon = horizon;
+    c->mpc_ready[type_id] = true;
+    return QRGPU_OK;
+}
+
+int qrgpu_wbc_setup(qrgpu_ctx *c, int type_id, const qrgpu_model_desc *desc)
+{
+    if (!c || type_id < 0 || type_id >= QR_MAX_TYPES || !desc) return QRGPU_ERR_BAD_ARG;
+    build_wbc_const(*desc, c->wbc_host[type_id]);
+    MpcType &T = c->mpc.type[type_id];
+    T.hip_l = desc->hip_l; T.upper_l = desc->upper_l; T.lower_l = desc->lower_l;    // leg geometry for the MPC torque map
+    c->wbc_ready[type_id] = true;
+    c->wbc_dirty = true;
+    return QRGPU_OK;
+}
+
+static int upload_wbc(qrgpu_ctx *c)
+{
+    if (!c->wbc_dirty) return QRGPU_OK;
+    HIPCHK(c, hipMemcpyAsync(c->d_wbc, c->wbc_host, sizeof(WbcConst) * QR_MAX_TYPES, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->wbc_dirty = false;
+    return QRGPU_OK;
+}
+
+static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_traj, const float *d_gait,
+                      const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc)
+{
+    if (!c || n <= 0 || n > c->max_batch || !d_state || !d_traj || !d_gait || !d_force) return QRGPU_ERR_BAD_ARG;
+    if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
+    if (!c->mpc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    HIPCHK(c, hipSetDevice(c->device));
+    MpcLaunch P = c->mpc;
+    P.n = n;
+    P.lds_bytes = mpc_lds_bytes(c, P.horizon);
+    static int configured_lds = 0;
+    if (configured_lds < P.lds_bytes) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
+        configured_lds = P.lds_bytes;
+    }
+    {
+        TimerScope ts(c, 0);
+        hipLaunchKernelGGL(qr_mpc_kernel, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
+                           d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51);
+    }
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
+                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or)
+{
+    if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
+    if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
+    if (!c->wbc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_wbc(c);
+    if (rc) return rc;
+    {
+        TimerScope ts(c, 1);
+        hipLaunchKernelGGL(qr_wbc_kernel, dim3(n), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
+                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or);
+    }
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+int qrgpu_mpc_solve_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
+                          const float *d_gait, const float *d_q, float *d_force, float *d_tau_mpc, int *d_status)
+{
+    return launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_q, d_force, d_tau_mpc, d_status, nullptr, nullptr, nullptr);
+}
+
+int qrgpu_mpc_assemble_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
+                             const float *d_gait, float *d_H, float *d_g)
+{
+    if (!c || !d_H || !d_g) return QRGPU_ERR_BAD_ARG;
+    // the kernel needs somewhere to put the forces; use the head of d_g's robot 0 row?  No: own scratch.
+    float *scratch = nullptr;
+    HIPCHK(c, hipMalloc(&scratch, sizeof(float) * 12 * (size_t)n));
+    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, nullptr, scratch, nullptr, nullptr, d_H, d_g, nullptr);
+    hipStreamSynchronize(c->stream);
+    hipFree(scratch);
+    return rc;
+}
+
+int qrgpu_wbc_run_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_fb_state, const float *d_wbc_cmd,
+                        float *d_prev_ori, float *d_tau, float *d_qdes, int *d_status)
+{
+    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 0, 0);
+}
+
+int qrgpu_fb_debug_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_fb_state, float *d_out)
+{
+    if (!d_out) return QRGPU_ERR_BAD_ARG;
+    return launch_wbc(c, n, d_type_id, d_fb_state, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, 0, 0);
+}
+
+int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
+                     const float *d_gait, const float *d_fb_state, const float *d_wbc_cmd, float *d_prev_ori,
+                     float *d_force, float *d_tau, int *d_status)
+{
+    if (!c || !d_fb_state || !d_wbc_cmd || !d_tau || !d_prev_ori) return QRGPU_ERR_BAD_ARG;
+    if (n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    // wbc_cmd copy whose Fr_des rows (51..62) the MPC kernel overwrites with its forces (wbcData.Fr_des = f, :408)
+    HIPCHK(c, hipMemcpyAsync(c->d_cmd_tick, d_wbc_cmd, sizeof(float) * 67 * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, d_force, d_tau, d_status,
+                        nullptr, nullptr, c->d_cmd_tick);
+    if (rc) return rc;
+    return launch_wbc(c, n, d_type_id, d_fb_state, c->d_cmd_tick, d_prev_ori, d_tau, nullptr, d_status, nullptr, 1, d_status ? 1 : 0);
+}
+
+int qrgpu_mpc_solve1(qrgpu_ctx *c, int type_id, const float p[3], const float v[3], const float quat[4], const float w[3],
+                     const float r[12], const float rpy[3], const float *traj, const float *gait, const float q[12],
+                     double f_out[12], float tau_out[12], int *status)
+{
+    if (!c || !p || !v || !quat || !w || !r || !rpy || !traj || !gait || !f_out) return QRGPU_ERR_BAD_ARG;
+    if (type_id < 0 || type_id >= QR_MAX_TYPES || !c->mpc_ready[type_id]) return QRGPU_ERR_NOT_SETUP;
+    const int h = c->mpc.horizon;
+    std::vector<float> in(28 + 16 * h + 12, 0.f);
+    memcpy(&in[0], p, 12); memcpy(&in[3], v, 12); memcpy(&in[6], quat, 16); memcpy(&in[10], w, 12);
+    memcpy(&in[13], r, 48); memcpy(&in[25], rpy, 12);
+    memcpy(&in[28], traj, sizeof(float) * 12 * h);
+    memcpy(&in[28 + 12 * h], gait, sizeof(float) * 4 * h);
+    if (q) memcpy(&in[28 + 16 * h], q, 48);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_in1, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int *d_type = nullptr;
+    int tid_host = type_id;
+    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
+    int rc = launch_mpc(c, 1, d_type, c->d_in1, c->d_in1 + 28, c->d_in1 + 28 + 12 * h, c->d_in1 + 28 + 16 * h, c->d_out1,
+                        (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    float out[24]; int st = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 12; ++i) f_out[i] = out[i];
+    if (q && tau_out) for (int i = 0; i < 12; ++i) tau_out[i] = out[12 + i];
+    if (status) *status = st;
+    return QRGPU_OK;
+}
+
+int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const float wbc_cmd[67], float prev_ori_vel[3],
+                   float tau_out[12], float qdes_out[12], float qddes_out[12], int *status)
+{
+    if (!c || !fb_state || !wbc_cmd || !prev_ori_vel || !tau_out) return QRGPU_ERR_BAD_ARG;
+    if (type_id < 0 || type_id >= QR_MAX_TYPES || !c->wbc_ready[type_id]) return QRGPU_ERR_NOT_SETUP;
+    float in[37 + 67 + 3];
+    memcpy(in, fb_state, 37 * 4); memcpy(in + 37, wbc_cmd, 67 * 4); memcpy(in + 104, prev_ori_vel, 12);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_in1, in, sizeof(in), hipMemcpyHostToDevice, c->stream));
+    int *d_type = nullptr;
+    int tid_host = type_id;
+    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
+    const bool want_q = qdes_out || qddes_out;
+    int rc = launch_wbc(c, 1, d_type, c->d_in1, c->d_in1 + 37, c->d_in1 + 104, c->d_out1, want_q ? c->d_out1 + 12 : nullptr,
+                        c->d_st1, nullptr, 0, 0);
+    if (rc) return rc;
+    float out[36]; int st = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(prev_ori_vel, c->d_in1 + 104, 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(tau_out, out, 48);
+    if (qdes_out) memcpy(qdes_out, out + 12, 48);
+    if (qddes_out) memcpy(qddes_out, out + 24, 48);
+    if (status) *status = st;
+    return QRGPU_OK;
+}
+
+int qrgpu_sync(qrgpu_ctx *c)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QRGPU_OK;
+}
+
+int qrgpu_enable_timing(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->timing = on != 0;
+    c->ev_used[0] = c->ev_used[1] = 0;
+    return QRGPU_OK;
+}
+
+int qrgpu_get_timing(qrgpu_ctx *c, int kernel, double *mean_ms, int *count)
+{
+    if (!c || kernel < 0 || kernel > 1 || !mean_ms) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->ev_used[kernel]; ++i) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[kernel][i].first, c->ev[kernel][i].second));
+        tot += ms;
+    }
+    *mean_ms = c->ev_used[kernel] ? tot / (double)c->ev_used[kernel] : 0.0;
+    if (count) *count = (int)c->ev_used[kernel];
+    return QRGPU_OK;
+}
+
+void *qrgpu_malloc(qrgpu_ctx *c, unsigned long long bytes)
+{
+    if (!c) return nullptr;
+    void *p = nullptr;
+    hipSetDevice(c->device);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void qrgpu_free(qrgpu_ctx *c, void *p) { if (c && p) { hipSetDevice(c->device); hipFree(p); } }
+int qrgpu_memcpy_h2d(qrgpu_ctx *c, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QRGPU_OK;
+}
+int qrgpu_memcpy_d2h(qrgpu_ctx *c, void *dst, const void *src, unsigned long long bytes)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QRGPU_OK;
+}
+
+}  // extern "C"

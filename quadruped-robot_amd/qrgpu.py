@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's interfaces on top of libqrgpu.so (ctypes).
+
+Reference interface                                   -> here
+  Quadruped::SetupProblem / SolveMPCKernel / GetMPCSolution
+      (QI/controllers/mpc/qr_mpc_interface.h:157,200,215) -> MPCInterface.SetupProblem / SolveMPCKernel / GetMPCSolution
+  qrWbcLocomotionController<float>::Run
+      (QI/controllers/wbc/qr_wbc_locomotion_controller.hpp:59) -> WbcLocomotionController.Run
+  batched ticks (no reference equivalent; n independent robots) -> Context.mpc_solve_batch / wbc_run_batch / tick_batch
+
+There is no CPU path in this module: if the HIP library is missing or no gfx950 device is
+usable, construction raises (MissingExtension / QrgpuError).  torch is used only by callers
+for device memory, streams and torch.distributed; this module takes raw device pointers
+(ints) or anything with a .data_ptr() method.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERRORS = {0: "OK", 1: "NO_DEVICE", 2: "BAD_ARG", 3: "NOT_SETUP", 4: "LAUNCH", 5: "ALLOC"}
+ST_MPC_MAXITER, ST_MPC_INFEAS, ST_MPC_OVERFLOW, ST_MPC_NOTSPD = 0x1, 0x2, 0x4, 0x8
+ST_WBC_MAXITER, ST_WBC_INFEAS = 0x10, 0x20
+FB_DEBUG_FLOATS = 324 + 18 + 18 + 216 + 12 + 12 + 12
+
+
+class QrgpuError(RuntimeError):
+    pass
+
+
+class MissingExtension(QrgpuError):
+    """libqrgpu.so has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+
+
+class model_desc_struct(C.Structure):
+    _fields_ = [("hip_l", C.c_float), ("upper_l", C.c_float), ("lower_l", C.c_float), ("body_size", C.c_float * 3),
+                ("kp_body_pos", C.c_float), ("kd_body_pos", C.c_float), ("kp_body_ori", C.c_float), ("kd_body_ori", C.c_float),
+                ("kp_foot", C.c_float), ("kd_foot", C.c_float), ("weight_fb", C.c_float), ("weight_fr", C.c_float), ("mu", C.c_float)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libqrgpu.so")
+
+
+EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_set_stream", "qrgpu_last_error",
+           "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
+           "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
+           "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
+           "qrgpu_memcpy_d2h"]
+
+
+def load_library():
+    """dlopen libqrgpu.so; raises MissingExtension when it was never built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise MissingExtension("%s not found: the HIP extension must be built first (no CPU fallback exists)" % p)
+    lib = C.CDLL(p)
+    vp, ip, fp = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    lib.qrgpu_create.argtypes = [ip, ip, ip, C.POINTER(vp)]
+    lib.qrgpu_destroy.argtypes = [vp]; lib.qrgpu_destroy.restype = None
+    lib.qrgpu_set_stream.argtypes = [vp, vp]
+    lib.qrgpu_last_error.argtypes = [vp]; lib.qrgpu_last_error.restype = C.c_char_p
+    lib.qrgpu_device_info.argtypes = [vp, C.c_char_p, ip, C.POINTER(ip)]
+    lib.qrgpu_model_desc_default.argtypes = [C.POINTER(model_desc_struct)]; lib.qrgpu_model_desc_default.restype = None
+    lib.qrgpu_mpc_setup.argtypes = [vp, ip, C.c_float, ip, C.c_float, C.c_float, C.c_float, fp, fp, C.c_float]
+    lib.qrgpu_wbc_setup.argtypes = [vp, ip, C.POINTER(model_desc_struct)]
+    lib.qrgpu_mpc_solve_batch.argtypes = [vp, ip] + [vp] * 8
+    lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
+    lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 10
+    lib.qrgpu_mpc_assemble_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_fb_debug_batch.argtypes = [vp, ip, vp, vp, vp]
+    lib.qrgpu_mpc_solve1.argtypes = [vp, ip] + [fp] * 9 + [C.POINTER(C.c_double), fp, C.POINTER(ip)]
+    lib.qrgpu_wbc_run1.argtypes = [vp, ip] + [fp] * 6 + [C.POINTER(ip)]
+    lib.qrgpu_sync.argtypes = [vp]
+    lib.qrgpu_enable_timing.argtypes = [vp, ip]
+    lib.qrgpu_get_timing.argtypes = [vp, ip, C.POINTER(C.c_double), C.POINTER(ip)]
+    lib.qrgpu_malloc.argtypes = [vp, C.c_ulonglong]; lib.qrgpu_malloc.restype = vp
+    lib.qrgpu_free.argtypes = [vp, vp]; lib.qrgpu_free.restype = None
+    lib.qrgpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_ulonglong]
+    lib.qrgpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_ulonglong]
+    _LIB = lib
+    return lib
+
+
+def _dp(x):
+    """device pointer from an int, None, or an object with data_ptr()."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class DeviceArray:
+    """Minimal hipMalloc-backed array for callers that do not use torch (tests, smoke)."""
+
+    def __init__(self, ctx, shape, dtype=np.float32):
+        self.ctx, self.shape, self.dtype = ctx, tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx._lib.qrgpu_malloc(ctx._h, max(self.nbytes, 8))
+        if not self.ptr:
+            raise QrgpuError("hipMalloc of %d bytes failed" % self.nbytes)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, self.dtype)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        self.ctx._chk(self.ctx._lib.qrgpu_memcpy_h2d(self.ctx._h, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, self.dtype)
+        self.ctx._chk(self.ctx._lib.qrgpu_memcpy_d2h(self.ctx._h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx._lib.qrgpu_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One qrgpu_ctx: a device, a stream, per-type MPC/WBC parameters."""
+
+    def __init__(self, device_id=0, max_batch=1024, horizon_max=16):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.qrgpu_create(device_id, max_batch, horizon_max, C.byref(h))
+        if rc != 0:
+            raise QrgpuError("qrgpu_create failed: %s (a gfx950 device is required; there is no CPU fallback)" % ERRORS.get(rc, rc))
+        self._h = h
+        self.max_batch, self.horizon = max_batch, None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.qrgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise QrgpuError("%s: %s" % (ERRORS.get(rc, rc), self._lib.qrgpu_last_error(self._h).decode()))
+
+    # -- setup ---------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.qrgpu_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def device_info(self):
+        buf = C.create_string_buffer(256); lds = C.c_int(0)
+        cus = self._lib.qrgpu_device_info(self._h, buf, 256, C.byref(lds))
+        return dict(name=buf.value.decode(), cus=cus, lds_per_cu=lds.value)
+
+    def mpc_setup(self, type_id, dt, horizon, mu, fmax, mass, inertia, weights, alpha):
+        inertia = np.ascontiguousarray(inertia, np.float32); weights = np.ascontiguousarray(weights, np.float32)
+        self._chk(self._lib.qrgpu_mpc_setup(self._h, type_id, dt, horizon, mu, fmax, mass, _fp(inertia), _fp(weights), alpha))
+        self.horizon = horizon
+
+    def mpc_setup_packed(self, type_id, cfg20, horizon):
+        """cfg20 = dt, mu, fmax, mass, inertia[3], weights[12], alpha (workload.mpc_cfg)."""
+        c = np.asarray(cfg20, np.float32)
+        self.mpc_setup(type_id, float(c[0]), horizon, float(c[1]), float(c[2]), float(c[3]), c[4:7], c[7:19], float(c[19]))
+
+    def wbc_setup(self, type_id, hip_l=None, upper_l=None, lower_l=None, body_size=None, **gains):
+        d = model_desc_struct()
+        self._lib.qrgpu_model_desc_default(C.byref(d))
+        if hip_l is not None: d.hip_l = hip_l
+        if upper_l is not None: d.upper_l = upper_l
+        if lower_l is not None: d.lower_l = lower_l
+        if body_size is not None:
+            for i in range(3): d.body_size[i] = body_size[i]
+        for k, v in gains.items():
+            setattr(d, k, v)
+        self._chk(self._lib.qrgpu_wbc_setup(self._h, type_id, C.byref(d)))
+
+    def wbc_setup_packed(self, type_id, model6):
+        m = np.asarray(model6, np.float32)
+        self.wbc_setup(type_id, float(m[0]), float(m[1]), float(m[2]), [float(x) for x in m[3:6]])
+
+    def alloc(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    # -- batched device-pointer API ---------------------------------------------------------------
+    def mpc_solve_batch(self, n, mpc_state, traj, gait, q, force, tau=None, status=None, type_id=None):
+        self._chk(self._lib.qrgpu_mpc_solve_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(q),
+                                                  _dp(force), _dp(tau), _dp(status)))
+
+    def wbc_run_batch(self, n, fb_state, wbc_cmd, prev_ori, tau, qdes=None, status=None, type_id=None):
+        self._chk(self._lib.qrgpu_wbc_run_batch(self._h, n, _dp(type_id), _dp(fb_state), _dp(wbc_cmd), _dp(prev_ori), _dp(tau),
+                                                _dp(qdes), _dp(status)))
+
+    def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None):
+        self._chk(self._lib.qrgpu_tick_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(fb_state),
+                                             _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(status)))
+
+    def mpc_assemble_batch(self, n, mpc_state, traj, gait, H, g, type_id=None):
+        self._chk(self._lib.qrgpu_mpc_assemble_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(H), _dp(g)))
+
+    def fb_debug_batch(self, n, fb_state, out, type_id=None):
+        self._chk(self._lib.qrgpu_fb_debug_batch(self._h, n, _dp(type_id), _dp(fb_state), _dp(out)))
+
+    def sync(self):
+        self._chk(self._lib.qrgpu_sync(self._h))
+
+    def enable_timing(self, on=True):
+        self._chk(self._lib.qrgpu_enable_timing(self._h, 1 if on else 0))
+
+    def get_timing(self, kernel):
+        ms = C.c_double(0); cnt = C.c_int(0)
+        self._chk(self._lib.qrgpu_get_timing(self._h, kernel, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    # -- single-robot host API ------------------------------------------------------------------------
+    def mpc_solve1(self, p, v, quat, w, r, rpy, traj, gait, q=None, type_id=0):
+        a = [np.ascontiguousarray(x, np.float32) for x in (p, v, quat, w, r, rpy, traj, gait)]
+        qa = np.ascontiguousarray(q, np.float32) if q is not None else None
+        f = np.zeros(12, np.float64); tau = np.zeros(12, np.float32); st = C.c_int(0)
+        self._chk(self._lib.qrgpu_mpc_solve1(self._h, type_id, *[_fp(x) for x in a], _fp(qa) if qa is not None else None,
+                                             f.ctypes.data_as(C.POINTER(C.c_double)), _fp(tau), C.byref(st)))
+        return f, (tau if q is not None else None), st.value
+
+    def wbc_run1(self, fb_state, wbc_cmd, prev_ori_vel, type_id=0, want_qdes=True):
+        s = np.ascontiguousarray(fb_state, np.float32); c = np.ascontiguousarray(wbc_cmd, np.float32)
+        prev = np.ascontiguousarray(prev_ori_vel, np.float32).copy()
+        tau = np.zeros(12, np.float32); qd = np.zeros(12, np.float32); qdd = np.zeros(12, np.float32); st = C.c_int(0)
+        self._chk(self._lib.qrgpu_wbc_run1(self._h, type_id, _fp(s), _fp(c), _fp(prev), _fp(tau),
+                                           _fp(qd) if want_qdes else None, _fp(qdd) if want_qdes else None, C.byref(st)))
+        return tau, qd, qdd, prev, st.value
+
+
+class MPCInterface:
+    """Drop-in shaped like the free functions of qr_mpc_interface.h (one robot, host pointers).
+
+    The reference keeps its problem in file-static state (qr_mpc_interface.cpp:35-104); here the
+    state lives in this object."""
+
+    def __init__(self, ctx=None, type_id=0):
+        self.ctx = ctx or Context(max_batch=1)
+        self.type_id = type_id
+        self._soln = None
+        self.status = 0
+
+    def SetupProblem(self, dt, horizon, frictionCoeff, fMax, totalMass, inertia, weight, alpha):
+        self.ctx.mpc_setup(self.type_id, float(dt), int(horizon), float(frictionCoeff), float(fMax), float(totalMass),
+                           inertia, weight, float(alpha))
+        self.horizon = int(horizon)
+
+    def SolveMPCKernel(self, p, v, q, w, r, rpy, state_trajectory, gait):
+        """r: 3x4 (column = leg) as Eigen::Matrix<float,3,4>; q: quaternion (w,x,y,z)."""
+        r = np.asarray(r, np.float32)
+        r_colmajor = r.T.reshape(12) if r.shape == (3, 4) else r.reshape(12)
+        f, _, st = self.ctx.mpc_solve1(p, v, q, w, r_colmajor, rpy, np.asarray(state_trajectory, np.float32)[:12 * self.horizon],
+                                       np.asarray(gait, np.float32)[:4 * self.horizon], None, self.type_id)
+        self._soln, self.status = f, st
+
+    def GetMPCSolution(self, index):
+        """First-step forces only (indices 0..11), as every call site of the reference uses it
+        (qr_mpc_stance_leg_controller.cpp:404); 0 before the first solve (qr_mpc_interface.cpp:448)."""
+        if self._soln is None:
+            return 0.0
+        return float(self._soln[index])
+
+
+class WbcLocomotionController:
+    """Shaped like qrWbcLocomotionController<float> (QI/controllers/wbc/qr_wbc_locomotion_controller.hpp:47-59).
+
+    Run() keeps the reference's cadence: it computes on every 2nd call (iteration % 2 == 0,
+    qr_wbc_locomotion_controller.cpp:111,133) and otherwise re-applies the last torques to the
+    stance legs (UpdateLegCMD runs every call, :129)."""
+
+    def __init__(self, ctx, type_id=0):
+        self.ctx, self.type_id = ctx, type_id
+        self.iteration = 0
+        self.prev_ori_vel = np.zeros(3, np.float32)
+        self.jointTorqueCmd = np.zeros(12, np.float32)
+        self.desiredJPos = np.zeros(12, np.float32)
+        self.desiredJVel = np.zeros(12, np.float32)
+        self.status = 0
+
+    def Run(self, fb_state, wbc_cmd, leg_cmd_tua):
+        """leg_cmd_tua: array of 12 torques, stance-leg entries are overwritten in place."""
+        if self.iteration % 2 == 0:
+            tau, qd, qdd, prev, st = self.ctx.wbc_run1(fb_state, wbc_cmd, self.prev_ori_vel, self.type_id)
+            self.jointTorqueCmd, self.desiredJPos, self.desiredJVel, self.prev_ori_vel, self.status = tau, qd, qdd, prev, st
+        contact = np.asarray(wbc_cmd, np.float32)[63:67]
+        for leg in range(4):
+            if contact[leg] != 0:
+                leg_cmd_tua[3 * leg:3 * leg + 3] = self.jointTorqueCmd[3 * leg:3 * leg + 3]
+        self.iteration += 1
+        return leg_cmd_tua

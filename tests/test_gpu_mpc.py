@@ -1,0 +1,127 @@
+"""-m gpu: the HIP MPC kernel (through the C ABI) against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+import gpu_helpers as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_forces(oracle, pkg, b, robot="a1"):
+    cfg = pkg.mpc_cfg(robot)
+    n, h = b["n"], b["horizon"]
+    f = np.zeros((n, 12)); tau = np.zeros((n, 12), np.float32)
+    geom = pkg.model_desc(robot)[:3]
+    for i in range(n):
+        u, st, rc = oracle.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        assert rc == 0
+        f[i] = u[:12]
+        tau[i] = oracle.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], u[:12])
+    return f, tau
+
+
+def test_assembly_bit_exact(gpu_ctx, pkg, oracle):
+    """fp32 H and g from the kernel are bit-identical to the oracle's dense k-ordered GEMM
+    (all-stance robots so that every entry is produced) and on stance x stance entries for trot."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    cfg = pkg.mpc_cfg("a1")
+    for fr_all, seed in ((1.0, 3), (0.05, 4)):
+        b = pkg.make_batch(16, 10, "a1", seed=seed, frac_all_stance=fr_all, frac_three_leg=0.0 if fr_all == 1.0 else 0.1)
+        Hg, gg = G.run_assemble(gpu_ctx, pkg, b)
+        for i in range(b["n"]):
+            Ho, go, ub = oracle.mpc_assemble(cfg, 10, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+            free = np.repeat(ub[4::5] > 0, 3)
+            m2 = np.outer(free, free)
+            assert np.array_equal(Hg[i][m2].view(np.uint32), Ho[m2].view(np.uint32)), "H differs bitwise (robot %d)" % i
+            assert np.array_equal(gg[i][free].view(np.uint32), go[free].view(np.uint32)), "g differs bitwise (robot %d)" % i
+            assert np.all(np.isnan(Hg[i][~m2]))      # swing entries are never touched
+
+
+@pytest.mark.parametrize("horizon,n,seed", [(10, 256, 0xA2), (5, 64, 7)])
+def test_mpc_parity(gpu_ctx, pkg, oracle, horizon, n, seed):
+    """Config 2 of BASELINE.json (256 A1, h=10, MPC only): forces and J^T f torques vs the oracle."""
+    G.setup_a1(gpu_ctx, pkg, horizon)
+    b = pkg.make_batch(n, horizon, "a1", seed=seed)
+    out = G.run_mpc(gpu_ctx, pkg, b)
+    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    f, tau = _oracle_forces(oracle, pkg, b)
+    fmax = np.abs(f).max(axis=1, keepdims=True)
+    assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max()), np.abs(out["force"] - f).max()
+    assert np.all(np.abs(out["force"] - f) <= 1e-6 * np.maximum(1.0, fmax) + 1e-5)
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau)), np.abs(out["tau"] - tau).max()
+
+
+def test_mpc_edge_cases(gpu_ctx, pkg, oracle):
+    """all swing (flight), all stance, three legs, one stance leg-step only."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(8, 10, "a1", seed=11)
+    g = b["gait"].reshape(8, 10, 4)
+    g[0] = 0.0                       # flight: no free variable, forces 0
+    g[1] = 1.0                       # stand
+    g[2] = 1.0; g[2, :, 2] = 0.0     # three legs
+    g[3] = 0.0; g[3, 0, 1] = 1.0     # a single stance leg-step
+    g[4] = 0.0; g[4, 5:, :] = 1.0    # flight now, stance later: first-step forces 0 but the QP is not empty
+    b["gait"] = g.reshape(8, 40)
+    out = G.run_mpc(gpu_ctx, pkg, b)
+    assert np.all((out["status"] & 0xff) == 0)
+    f, tau = _oracle_forces(oracle, pkg, b)
+    assert np.all(out["force"][0] == 0) and np.all(out["tau"][0] == 0)
+    assert np.all(out["force"][4] == 0)
+    assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau))
+
+
+def test_mpc_kkt_full_size(gpu_ctx, pkg, oracle):
+    """Size-independent property at the bench size (1024 robots): the first-step forces satisfy the
+    pyramid constraints, and perturbing the state slightly perturbs the forces slightly (no
+    active-set garbage).  Feasibility is checked for every robot, optimality through the oracle on
+    a sample."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(1024, 10, "a1", seed=0xA3)
+    out = G.run_mpc(gpu_ctx, pkg, b)
+    assert np.all((out["status"] & 0xff) == 0)
+    f = out["force"].reshape(1024, 4, 3)
+    mu = np.float32(0.45); fmaxv = np.float32(13 * 9.81)
+    assert np.all(f[:, :, 2] >= -1e-6) and np.all(f[:, :, 2] <= fmaxv * (1 + 1e-6))
+    assert np.all(np.abs(f[:, :, 0]) <= mu * f[:, :, 2] + 1e-5) and np.all(np.abs(f[:, :, 1]) <= mu * f[:, :, 2] + 1e-5)
+    contact = b["gait"][:, :4]
+    assert np.all(f[contact == 0] == 0)
+    cfg = pkg.mpc_cfg("a1")
+    for i in range(0, 1024, 64):
+        u, st, rc = oracle.mpc_solve(cfg, 10, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        assert np.abs(out["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max())
+
+
+def test_mpc_lite3_and_mixed_types(gpu_ctx, pkg, oracle):
+    """type_id selects the parameter set per robot (config 5 mixes A1 and Lite3)."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    gpu_ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), 10)
+    gpu_ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
+    ba = pkg.make_batch(16, 10, "a1", seed=21); bl = pkg.make_batch(16, 10, "lite3", seed=22)
+    b = dict(ba)
+    for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+        b[k] = np.concatenate([ba[k], bl[k]], axis=0)
+    b["n"] = 32
+    tid = np.array([0] * 16 + [1] * 16, np.int32)
+    out = G.run_mpc(gpu_ctx, pkg, b, type_id=tid)
+    assert np.all((out["status"] & 0xff) == 0)
+    fa, ta = _oracle_forces(oracle, pkg, ba, "a1"); fl, tl = _oracle_forces(oracle, pkg, bl, "lite3")
+    f = np.concatenate([fa, fl]); tau = np.concatenate([ta, tl])
+    assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau))
+
+
+def test_mpc_single_robot_interface(gpu_ctx, pkg, oracle):
+    """SetupProblem / SolveMPCKernel / GetMPCSolution, as SolveDenseMPC calls them."""
+    mpc = pkg.MPCInterface(gpu_ctx, 0)
+    c = pkg.mpc_cfg("a1")
+    assert mpc.GetMPCSolution(0) == 0.0            # has_solved == 0
+    mpc.SetupProblem(c[0], 10, c[1], c[2], c[3], c[4:7], c[7:19], c[19])
+    b = pkg.make_batch(4, 10, "a1", seed=31)
+    for i in range(4):
+        s = b["mpc_state"][i]
+        mpc.SolveMPCKernel(s[0:3], s[3:6], s[6:10], s[10:13], s[13:25].reshape(4, 3).T, s[25:28], b["traj"][i], b["gait"][i])
+        u, st, rc = oracle.mpc_solve(c, 10, s, b["traj"][i], b["gait"][i])
+        got = np.array([mpc.GetMPCSolution(k) for k in range(12)])
+        assert (mpc.status & 0xff) == 0
+        assert np.abs(got - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max())

@@ -1,0 +1,145 @@
+"""-m gpu: the HIP WBC kernel (through the C ABI) against the CPU oracle on identical inputs.
+
+The kernel evaluates the reference's formulas in fp64 on the fp32 inputs; the oracle is run both
+as written in the reference (fp32, T=float) and in fp64 (T=double).  Bars:
+  * vs the fp64 oracle: 1e-6 * max(1,|tau|)   (only the float32 output rounding is left)
+  * vs the fp32 oracle: 1e-4 * max(1,|tau|)   (north_star tolerance; the gap is the fp32 oracle's own rounding)
+"""
+import numpy as np
+import pytest
+
+import gpu_helpers as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_wbc(oracle, pkg, b, cmd=None, prev=None, dtype=np.float64, robot="a1"):
+    md = pkg.model_desc(robot)
+    n = b["n"]
+    cmd = b["wbc_cmd"] if cmd is None else cmd
+    prev = b["prev_ori_vel"] if prev is None else prev
+    tau = np.zeros((n, 12)); qdes = np.zeros((n, 12)); qddes = np.zeros((n, 12)); nact = np.zeros(n, int)
+    for i in range(n):
+        r = oracle.wbc_run(md, b["fb_state"][i].astype(dtype), cmd[i].astype(dtype), prev[i].astype(dtype), dtype=dtype)
+        assert r["rc"] == 0
+        tau[i], qdes[i], qddes[i], nact[i] = r["tau"], r["qdes"], r["qddes"], r["qp"]["n_active"]
+    return tau, qdes, qddes, nact
+
+
+def test_rigid_body_quantities(gpu_ctx, pkg, oracle):
+    """K8-K10: mass matrix, gravity, Coriolis, foot Jacobians, Jdot*qdot, foot positions/velocities."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(32, 10, "a1", seed=41)
+    got = G.run_fb_debug(gpu_ctx, pkg, b)
+    md = pkg.model_desc("a1")
+    for i in range(b["n"]):
+        r = oracle.fb_compute(md, b["fb_state"][i].astype(np.float64), np.float64)
+        for k, tol in (("H", 2e-6), ("G", 2e-5), ("C", 2e-6), ("Jc", 1e-6), ("Jcdqd", 2e-5), ("pGC", 1e-6), ("vGC", 1e-6)):
+            err = np.abs(got[k][i] - r[k]).max()
+            assert err <= tol * max(1.0, np.abs(r[k]).max()), (k, i, err)
+
+
+@pytest.mark.parametrize("seed,n", [(51, 256)])
+def test_wbc_parity(gpu_ctx, pkg, oracle, seed, n):
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(n, 10, "a1", seed=seed)
+    out = G.run_wbc(gpu_ctx, pkg, b)
+    assert np.all(out["status"] == 0), np.unique(out["status"])
+    tau64, qd64, qdd64, _ = _oracle_wbc(oracle, pkg, b, dtype=np.float64)
+    tau32, qd32, qdd32, _ = _oracle_wbc(oracle, pkg, b, dtype=np.float32)
+    assert np.all(np.abs(out["tau"] - tau64) <= G.tau_tol(tau64, 1e-6)), np.abs(out["tau"] - tau64).max()
+    assert np.all(np.abs(out["tau"] - tau32) <= G.tau_tol(tau32, 1e-4)), np.abs(out["tau"] - tau32).max()
+    assert np.abs(out["qdes"] - qd64).max() <= 1e-5 and np.abs(out["qddes"] - qdd64).max() <= 1e-4
+    # quirk 4: prev_ori_vel <- this tick's vBody_Ori_des
+    assert np.array_equal(out["prev"], b["wbc_cmd"][:, 12:15])
+
+
+def test_wbc_friction_active_and_stateful(gpu_ctx, pkg, oracle):
+    """Fr_des on/outside the WBC pyramid (mu = 0.4 < MPC's 0.45) makes the relaxation QP's inequalities
+    bind; a non-zero prev_ori_vel exercises the stateful orientation-rate quirk."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(64, 10, "a1", seed=61)
+    rng = np.random.default_rng(5)
+    cmd = b["wbc_cmd"].copy()
+    fr = cmd[:, 51:63].reshape(-1, 4, 3)
+    fr[:, :, 0] = 0.45 * fr[:, :, 2] * rng.choice([-1, 1], size=fr[:, :, 0].shape)
+    fr[:, :, 1] = 0.3 * fr[:, :, 2]
+    fr[::4, :, 2] *= 3.0                      # above maxFz for every 4th robot
+    cmd[:, 51:63] = fr.reshape(-1, 12)
+    prev = rng.uniform(-0.5, 0.5, (64, 3)).astype(np.float32)
+    out = G.run_wbc(gpu_ctx, pkg, b, wbc_cmd=cmd, prev=prev)
+    assert np.all(out["status"] == 0)
+    tau64, _, _, nact = _oracle_wbc(oracle, pkg, b, cmd=cmd, prev=prev, dtype=np.float64)
+    assert nact.max() > 0, "test must exercise active inequalities"
+    assert np.all(np.abs(out["tau"] - tau64) <= G.tau_tol(tau64, 1e-6)), np.abs(out["tau"] - tau64).max()
+
+
+def test_wbc_contact_patterns(gpu_ctx, pkg, oracle):
+    """flight (no contact: 6 tasks, dummy inequality), stand (4 contacts, no foot task), 3 and 1 contacts."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(16, 10, "a1", seed=71)
+    cmd = b["wbc_cmd"].copy()
+    pats = [(0, 0, 0, 0), (1, 1, 1, 1), (1, 1, 1, 0), (0, 1, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0), (1, 0, 1, 1), (0, 0, 1, 1)]
+    for i in range(16):
+        cmd[i, 63:67] = pats[i % 8]
+        cmd[i, 51:63] = (np.array(pats[i % 8], np.float32)[:, None] * np.array([1.0, -2.0, 30.0], np.float32)).reshape(12)
+    out = G.run_wbc(gpu_ctx, pkg, b, wbc_cmd=cmd)
+    assert np.all(out["status"] == 0)
+    tau64, qd64, qdd64, _ = _oracle_wbc(oracle, pkg, b, cmd=cmd, dtype=np.float64)
+    assert np.all(np.abs(out["tau"] - tau64) <= G.tau_tol(tau64, 1e-6)), np.abs(out["tau"] - tau64).max()
+    assert np.abs(out["qdes"] - qd64).max() <= 1e-5
+
+
+def test_wbc_straight_knee_rank_cut(gpu_ctx, pkg, oracle):
+    """Kinematic singularity (knee straight): pseudoInverse()'s singular-value cut changes the rank;
+    the kernel must take its eigen-decomposition path and agree with the SVD-based oracle."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(8, 10, "a1", seed=81)
+    fb = b["fb_state"].copy()
+    for i in range(8):
+        fb[i, 13 + 2] = 0.0 if i % 2 == 0 else 1e-5          # FR knee straight / almost straight
+        fb[i, 13 + 1] = 0.3
+    b["fb_state"] = fb
+    cmd = b["wbc_cmd"].copy()
+    cmd[:, 63:67] = (0, 1, 1, 0)                              # FR is a swing leg -> its foot task is rank deficient
+    cmd[:, 51:63] = (np.array([0, 1, 1, 0], np.float32)[:, None] * np.array([0.0, 0.0, 60.0], np.float32)).reshape(12)
+    out = G.run_wbc(gpu_ctx, pkg, b, wbc_cmd=cmd)
+    assert np.all(out["status"] == 0)
+    tau64, qd64, qdd64, _ = _oracle_wbc(oracle, pkg, b, cmd=cmd, dtype=np.float64)
+    assert np.all(np.abs(out["tau"] - tau64) <= G.tau_tol(tau64, 1e-5)), np.abs(out["tau"] - tau64).max()
+    assert np.abs(out["qdes"] - qd64).max() <= 1e-4
+
+
+def test_wbc_single_robot_interface_cadence(gpu_ctx, pkg, oracle):
+    """qrWbcLocomotionController::Run computes on every 2nd call and only overwrites stance legs."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(2, 10, "a1", seed=91)
+    wbc = pkg.WbcLocomotionController(gpu_ctx, 0)
+    md = pkg.model_desc("a1")
+    tua = np.full(12, 7.0, np.float32)
+    r0 = oracle.wbc_run(md, b["fb_state"][0].astype(np.float64), b["wbc_cmd"][0].astype(np.float64), dtype=np.float64)
+    wbc.Run(b["fb_state"][0], b["wbc_cmd"][0], tua)
+    contact = b["wbc_cmd"][0, 63:67]
+    for leg in range(4):
+        sl = slice(3 * leg, 3 * leg + 3)
+        if contact[leg]:
+            assert np.all(np.abs(tua[sl] - r0["tau"][sl]) <= G.tau_tol(r0["tau"][sl], 1e-6))
+        else:
+            assert np.all(tua[sl] == 7.0)
+    first = wbc.jointTorqueCmd.copy()
+    wbc.Run(b["fb_state"][1], b["wbc_cmd"][1], tua)           # odd call: no recompute
+    assert np.array_equal(first, wbc.jointTorqueCmd) and wbc.iteration == 2
+
+
+def test_full_tick(gpu_ctx, pkg, oracle):
+    """Config 3 of BASELINE.json in small: MPC -> Fr_des -> WBC, torque = WBC on stance legs, J^T f on swing legs."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(128, 10, "a1", seed=0xA4)
+    out = G.run_tick(gpu_ctx, pkg, b)
+    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    f, tau, st, sec, prev = oracle.tick_batch(1, pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
+                                              b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
+    assert np.all(st == 0)
+    assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
+    assert np.array_equal(out["prev"], prev)
