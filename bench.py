@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC+WBC control ticks/s over a batch of A1 robots (BASELINE.json configs[2]:
+1024 A1 instances, horizon 10, full MPC+WBC tick per robot), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one qrgpu_tick_batch over this rank's 1024 robots (inputs already resident in HBM) and, for
+N > 1, one RCCL all-gather of the per-robot torques (weak scaling: every rank owns 1024 robots).
+torch is plumbing only (device buffers, the stream, torch.distributed); the tick itself is two
+hand-written HIP kernels behind the C ABI of include/qrgpu.h.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+# SURVEY.md 8(d) algorithmic figures at h = 10 (dense counts, mul+add = 2)
+FLOP_K4_HESSIAN = 2 * 120 * 130 * 120            # 3.744 MFLOP
+FLOP_K4_GRADIENT = 2 * 120 * 130 + 2 * 130 * 13  # 34.6 kFLOP
+FLOP_K6_FACTOR = 120 ** 3 / 3.0                  # 0.576 MFLOP
+FLOP_K6_PER_ITER = 4 * 120 ** 2                  # 57.6 kFLOP per working-set change
+FLOP_WBC = 0.35e6
+BYTES_PER_TICK = 1216                            # algorithmic HBM bytes per full tick at h = 10
+PEAK_F32_MATRIX_TFLOPS = 157.3                   # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def _load_pkg():
+    d = os.path.join(ROOT, "quadruped-robot_amd")
+    spec = importlib.util.spec_from_file_location("quadruped_robot_amd", os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["quadruped_robot_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(pkg, b, horizon):
+    """The CPU restatement (oracle/, kind "port") timed on this box's host cores over a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    cfg, md = pkg.mpc_cfg("a1"), pkg.model_desc("a1")
+    args = (1, cfg, horizon, md[:3], md, b["mpc_state"], b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"])
+    n = b["n"]
+    # single thread on a 128-robot slice, all cores on the whole batch
+    sl = {k: (v[:128] if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+    t0 = time.perf_counter()
+    O.tick_batch(1, cfg, horizon, md[:3], md, sl["mpc_state"], sl["traj"], sl["gait"], sl["fb_state"], sl["wbc_cmd"],
+                 sl["prev_ori_vel"].copy(), nthreads=1)
+    t1 = time.perf_counter() - t0
+    passes, wall = 0, 0.0
+    while wall < 4.0 and passes < 8:
+        t0 = time.perf_counter()
+        O.tick_batch(*args, b["prev_ori_vel"].copy(), nthreads=cores)
+        wall += time.perf_counter() - t0
+        passes += 1
+    return dict(value=passes * n / wall, unit="ticks/s", cores=cores, kind="port",
+                sample="%d passes over the same %d-robot batch on %d threads (oracle/ CPU restatement, own fp64 active-set QP)"
+                       % (passes, n, cores),
+                single_thread_value=128 / t1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--robots", type=int, default=1024, help="robots per GPU")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--excite", type=float, default=1.0)
+    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = _load_pkg()
+    pkg._build.build()
+    n, h = args.robots, args.horizon
+    ctx = pkg.Context(device_id=local_rank, max_batch=n, horizon_max=16)   # raises without gfx950 / built library
+    ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h)
+    ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # every rank owns its own contiguous shard of the global robot population (seed offset by rank)
+    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite)
+    S = pkg.to_soa
+    T = lambda a: torch.from_numpy(S(a)).to(dev)
+    d_state, d_traj, d_gait = T(b["mpc_state"]), T(b["traj"]), T(b["gait"])
+    d_fb, d_cmd, d_prev = T(b["fb_state"]), T(b["wbc_cmd"]), T(b["prev_ori_vel"])
+    d_force = torch.zeros((12, n), dtype=torch.float32, device=dev)
+    d_tau = torch.zeros((12, n), dtype=torch.float32, device=dev)
+    d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
+    d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
+    d_tau_all = torch.zeros((world, 12, n), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        if args.mode == "tick":
+            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, d_tau, d_status)
+        elif args.mode == "mpc":
+            ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_force, d_tau, d_status)
+        else:
+            ctx.wbc_run_batch(n, d_fb, d_cmd, d_prev, d_tau, d_qdes, d_status)
+        if world > 1:
+            dist.all_gather_into_tensor(d_tau_all, d_tau)      # RCCL over xGMI: the only exchange of the path
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    mpc_ms, mpc_cnt = ctx.get_timing(0)
+    wbc_ms, wbc_cnt = ctx.get_timing(1)
+    ctx.enable_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    status = d_status.cpu().numpy()
+    iters = (status >> 8).astype(np.float64)
+    flags = status & 0xff
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * n * args.steps / elapsed
+        it_mean = float(iters.mean()) if args.mode != "wbc" else 0.0
+        flop_mpc = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + it_mean * FLOP_K6_PER_ITER
+        if args.mode == "wbc":
+            dom_ms, dom_flop, dom_name = wbc_ms, FLOP_WBC, "qr_wbc_kernel"
+        else:
+            dom_ms, dom_flop, dom_name = mpc_ms, flop_mpc, "qr_mpc_kernel"
+        achieved = (dom_flop * n) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom_name)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC+WBC control ticks/s (batched robots)" if args.mode == "tick" else "%s-only control ticks/s (batched robots)" % args.mode.upper(),
+            "value": value, "unit": "ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
+                       if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
+                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques" % world,
+                       "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum())},
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+                         "kernel_ms": dom_ms, "kernel_launches": mpc_cnt if dom_name == "qr_mpc_kernel" else wbc_cnt,
+                         "algorithmic_flop_per_robot": dom_flop, "other_kernel_ms": wbc_ms if dom_name == "qr_mpc_kernel" else mpc_ms,
+                         "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, b, h)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

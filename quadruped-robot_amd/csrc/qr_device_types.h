@@ -1,6 +1,7 @@
 // Shared host/device plain structs for the qrgpu kernels (gfx950).
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace qrgpu {
 
@@ -32,10 +33,10 @@ struct MpcLaunch {
 };
 
 // Bytes of LDS in front of the packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
-static inline size_t mpc_lds_fixed_bytes(int h)
+__host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h)
 {
     const size_t NV = 12 * (size_t)h, NL = 4 * (size_t)h;
-    size_t b = 8 * (4 * NV + 3 * QR_QH + NL);                    // xv wv zv yv dv rv uv fmk
+    size_t b = 8 * (3 * NV + QR_QH + NL);                        // gl wl yl rl fmk
     b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);          // sT sU sSt sTraj sGait sV
     b += 4 * (NL + QR_QH);                                       // sLs sAct
     b += 2 * (6 * NL + ((6 * NL) & 1));                          // sPos

@@ -1,7 +1,7 @@
 // ============================================================================
 // Convex-MPC tick for a batch of quadrupeds, one 256-thread workgroup per robot.
-// gfx950 (MI355X) only.  Everything between the coalesced state load and the
-// 24-float result store lives in LDS / registers.
+// gfx950 (MI355X) only.  Everything between the state load and the 24-float
+// result store lives in LDS / registers.
 //
 // Replaces, per robot (reference: TopHillRobotics/quadruped-robot, QS/ = quadruped/src/):
 //   K1  ComputeContinuousTimeStateSpaceMatrices   QS/controllers/mpc/qr_mpc_interface.cpp:296-331
@@ -13,15 +13,22 @@
 //   K7  force -> torque                            qr_mpc_stance_leg_controller.cpp:402-409,139-153,
 //                                                  QS/robots/qr_robot.cpp:148-172,241-251
 //
-// Phases (barriers between them):
-//   0  load state/traj/gait to LDS; 1  SRBD terms R, U_p = Iw^-1 [r_p]x, T_p = R'U_p, free
-//   (stance) leg-step list, v = Aqp x0 - X_d; 2  Hessian blocks for stance x stance leg-step
-//   pairs as fp32 k-ordered fmaf chains (bit-identical to the CPU oracle's dense GEMM: skipped
-//   terms are exact zeros), averaged with the transposed entry in fp64 -> packed lower triangle;
-//   3  in-place symmetric sweep inverse M = H^-1 (fp64, packed, LDS);  4  x = -M g;
-//   5  (wave 0 only) Goldfarb-Idnani dual active set in Schur-complement form: with the pyramid
-//   rows having <= 2 non-zeros, M c_p is two rows of M, S = N'MN is read off M, and S^-1 is kept
-//   explicitly by bordered-inverse updates;  6  J' f torques, store.
+// Data layout.  The unknowns are grouped by "leg-step" (one foot at one horizon step, 3 force
+// components); only stance leg-steps are free (swing ones are pinned to 0 by U_b = 0).  Every
+// matrix is handled as 3x3 blocks indexed by (leg-step, leg-step):
+//   phase 2  each thread owns up to MAXB lower-triangle blocks (a >= b) and builds them as fp32
+//            k-ordered fmaf chains -- bit-identical to the CPU oracle's dense GEMM, the skipped terms
+//            being exact zeros -- H[a][b] and H[b][a] separately, averaged in fp64;
+//   phase 3  in-place symmetric *block* sweep (Gauss-Jordan without pivoting on an SPD matrix) with
+//            the owned blocks held in registers; per pivot leg-step only the pivot block column goes
+//            through LDS (double-buffered, one barrier per pivot);  result  M = H^-1  -> LDS,
+//            block-packed lower triangle;
+//   phase 4  x = -M g;
+//   phase 5  wave 0 alone: Goldfarb-Idnani dual active set in Schur-complement form.  Lane k owns
+//            leg-step k (x_k, w_k, z_k in registers).  The pyramid rows touch one leg-step, so
+//            M c_p is one block column, S = N'MN is never formed: S^-1 is kept explicitly (packed,
+//            LDS) by bordered-inverse updates / downdates.  Reductions use DPP, broadcasts v_readlane;
+//   phase 6  f -> J'(-R'f) torques, store.
 // ============================================================================
 #include <hip/hip_runtime.h>
 #include "qr_device_types.h"
@@ -42,33 +49,175 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 __device__ __forceinline__ int pidx(int i, int j) { return i >= j ? tri(i) + j : tri(j) + i; }
 
-// Pyramid constraint `cid = 6*k + t` of free leg-step k (rows of f_block, :232-236, plus the
-// two-sided f_z row split in two):  c'u + ci0 >= 0 with c = ca*e[ia] + cb*e[ib].
-struct Cons { int ia, ib; double ca, cb; };
-__device__ __forceinline__ Cons decode_cons(int cid, double im)
+// ---- cross-lane helpers (wave64) ---------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
 {
-    const int k = cid / 6, t = cid - 6 * k;
-    Cons c;
-    c.ib = 3 * k + 2;
-    if (t < 4) { c.ia = 3 * k + (t >> 1); c.ca = (t & 1) ? -im : im; c.cb = 1.0; }
-    else       { c.ia = 3 * k + 2;        c.ca = (t == 4) ? 1.0 : -1.0; c.cb = 0.0; }
-    return c;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// srclane must be wave-uniform
+__device__ __forceinline__ double readlane_d(double v, int srclane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+// All-reduce inside each 16-lane row: xor 1, xor 2 (quad_perm), rotate by 4 and 8 (row_ror); then
+// the four row results are combined through v_readlane.  Result is wave-uniform.
+__device__ __forceinline__ double wave_min_d(double v)
+{
+    v = fmin(v, dpp_d<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_d<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_d<0x124>(v));     // row_ror:4
+    v = fmin(v, dpp_d<0x128>(v));     // row_ror:8
+    const double a = readlane_d(v, 0), b = readlane_d(v, 16), c = readlane_d(v, 32), d = readlane_d(v, 48);
+    return fmin(fmin(a, b), fmin(c, d));
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x124>(v);
+    v += dpp_d<0x128>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+// lowest lane whose predicate holds (or -1); uniform
+__device__ __forceinline__ int first_lane(bool pred)
+{
+    const unsigned long long m = __ballot(pred);
+    return m ? (int)__builtin_ctzll(m) : -1;
 }
 
-__global__ __launch_bounds__(QR_MPC_THREADS, 2)
+// Pyramid row `t` of a leg-step (rows of f_block, :232-236, with the two-sided f_z row split):
+//   c'f + ci0 >= 0,  c = (c0, c1, c2)
+__device__ __forceinline__ void cons_vec(int t, double im, double &c0, double &c1, double &c2)
+{
+    c0 = (t == 0) ? im : ((t == 1) ? -im : 0.0);
+    c1 = (t == 2) ? im : ((t == 3) ? -im : 0.0);
+    c2 = (t == 5) ? -1.0 : 1.0;
+}
+
+struct Blk { double m[9]; };
+
+// 3x3 block (a, b) of M read as seen from row leg-step `k` against column leg-step `kc`
+// (block-packed lower triangle, 9 doubles per block, row-major).
+__device__ __forceinline__ void load_block(const double *Mb, int k, int kc, Blk &B)
+{
+    // one code path for both triangles: element (i, j) sits at base + i*si + j*sj with (si, sj) = (3, 1) or (1, 3)
+    const bool lower = k >= kc;
+    const double *p = Mb + (lower ? tri(k) + kc : tri(kc) + k) * 9;
+    const int si = lower ? 3 : 1, sj = lower ? 1 : 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B.m[3 * i + j] = p[i * si + j * sj];
+}
+
+// One 3x3 block pair of the Hessian: hab = H[3a.., 3b..], hba = H[3b.., 3a..] as the fp32 k-ordered fmaf
+// chains of  qH = temp * Bqp  (:411), then out = (hab + hba')/2 in fp64.  la/lb: original leg-step ids
+// (4*step + leg).  The caller fences the scheduler between blocks so that only one block's temporaries are live.
+__device__ __forceinline__ Blk hess_block(const float *sT, const float *sU, int la, int lb, int h, float dt, float dt2, float minv,
+                                        const float *weights, float alpha, float *Hd, int NV)
+{
+    Blk out;
+    const int ia = la >> 2, pa = la & 3, ib = lb >> 2, pb = lb & 3;   // horizon step, leg
+    float w2[12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) w2[s] = 2.f * weights[s];
+    const float dtm = dt * minv;
+    const float two_alpha = 2.f * alpha;
+    float Ta[3][3], Tb[3][3], Ua[3][3], Ub[3][3], Uaw[3][3], Ubw[3][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Ta[s][j] = sT[9 * pa + 3 * s + j]; Tb[s][j] = sT[9 * pb + 3 * s + j];
+            Ua[s][j] = dt * sU[9 * pa + 3 * s + j]; Ub[s][j] = dt * sU[9 * pb + 3 * s + j];      // G rows 6-8
+            Uaw[s][j] = Ua[s][j] * w2[6 + s]; Ubw[s][j] = Ub[s][j] * w2[6 + s];                  // temp = G*2w
+        }
+    float hab[3][3], hba[3][3];      // hab[i][j] = H[3a+i][3b+j],  hba[j][i] = H[3b+j][3a+i]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { hab[i][j] = 0.f; hba[j][i] = 0.f; }
+    const int r0 = ia > ib ? ia : ib;
+    for (int r = r0; r < h; ++r) {
+        const float caa = ((float)(r - ia) + 0.5f) * dt2, cab = ((float)(r - ib) + 0.5f) * dt2;
+        // s = 0..2 : rows c_a * T
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float ga[3], gb[3], gaw[3], gbw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ga[j] = caa * Ta[s][j]; gb[j] = cab * Tb[s][j];
+                gaw[j] = ga[j] * w2[s]; gbw[j] = gb[j] * w2[s];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    hab[i][j] = __builtin_fmaf(gaw[i], gb[j], hab[i][j]);
+                    hba[j][i] = __builtin_fmaf(gbw[j], ga[i], hba[j][i]);
+                }
+        }
+        // s = 3..5 : rows (c_a/m) e_i  -> only the (i,i) entry of the block
+        {
+            const float cama = caa * minv, camb = cab * minv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                hab[i][i] = __builtin_fmaf(cama * w2[3 + i], camb, hab[i][i]);
+                hba[i][i] = __builtin_fmaf(camb * w2[3 + i], cama, hba[i][i]);
+            }
+        }
+        // s = 6..8 : rows dt * U
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    hab[i][j] = __builtin_fmaf(Uaw[s][i], Ub[s][j], hab[i][j]);
+                    hba[j][i] = __builtin_fmaf(Ubw[s][j], Ua[s][i], hba[j][i]);
+                }
+        // s = 9..11 : rows (dt/m) e_i
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            hab[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hab[i][i]);
+            hba[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hba[i][i]);
+        }
+    }
+    if (la == lb) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { hab[i][i] = hab[i][i] + two_alpha; hba[i][i] = hba[i][i] + two_alpha; }   // + 2 alpha I (:411)
+    }
+    // the stated QP depends on H only through (H + H')/2: average the two fp32 entries exactly in fp64
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out.m[3 * i + j] = 0.5 * ((double)hab[i][j] + (double)hba[j][i]);
+    if (Hd) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Hd[(size_t)(3 * la + i) * NV + 3 * lb + j] = hab[i][j];
+                Hd[(size_t)(3 * lb + j) * NV + 3 * la + i] = hba[j][i];
+            }
+    }
+    return out;
+}
+
+template <int MAXB>
+__global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
 void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
                    const float *__restrict__ g_traj, const float *__restrict__ g_gait, const float *__restrict__ g_q,
                    float *__restrict__ g_force, float *__restrict__ g_tau, int *__restrict__ g_status,
-                   float *__restrict__ dbgH, float *__restrict__ dbgG, float *__restrict__ g_force_wbc, int force_stride)
+                   float *__restrict__ dbgH, float *__restrict__ dbgG, float *__restrict__ g_force_wbc, int force_stride,
+                   long long *__restrict__ dbgT)
 {
     const int rid = blockIdx.x;
     const int tid = threadIdx.x;
@@ -79,16 +228,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int h = P.horizon;
     const int NV = 12 * h, NL = 4 * h;
 
-    // ---------------- LDS carve ----------------
+    // ---------------- LDS carve (must match mpc_lds_fixed_bytes) ----------------
     extern __shared__ double smem[];
-    double *xv = smem;                 // [NV] primal
-    double *wv = xv + NV;              // [NV] M c_p; sweep pivot column
-    double *zv = wv + NV;              // [NV] primal step
-    double *yv = zv + NV;              // [NV] g, later N r
-    double *dv = yv + NV;              // [QH] N' w
-    double *rv = dv + QR_QH;           // [QH] S^-1 d
-    double *uv = rv + QR_QH;           // [QH] multipliers
-    double *fmk = uv + QR_QH;          // [NL] f_z upper bound per free leg-step
+    double *gl = smem;                 // [NV] gradient (free variables, leg-step major)
+    double *wl = gl + NV;              // [NV] staging of w
+    double *yl = wl + NV;              // [NV] staging of y = N r
+    double *rl = yl + NV;              // [QH] staging of r
+    double *fmk = rl + QR_QH;          // [NL] f_z upper bound per free leg-step
     float *sT = (float *)(fmk + NL);   // [4][3][3]
     float *sU = sT + 36;               // [4][3][3]
     float *sSt = sU + 36;              // [28]
@@ -96,11 +242,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     float *sGait = sTraj + NV;         // [4h]
     float *sV = sGait + NL;            // [13h]
     int *sLs = (int *)(sV + 13 * h);   // [NL] free leg-step -> original leg-step
-    int *sAct = sLs + NL;              // [QH] active constraint ids
+    int *sAct = sLs + NL;              // [QH] active constraint ids (6*k + t)
     short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> position in sAct, or -1
     int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [4]
-    double *Mp = (double *)(((uintptr_t)(sMisc + 4) + 7) & ~(uintptr_t)7);
+    // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
+    double *Mb = smem + (int)(mpc_lds_fixed_bytes(h) / 8);   // block-packed M; the sweep panels live here first
 
+    long long tstamp[7];
+    tstamp[0] = clock64();
     // ---------------- phase 0: inputs ----------------
     if (tid < 28) sSt[tid] = g_state[(size_t)tid * n + rid];
     for (int i = tid; i < NV; i += QR_MPC_THREADS) sTraj[i] = g_traj[(size_t)i * n + rid];
@@ -198,19 +347,22 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         sV[13 * r + 12] = ax[12] - 0.f;
     }
     __syncthreads();
-    const int nls = sMisc[0];
+    tstamp[1] = clock64();
+    // LDS loads count as divergent for the compiler; make the sizes scalar so that loops and branches on them are SALU
+    const int nls = __builtin_amdgcn_readfirstlane(sMisc[0]);
     const int ns = 3 * nls;
-    const size_t lds_doubles = (size_t)P.lds_bytes / 8;
-    const size_t mp_off = (size_t)(Mp - smem);
-    double *Sinv = Mp + tri(ns);
+    const int npairs = tri(nls);
+    double *Sinv = Mb + npairs * 9;
     int qcap;
-    {   // rows of S^-1 that fit behind the packed M
-        long long rem = (long long)lds_doubles - (long long)mp_off - (long long)tri(ns);
+    {   // rows of S^-1 that fit behind M
+        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9;
         int qc = 0;
         if (rem > 0) { qc = (int)((__builtin_sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5); while (tri(qc) > rem) --qc; }
         qcap = qc < QR_QH ? qc : QR_QH;
         if (qcap > ns) qcap = ns;
     }
+    int st = 0;
+    if (npairs > MAXB * QR_MPC_THREADS) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
 
     float w2[13];
 #pragma unroll
@@ -219,95 +371,23 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const float dtm = dt * minv;
     const float two_alpha = 2.f * C.alpha;
 
-    // ---------------- phase 2: Hessian blocks + gradient ----------------
-    const int npairs = tri(nls);
-    for (int pid = tid; pid < npairs; pid += QR_MPC_THREADS) {
-        int a = (int)((__builtin_sqrtf(8.f * (float)pid + 1.f) - 1.f) * 0.5f);
-        while (tri(a + 1) <= pid) ++a;
-        while (tri(a) > pid) --a;
-        const int b = pid - tri(a);                 // a >= b
-        const int la = sLs[a], lb = sLs[b];
-        const int ia = la >> 2, pa = la & 3, ib = lb >> 2, pb = lb & 3;   // horizon step, leg
-        float Ta[3][3], Tb[3][3], Ua[3][3], Ub[3][3], Uaw[3][3], Ubw[3][3];
+    // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
+    Blk A[MAXB];
+    int ba[MAXB], bb[MAXB];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Ta[s][j] = sT[9 * pa + 3 * s + j]; Tb[s][j] = sT[9 * pb + 3 * s + j];
-                Ua[s][j] = dt * sU[9 * pa + 3 * s + j]; Ub[s][j] = dt * sU[9 * pb + 3 * s + j];      // G rows 6-8
-                Uaw[s][j] = Ua[s][j] * w2[6 + s]; Ubw[s][j] = Ub[s][j] * w2[6 + s];                  // temp = G*2w
-            }
-        float hab[3][3], hba[3][3];      // hab[i][j] = H[3a+i][3b+j],  hba[j][i] = H[3b+j][3a+i]
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { hab[i][j] = 0.f; hba[j][i] = 0.f; }
-        const int r0 = ia > ib ? ia : ib;
-        for (int r = r0; r < h; ++r) {
-            const float caa = ((float)(r - ia) + 0.5f) * dt2, cab = ((float)(r - ib) + 0.5f) * dt2;
-            // s = 0..2 : rows c_a * T
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                float ga[3], gb[3], gaw[3], gbw[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    ga[j] = caa * Ta[s][j]; gb[j] = cab * Tb[s][j];
-                    gaw[j] = ga[j] * w2[s]; gbw[j] = gb[j] * w2[s];
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        hab[i][j] = __builtin_fmaf(gaw[i], gb[j], hab[i][j]);
-                        hba[j][i] = __builtin_fmaf(gbw[j], ga[i], hba[j][i]);
-                    }
-            }
-            // s = 3..5 : rows (c_a/m) e_i  -> only the (i,i) entry of the block
-            {
-                const float cama = caa * minv, camb = cab * minv;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    hab[i][i] = __builtin_fmaf(cama * w2[3 + i], camb, hab[i][i]);
-                    hba[i][i] = __builtin_fmaf(camb * w2[3 + i], cama, hba[i][i]);
-                }
-            }
-            // s = 6..8 : rows dt * U
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        hab[i][j] = __builtin_fmaf(Uaw[s][i], Ub[s][j], hab[i][j]);
-                        hba[j][i] = __builtin_fmaf(Ubw[s][j], Ua[s][i], hba[j][i]);
-                    }
-            // s = 9..11 : rows (dt/m) e_i
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                hab[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hab[i][i]);
-                hba[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hba[i][i]);
-            }
+    for (int sl = 0; sl < MAXB; ++sl) {
+        const int pid = tid + QR_MPC_THREADS * sl;
+        ba[sl] = -1; bb[sl] = -1;
+        if (pid < npairs) {
+            int a = (int)((__builtin_sqrtf(8.f * (float)pid + 1.f) - 1.f) * 0.5f);
+            while (tri(a + 1) <= pid) ++a;
+            while (tri(a) > pid) --a;
+            const int b = pid - tri(a);                 // a >= b
+            ba[sl] = a; bb[sl] = b;
+            A[sl] = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
+                       dbgH ? dbgH + (size_t)rid * NV * NV : nullptr, NV);
         }
-        if (a == b) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { hab[i][i] = hab[i][i] + two_alpha; hba[i][i] = hba[i][i] + two_alpha; }   // + 2 alpha I (:411)
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (a > b || j <= i) Mp[tri(3 * a + i) + 3 * b + j] = 0.5 * ((double)hab[i][j] + (double)hba[j][i]);
-            }
-        if (dbgH) {
-            float *Hd = dbgH + (size_t)rid * NV * NV;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    Hd[(size_t)(3 * la + i) * NV + 3 * lb + j] = hab[i][j];
-                    Hd[(size_t)(3 * lb + j) * NV + 3 * la + i] = hba[j][i];
-                }
-        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the blocks' temporaries from overlapping (register pressure)
     }
     // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread
     for (int e = tid; e < ns; e += QR_MPC_THREADS) {
@@ -328,201 +408,336 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             acc = __builtin_fmaf(u2, vr[8], acc);
             acc = __builtin_fmaf(dw, vr[9 + j], acc);
         }
-        yv[e] = (double)acc;
+        gl[e] = (double)acc;
         if (dbgG) dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
-    __syncthreads();
+    for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
+    tstamp[2] = clock64();
 
-    // ---------------- phase 3: packed symmetric sweep, Mp <- -H^-1 ----------------
-    int st = 0;
+    // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
+    // Pivot leg-step k:  P = A_kk,  C_i = A_ik (i > k) or A_ki' (i < k);
+    //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
+    // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
     {
-        const int tx = tid & 15, ty = tid >> 4;
-        const int nt = (ns + 15) >> 4;
-        for (int k = 0; k < ns; ++k) {
-            for (int i = tid; i < ns; i += QR_MPC_THREADS) wv[i] = Mp[pidx(i, k)];
-            __syncthreads();
-            const double piv = wv[k];
-            if (!(piv > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
-            const double ip = 1.0 / piv;
-            for (int ta = 0; ta < nt; ++ta) {
-                const int i = 16 * ta + ty;
-                const double ci = (i < ns) ? wv[i] : 0.0;
-                for (int tb = 0; tb <= ta; ++tb) {
-                    const int j = 16 * tb + tx;
-                    if (i < ns && j <= i) {
-                        const double cj = wv[j];
-                        double *m = &Mp[tri(i) + j];
-                        double v;
-                        if (i == k) v = (j == k) ? -ip : cj * ip;
-                        else if (j == k) v = ci * ip;
-                        else v = *m - ci * cj * ip;
-                        *m = v;
-                    }
+        double *panel0 = Mb, *panel1 = Mb + NL * 9;
+        for (int k = 0; k < nls; ++k) {
+            double *pan = (k & 1) ? panel1 : panel0;
+#pragma unroll
+            for (int sl = 0; sl < MAXB; ++sl) {
+                if (bb[sl] == k) {                       // block (a, k), a >= k: C_a = A
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) pan[9 * ba[sl] + i] = A[sl].m[i];
+                } else if (ba[sl] == k) {                // block (k, b), b < k: C_b = A'
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) pan[9 * bb[sl] + 3 * j + i] = A[sl].m[3 * i + j];
                 }
             }
             __syncthreads();
+            // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per thread
+            double Pi[9];
+            {
+                const double *Pk = pan + 9 * k;
+                const double p00 = Pk[0], p01 = 0.5 * (Pk[1] + Pk[3]), p02 = 0.5 * (Pk[2] + Pk[6]), p11 = Pk[4], p12 = 0.5 * (Pk[5] + Pk[7]), p22 = Pk[8];
+                const double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
+                const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
+                const double det = p00 * c00 + p01 * c01 + p02 * c02;
+                if (!(det > 0.0) || !(p00 > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
+                const double id = 1.0 / det;
+                Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
+                Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
+                Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
+            }
+#pragma unroll
+            for (int sl = 0; sl < MAXB; ++sl) {
+                const int a = ba[sl], b = bb[sl];
+                if (a < 0) continue;
+                // D = C_x P^-1, x = the non-pivot index of the block (any index for the pivot block itself)
+                const double *Cx = pan + 9 * (a == k ? b : a);
+                double D[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) D[3 * i + j] = Cx[3 * i] * Pi[j] + Cx[3 * i + 1] * Pi[3 + j] + Cx[3 * i + 2] * Pi[6 + j];
+                if (a != k && b != k) {
+                    const double *Cb = pan + 9 * b;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            A[sl].m[3 * i + j] -= D[3 * i] * Cb[3 * j] + D[3 * i + 1] * Cb[3 * j + 1] + D[3 * i + 2] * Cb[3 * j + 2];
+                } else {
+                    // pivot row / column: A_xk = D (x > k), A_kx = D' (x < k), A_kk = -P^-1
+                    const bool piv = (a == k && b == k), tr = (a == k);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) A[sl].m[3 * i + j] = piv ? -Pi[3 * i + j] : (tr ? D[3 * j + i] : D[3 * i + j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();           // everybody is done with the panels before M overwrites them
+#pragma unroll
+        for (int sl = 0; sl < MAXB; ++sl) {
+            if (ba[sl] >= 0) {
+                double *dst = Mb + (tri(ba[sl]) + bb[sl]) * 9;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dst[i] = -A[sl].m[i];         // M = +H^-1
+            }
+        }
+        __syncthreads();
+    }
+    tstamp[3] = clock64();
+    if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below
+
+    // ---------------- phase 4: x = -M g  (lane k owns leg-step k) ----------------
+    const bool own = lane < nls;
+    const int kme = own ? lane : 0;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (own) {
+        for (int kc = 0; kc < nls; ++kc) {
+            Blk B; load_block(Mb, kme, kc, B);
+            const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
+            x0 -= B.m[0] * g0 + B.m[1] * g1 + B.m[2] * g2;
+            x1 -= B.m[3] * g0 + B.m[4] * g1 + B.m[5] * g2;
+            x2 -= B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
         }
     }
-    // ---------------- phase 4: x = -M g = Mp g ----------------
-    for (int e = tid; e < ns; e += QR_MPC_THREADS) {
-        double acc = 0.0;
-        for (int j = 0; j < ns; ++j) acc += Mp[pidx(e, j)] * yv[j];
-        xv[e] = acc;
-    }
-    for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
-    __syncthreads();
-    if (tid >= 64) return;          // the active-set loop is a single wavefront; no barrier below
+    tstamp[4] = clock64();
 
     // ---------------- phase 5: dual active set (wave 0) ----------------
-    // NOTE Mp holds -H^-1: every use below flips the sign.
     const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
+    const double fmaxk = own ? fmk[kme] : 0.0;
+    const int tril = tri(lane);
     const double tol = 1e-9;
+    const double INF = __builtin_inf();
+    long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = 0;
+#define QR_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
     int q = 0, iter = 0;
+    unsigned amask = 0;                               // active rows of my leg-step (6 bits)
+    double u0 = 0.0, u1 = 0.0;                        // multipliers of working-set positions lane, lane+64
     const int maxit = 40 * nls + 100;
     bool done = (nls == 0);
     while (!done) {
-        // step 1: most violated inactive constraint (ties -> lowest id)
-        double bs = -tol; int bc = 0x7fffffff;
-        for (int c = lane; c < 6 * nls; c += 64) {
-            if (sPos[c] >= 0) continue;
-            const Cons cc = decode_cons(c, im);
-            double s = cc.ca * xv[cc.ia] + cc.cb * xv[cc.ib];
-            if (c - 6 * (c / 6) == 5) s += fmk[c / 6];
-            if (s < bs) { bs = s; bc = c; }
-        }
+        if (dbgT) tq0 = clock64();
+        // step 1: most violated inactive row (ties -> lowest id)
+        double bs = INF; int bt = 0;
+        if (own) {
+            const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double os = __shfl_xor(bs, m, 64); const int oc = __shfl_xor(bc, m, 64);
-            if (os < bs || (os == bs && oc < bc)) { bs = os; bc = oc; }
+            for (int t = 0; t < 6; ++t) if (!((amask >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
         }
-        if (bc == 0x7fffffff) break;
-        const int p = bc;
-        const Cons cp = decode_cons(p, im);
-        const double ci0p = (p - 6 * (p / 6) == 5) ? fmk[p / 6] : 0.0;
+        const double smin = wave_min_d(bs);
+        if (!(smin < -tol)) break;
+        const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
+        const int tp = __builtin_amdgcn_readlane(bt, kp);
+        const int p = 6 * kp + tp;
+        double c0, c1, c2;
+        cons_vec(tp, im, c0, c1, c2);
+        const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
         double up = 0.0;
+        QR_STAMP(0);
         for (;;) {
+            q = __builtin_amdgcn_readfirstlane(q);           // q is wave-uniform by construction; tell the compiler
             if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
-            // w = M c_p
-            for (int e = lane; e < ns; e += 64) wv[e] = -(cp.ca * Mp[pidx(e, cp.ia)] + cp.cb * Mp[pidx(e, cp.ib)]);
-            wave_sync();
-            const double delta = cp.ca * wv[cp.ia] + cp.cb * wv[cp.ib];
-            // d = N' w ; r = S^-1 d
-            for (int j = lane; j < q; j += 64) { const Cons cj = decode_cons(sAct[j], im); dv[j] = cj.ca * wv[cj.ia] + cj.cb * wv[cj.ib]; }
-            wave_sync();
-            double dr = 0.0;
-            for (int i = lane; i < q; i += 64) {
-                double acc = 0.0;
-                for (int j = 0; j < q; ++j) acc += Sinv[pidx(i, j)] * dv[j];
-                rv[i] = acc;
-                dr += acc * dv[i];
+            // w_k = M_{k,kp} c_p
+            double w0 = 0.0, w1 = 0.0, w2_ = 0.0;
+            if (own) {
+                Blk B; load_block(Mb, kme, kp, B);
+                w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
+                w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
+                w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
+                wl[3 * kme] = w0; wl[3 * kme + 1] = w1; wl[3 * kme + 2] = w2_;
             }
-            dr = wave_sum(dr);
+            const double delta = c0 * readlane_d(w0, kp) + c1 * readlane_d(w1, kp) + c2 * readlane_d(w2_, kp);
             wave_sync();
+            QR_STAMP(1);
+            // d = N' w  (position i lives in lane i & 63, slot i >> 6)
+            double d0 = 0.0, d1 = 0.0;
+            {
+                if (lane < q) { const int cj = sAct[lane]; const int kj = cj / 6; double a0, a1, a2; cons_vec(cj - 6 * kj, im, a0, a1, a2);
+                                d0 = a0 * wl[3 * kj] + a1 * wl[3 * kj + 1] + a2 * wl[3 * kj + 2]; }
+                if (q > 64 && lane + 64 < q) { const int cj = sAct[lane + 64]; const int kj = cj / 6; double a0, a1, a2; cons_vec(cj - 6 * kj, im, a0, a1, a2);
+                                     d1 = a0 * wl[3 * kj] + a1 * wl[3 * kj + 1] + a2 * wl[3 * kj + 2]; }
+            }
+            // r = S^-1 d.  Lane i owns position i (and i + 64 in the rare q > 64 case).  S^-1 is packed lower:
+            // (i, j) at tri(i) + j for j <= i, else tri(j) + i.  Four loads are issued before they are consumed.
+            double r0 = 0.0, r1 = 0.0;
+            {
+                const int q0 = q < 64 ? q : 64;
+                const int i0 = (lane < q) ? lane : 0;
+                int j = 0;
+                for (; j + 4 <= q0; j += 4) {
+                    double sv[4], dj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int jj = j + u;
+                        sv[u] = Sinv[(jj <= i0) ? tril + jj : tri(jj) + i0];
+                        dj[u] = readlane_d(d0, jj);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r0 += sv[u] * dj[u];
+                }
+                for (; j < q0; ++j) r0 += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(d0, j);
+                if (lane >= q) r0 = 0.0;
+                if (q > 64) {                     // cold path: positions 64..q-1
+                    const int i1 = lane + 64;
+                    for (int jj = 64; jj < q; ++jj) { const double dj = readlane_d(d1, jj - 64); if (lane < q) r0 += Sinv[pidx(lane, jj)] * dj; }
+                    for (int jj = 0; jj < q; ++jj) {
+                        const double dj = (jj < 64) ? readlane_d(d0, jj) : readlane_d(d1, jj - 64);
+                        if (i1 < q) r1 += Sinv[pidx(i1, jj)] * dj;
+                    }
+                }
+            }
+            QR_STAMP(2);
+            const double dr = wave_sum_d(r0 * d0 + r1 * d1);
             const double zc = delta - dr;                    // z'c_p
-            // dual step length
-            double t1 = __builtin_inf(); int lpos = 0x7fffffff;
-            for (int j = lane; j < q; j += 64) {
-                const double rj = rv[j];
-                if (rj > 0.0) { const double tt = uv[j] / rj; if (tt < t1) { t1 = tt; lpos = j; } }
+            // dual step length: min u_j / r_j over r_j > 0
+            double tt = INF;
+            if (lane < q && r0 > 0.0) tt = u0 / r0;
+            double tt1 = INF;
+            if (lane + 64 < q && r1 > 0.0) tt1 = u1 / r1;
+            const double t1 = wave_min_d(fmin(tt, tt1));
+            int lpos = -1;
+            if (t1 < INF) {
+                const int la = first_lane(tt == t1);
+                lpos = (la >= 0) ? la : 64 + first_lane(tt1 == t1);
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const double ot = __shfl_xor(t1, m, 64); const int ol = __shfl_xor(lpos, m, 64);
-                if (ot < t1 || (ot == t1 && ol < lpos)) { t1 = ot; lpos = ol; }
-            }
-            const double sp = cp.ca * xv[cp.ia] + cp.cb * xv[cp.ib] + ci0p;
+            const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
             const bool have_z = zc > 1e-13 * delta;
-            const double t2 = have_z ? -sp / zc : __builtin_inf();
+            const double t2 = have_z ? -sp / zc : INF;
             const double t = t1 < t2 ? t1 : t2;
-            if (!(t < __builtin_inf())) { st |= QRGPU_ST_MPC_INFEAS_D; done = true; break; }
+            if (!(t < INF)) { st |= QRGPU_ST_MPC_INFEAS_D; done = true; break; }
+            QR_STAMP(3);
             if (have_z) {
-                // y = N r (gathered per variable), z = w - M y, x += t z
-                for (int e = lane; e < ns; e += 64) {
-                    const int k = e / 3, ax = e - 3 * k;
-                    double acc = 0.0;
-                    if (ax == 2) {
-#pragma unroll
-                        for (int tt = 0; tt < 6; ++tt) { const int ps = sPos[6 * k + tt]; if (ps >= 0) acc += (tt == 5 ? -1.0 : 1.0) * rv[ps]; }
-                    } else {
-                        const int p0 = sPos[6 * k + 2 * ax], p1 = sPos[6 * k + 2 * ax + 1];
-                        if (p0 >= 0) acc += im * rv[p0];
-                        if (p1 >= 0) acc -= im * rv[p1];
-                    }
-                    yv[e] = acc;
-                }
+                // y_k = sum of active rows of my leg-step times r;  z = w - M y;  x += t z
+                if (lane < q) rl[lane] = r0;
+                if (q > 64 && lane + 64 < q) rl[lane + 64] = r1;
                 wave_sync();
-                for (int e = lane; e < ns; e += 64) {
-                    double acc = wv[e];
-                    for (int k = 0; k < nls; ++k) {
-                        const short *pk = sPos + 6 * k;
-                        if ((pk[0] & pk[1] & pk[2] & pk[3] & pk[4] & pk[5]) >= 0) {    // any constraint of leg-step k active
-                            acc += Mp[pidx(e, 3 * k)] * yv[3 * k] + Mp[pidx(e, 3 * k + 1)] * yv[3 * k + 1] + Mp[pidx(e, 3 * k + 2)] * yv[3 * k + 2];
+                double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+                if (own && amask) {
+#pragma unroll
+                    for (int tq = 0; tq < 6; ++tq)
+                        if ((amask >> tq) & 1u) {
+                            const double rr = rl[sPos[6 * kme + tq]];
+                            double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
+                            y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
                         }
-                    }
-                    zv[e] = acc;
-                    xv[e] += t * acc;
                 }
+                unsigned long long km = __ballot(own && amask != 0);
+                double z0 = w0, z1 = w1, z2 = w2_;
+                while (km) {
+                    const int kc = (int)__builtin_ctzll(km);
+                    km &= km - 1;
+                    int kc2 = -1;
+                    if (km) { kc2 = (int)__builtin_ctzll(km); km &= km - 1; }
+                    Blk B, B2;
+                    load_block(Mb, kme, kc, B);
+                    load_block(Mb, kme, kc2 >= 0 ? kc2 : kc, B2);
+                    const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
+                    const int kr = kc2 >= 0 ? kc2 : 0;
+                    const double sc = kc2 >= 0 ? 1.0 : 0.0;
+                    const double p0 = sc * readlane_d(y0, kr), p1 = sc * readlane_d(y1, kr), p2 = sc * readlane_d(y2, kr);
+                    z0 -= (B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2) + (B2.m[0] * p0 + B2.m[1] * p1 + B2.m[2] * p2);
+                    z1 -= (B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2) + (B2.m[3] * p0 + B2.m[4] * p1 + B2.m[5] * p2);
+                    z2 -= (B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2) + (B2.m[6] * p0 + B2.m[7] * p1 + B2.m[8] * p2);
+                }
+                x0 += t * z0; x1 += t * z1; x2 += t * z2;
             }
-            for (int j = lane; j < q; j += 64) uv[j] -= t * rv[j];
+            QR_STAMP(4);
+            u0 -= t * r0; u1 -= t * r1;
             up += t;
-            wave_sync();
             if (have_z && t == t2) {
                 // full step: p joins the working set; bordered update of S^-1
                 if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
                 const double isg = 1.0 / zc;
-                for (int e = lane; e < tri(q); e += 64) {
-                    int i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
-                    while (tri(i + 1) <= e) ++i;
-                    while (tri(i) > e) --i;
-                    const int j = e - tri(i);
-                    Sinv[e] += rv[i] * rv[j] * isg;
+                {
+                    // row i of the lower triangle belongs to lane i: S^-1(i, j) += r_i r_j / sigma for j <= i
+                    const int q0 = q < 64 ? q : 64;
+                    const bool act0 = lane < q;
+                    const double ri = r0 * isg;
+                    int j = 0;
+                    for (; j + 4 <= q0; j += 4) {
+                        double sv[4], rj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { rj[u] = readlane_d(r0, j + u); sv[u] = (act0 && j + u <= lane) ? Sinv[tril + j + u] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (act0 && j + u <= lane) Sinv[tril + j + u] = sv[u] + ri * rj[u];
+                    }
+                    for (; j < q0; ++j) { const double rj = readlane_d(r0, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
+                    if (q > 64) {                 // cold path
+                        const int i1 = lane + 64;
+                        for (int jj = 0; jj < q; ++jj) {
+                            const double rj = ((jj < 64) ? readlane_d(r0, jj) : readlane_d(r1, jj - 64)) * isg;
+                            if (i1 < q && jj <= i1) Sinv[tri(i1) + jj] += r1 * rj;
+                        }
+                        if (i1 < q) Sinv[tri(q) + i1] = -r1 * isg;
+                    }
+                    if (act0) Sinv[tri(q) + lane] = -r0 * isg;
                 }
-                for (int j = lane; j < q; j += 64) Sinv[tri(q) + j] = -rv[j] * isg;
-                if (lane == 0) { Sinv[tri(q) + q] = isg; sAct[q] = p; sPos[p] = (short)q; uv[q] = up; }
+                if (lane == 0) { Sinv[tri(q) + q] = isg; sAct[q] = p; sPos[p] = (short)q; }
+                if (lane == (q & 63)) { if (q < 64) u0 = up; else u1 = up; }
+                if (lane == kp) amask |= 1u << tp;
                 ++q;
                 wave_sync();
+                QR_STAMP(5);
                 break;
             }
-            // partial or dual-only step: constraint at lpos leaves; downdate S^-1, move last into its slot
+            // partial or dual-only step: the constraint at lpos leaves; downdate S^-1, move the last one into its slot
             {
                 const int l = lpos, last = q - 1;
-                for (int i = lane; i < q; i += 64) dv[i] = Sinv[pidx(i, l)];
+                double s0 = 0.0, s1 = 0.0;                    // column l of S^-1
+                if (lane < q) s0 = Sinv[pidx(lane, l)];
+                if (lane + 64 < q) s1 = Sinv[pidx(lane + 64, l)];
+                const double isl = 1.0 / ((l < 64) ? readlane_d(s0, l) : readlane_d(s1, l - 64));
                 wave_sync();
-                const double isl = 1.0 / dv[l];
-                for (int e = lane; e < tri(q); e += 64) {
-                    int i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
-                    while (tri(i + 1) <= e) ++i;
-                    while (tri(i) > e) --i;
-                    const int j = e - tri(i);
-                    if (i != l && j != l) Sinv[e] -= dv[i] * dv[j] * isl;
+                {
+                    const int i0 = lane, i1 = lane + 64;
+                    for (int j = 0; j < q; ++j) {
+                        if (j == l) continue;
+                        const double sj = ((j < 64) ? readlane_d(s0, j) : readlane_d(s1, j - 64)) * isl;
+                        if (i0 < q && i0 != l && j <= i0) Sinv[tri(i0) + j] -= s0 * sj;
+                        if (i1 < q && i1 != l && j <= i1) Sinv[tri(i1) + j] -= s1 * sj;
+                    }
                 }
                 wave_sync();
+                const int cl = sAct[l], clast = sAct[last];
                 if (l != last) {
-                    for (int j = lane; j < last; j += 64) rv[j] = (j == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, j)];
+                    double m0 = 0.0, m1 = 0.0;
+                    if (lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
+                    if (lane + 64 < last) m1 = (lane + 64 == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane + 64)];
                     wave_sync();
-                    for (int j = lane; j < last; j += 64) Sinv[pidx(l, j)] = rv[j];
+                    if (lane < last) Sinv[pidx(l, lane)] = m0;
+                    if (lane + 64 < last) Sinv[pidx(l, lane + 64)] = m1;
+                    const double ulast = (last < 64) ? readlane_d(u0, last) : readlane_d(u1, last - 64);
+                    if (lane == (l & 63)) { if (l < 64) u0 = ulast; else u1 = ulast; }
                 }
+                wave_sync();
                 if (lane == 0) {
-                    sPos[sAct[l]] = -1;
-                    if (l != last) { sAct[l] = sAct[last]; uv[l] = uv[last]; sPos[sAct[l]] = (short)l; }
+                    sPos[cl] = -1;
+                    if (l != last) { sAct[l] = clast; sPos[clast] = (short)l; }
                 }
+                if (lane == cl / 6) amask &= ~(1u << (cl - 6 * (cl / 6)));
                 --q;
                 wave_sync();
             }
         }
     }
+    tstamp[5] = clock64();
 
     // ---------------- phase 6: outputs ----------------
     // f(axis,leg) = q_soln[3*leg+axis] for horizon step 0 (GetMPCSolution, :446-451); swing legs are 0.
-    if (lane < 12) yv[lane] = 0.0;
+    if (lane < 12) yl[lane] = 0.0;
     wave_sync();
-    for (int e = lane; e < ns; e += 64) { const int ls = sLs[e / 3]; if (ls < 4) yv[3 * ls + e % 3] = xv[e]; }
+    if (own) { const int ls = sLs[kme]; if (ls < 4) { yl[3 * ls] = x0; yl[3 * ls + 1] = x1; yl[3 * ls + 2] = x2; } }
     wave_sync();
     if (lane < 12) {
         const int leg = lane / 3, j = lane - 3 * leg;
-        const float fx = (float)yv[3 * leg], fy = (float)yv[3 * leg + 1], fz = (float)yv[3 * leg + 2];
-        g_force[(size_t)lane * n + rid] = (float)yv[lane];
-        if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yv[lane];
+        const float fx = (float)yl[3 * leg], fy = (float)yl[3 * leg + 1], fz = (float)yl[3 * leg + 2];
+        g_force[(size_t)lane * n + rid] = (float)yl[lane];
+        if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yl[lane];
         if (g_tau) {
             // f_ff = -R^T f  (R^T = quaternionToRotationMatrix(quat)), tau = J^T f_ff
             float fff[3];
@@ -551,6 +766,27 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
     }
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+    if (lane == 0 && dbgT) { tstamp[6] = clock64(); for (int i = 0; i < 7; ++i) dbgT[(size_t)rid * 16 + i] = tstamp[i]; dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
+}
+
+template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,
+                                          int *, float *, float *, float *, int, long long *);
+template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,
+                                          int *, float *, float *, float *, int, long long *);
+
+// Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
+__global__ void qr_selftest_kernel(double *out)
+{
+    const int lane = threadIdx.x & 63;
+    const double v = (double)((lane * 37 + 11) % 64) - 20.5;          // a permutation of -20.5 .. 42.5
+    const double mn = wave_min_d(v);
+    const double sm = wave_sum_d((double)(lane + 1));
+    const int fl = first_lane(v == mn);
+    const double rd = readlane_d(v, 17);
+    out[lane] = mn;
+    out[64 + lane] = sm;
+    out[128 + lane] = (double)fl;
+    out[192 + lane] = rd;
 }
 
 }  // namespace qrgpu

@@ -503,7 +503,10 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     int nc = 0, nt = 2;
     int cleg[4], tleg[4];
 #pragma unroll
-    for (int l = 0; l < 4; ++l) { if (cm[63 + l] != 0.0) cleg[nc++] = l; else tleg[nt++ - 2] = l; }
+    for (int l = 0; l < 4; ++l) {       // readfirstlane: LDS loads count as divergent, the contact pattern is wave-uniform
+        const int in_contact = __builtin_amdgcn_readfirstlane(cm[63 + l] != 0.0 ? 1 : 0);
+        if (in_contact) cleg[nc++] = l; else tleg[nt++ - 2] = l;
+    }
     if (lane == 0) {
         const m3 RotT = transpose(Rwb);
         // --- orientation task (qr_task_body_orientation.cpp:43-81)

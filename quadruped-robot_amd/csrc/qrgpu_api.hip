@@ -13,9 +13,15 @@
 #include "qr_device_types.h"
 
 namespace qrgpu {
+template <int MAXB>
 __global__ void qr_mpc_kernel(MpcLaunch P, const int *type_id, const float *g_state, const float *g_traj, const float *g_gait,
                               const float *g_q, float *g_force, float *g_tau, int *g_status, float *dbgH, float *dbgG,
-                              float *g_force_wbc, int force_stride);
+                              float *g_force_wbc, int force_stride, long long *dbgT);
+extern template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
+                                                 float *, int *, float *, float *, float *, int, long long *);
+extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
+                                                 float *, int *, float *, float *, float *, int, long long *);
+__global__ void qr_selftest_kernel(double *out);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or);
 }
@@ -37,6 +43,7 @@ struct qrgpu_ctx {
     float *d_out1 = nullptr;      // staging: single-robot outputs
     int *d_st1 = nullptr;
     float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
+    void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
     int lds_per_cu = 0, num_cu = 0;
     std::string name;
     std::string err;
@@ -281,15 +288,22 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     MpcLaunch P = c->mpc;
     P.n = n;
     P.lds_bytes = mpc_lds_bytes(c, P.horizon);
-    static int configured_lds = 0;
-    if (configured_lds < P.lds_bytes) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
-        configured_lds = P.lds_bytes;
+    // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
+    const bool small = 4 * P.horizon <= 44;
+    static int configured_lds[2] = {0, 0};
+    if (configured_lds[small ? 0 : 1] < P.lds_bytes) {
+        if (small) HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
+        else HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
+        configured_lds[small ? 0 : 1] = P.lds_bytes;
     }
     {
         TimerScope ts(c, 0);
-        hipLaunchKernelGGL(qr_mpc_kernel, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
-                           d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51);
+        if (small)
+            hipLaunchKernelGGL(qr_mpc_kernel<4>, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
+                               d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
+        else
+            hipLaunchKernelGGL(qr_mpc_kernel<9>, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
+                               d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -415,6 +429,27 @@ int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const fl
     if (qdes_out) memcpy(qdes_out, out + 12, 48);
     if (qddes_out) memcpy(qddes_out, out + 24, 48);
     if (status) *status = st;
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to disable */, int n)
+{   // undocumented diagnostic: phase cycle stamps of the last MPC launch (enable by calling once with NULL first)
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    if (!c->d_dbg_cycles) { HIPCHK(c, hipMalloc(&c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)c->max_batch)); return QRGPU_OK; }
+    if (host_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(host_out, c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)n, hipMemcpyDeviceToHost)); }
+    return QRGPU_OK;
+}
+
+int qrgpu_selftest(qrgpu_ctx *c, double *host_out256)
+{   // cross-lane helper self-test (tests/test_gpu_mpc.py::test_wave_helpers)
+    if (!c || !host_out256) return QRGPU_ERR_BAD_ARG;
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 256 * sizeof(double)));
+    hipLaunchKernelGGL(qr_selftest_kernel, dim3(1), dim3(64), 0, c->stream, d);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out256, d, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(d);
     return QRGPU_OK;
 }
 

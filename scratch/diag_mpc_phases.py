@@ -1,0 +1,33 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+ctx = pkg.Context(0, 4096, 16)
+G.setup_a1(ctx, pkg, 10)
+lib = ctx._lib
+lib.qrgpu_debug_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.qrgpu_debug_cycles(ctx._h, None, 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+b = pkg.make_batch(n, 10, "a1", seed=0xA3)
+out = G.run_mpc(ctx, pkg, b)
+out = G.run_mpc(ctx, pkg, b)
+buf = np.zeros((n, 16), np.int64)
+lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, n)
+d = np.diff(buf[:, :7], axis=1).astype(np.float64)
+names = ["load+srbd", "H/g build", "sweep inv", "x0", "GI", "out"]
+it = out["status"] >> 8
+print("clock64 ticks per phase (mean / p50 / max):")
+for k, nm in enumerate(names):
+    print("  %-10s mean %9.0f  p50 %9.0f  max %9.0f" % (nm, d[:, k].mean(), np.median(d[:, k]), d[:, k].max()))
+tot = (buf[:, 6] - buf[:, 0])
+print("total per WG mean %.0f max %.0f ; GI ticks per iteration mean %.0f ; iters mean %.1f max %d; ns mean %.0f" % (tot.mean(), tot.max(), (d[:, 4] / np.maximum(it, 1)).mean(), it.mean(), it.max(), buf[:, 7].mean()))
+print("span first start -> last end: %.0f ticks" % (buf[:, 6].max() - buf[:, 0].min()))
+
+sub = buf[:, 8:14].astype(np.float64)
+nm2 = ["scan+select", "w+delta", "d,r", "zc,t1,t2", "y,z,x", "S^-1 add"]
+for k, nm in enumerate(nm2):
+    print("  GI %-12s per-iter mean %8.0f   share %.2f" % (nm, (sub[:, k] / np.maximum(it, 1)).mean(), sub[:, k].sum() / d[:, 4].sum()))
+print("final q mean %.1f max %d" % (buf[:, 14].mean(), buf[:, 14].max()))

@@ -125,3 +125,17 @@ def test_mpc_single_robot_interface(gpu_ctx, pkg, oracle):
         got = np.array([mpc.GetMPCSolution(k) for k in range(12)])
         assert (mpc.status & 0xff) == 0
         assert np.abs(got - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max())
+
+
+def test_wave_helpers(gpu_ctx):
+    """DPP min / sum all-reduce, first_lane and readlane helpers used by the active-set loop."""
+    import ctypes as C
+    out = np.zeros(256)
+    lib = gpu_ctx._lib
+    lib.qrgpu_selftest.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.qrgpu_selftest(gpu_ctx._h, out.ctypes.data) == 0
+    v = ((np.arange(64) * 37 + 11) % 64) - 20.5
+    assert np.all(out[:64] == v.min())
+    assert np.all(out[64:128] == 64 * 65 / 2)
+    assert np.all(out[128:192] == np.argmin(v))
+    assert np.all(out[192:256] == v[17])
