@@ -120,7 +120,7 @@ def main():
     d_tau = torch.zeros((12, n), dtype=torch.float32, device=dev)
     d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
     d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
-    d_tau_all = torch.zeros((world, 12, n), dtype=torch.float32, device=dev) if world > 1 else None
+    d_tau_all = torch.zeros((world * 12, n), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major [world][12][n]
 
     def step():
         if args.mode == "tick":

@@ -198,7 +198,7 @@ def wbc_run(model, state37, cmd67, prev_ori_vel=None, dtype=_f):
 def pinv(A, thr):
     A = np.ascontiguousarray(A, _f)
     out = np.zeros((A.shape[1], A.shape[0]), _f)
-    lib().qro_pinv_f32(A.shape[0], A.shape[1], _fp(A), float(thr), _fp(out))
+    lib().qro_pinv_f32(A.shape[0], A.shape[1], _fp(A), C.c_double(float(thr)), _fp(out))
     return out
 
 

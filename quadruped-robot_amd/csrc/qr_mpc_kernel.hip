@@ -248,8 +248,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
     double *Mb = smem + (int)(mpc_lds_fixed_bytes(h) / 8);   // block-packed M; the sweep panels live here first
 
-    long long tstamp[7];
-    tstamp[0] = clock64();
+#define QR_TS(i) do { if (dbgT && tid == 0) dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
+    QR_TS(0);
     // ---------------- phase 0: inputs ----------------
     if (tid < 28) sSt[tid] = g_state[(size_t)tid * n + rid];
     for (int i = tid; i < NV; i += QR_MPC_THREADS) sTraj[i] = g_traj[(size_t)i * n + rid];
@@ -347,7 +347,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         sV[13 * r + 12] = ax[12] - 0.f;
     }
     __syncthreads();
-    tstamp[1] = clock64();
+    QR_TS(1);
     // LDS loads count as divergent for the compiler; make the sizes scalar so that loops and branches on them are SALU
     const int nls = __builtin_amdgcn_readfirstlane(sMisc[0]);
     const int ns = 3 * nls;
@@ -372,7 +372,6 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const float two_alpha = 2.f * C.alpha;
 
     // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
-    Blk A[MAXB];
     int ba[MAXB], bb[MAXB];
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
@@ -384,8 +383,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             while (tri(a) > pid) --a;
             const int b = pid - tri(a);                 // a >= b
             ba[sl] = a; bb[sl] = b;
-            A[sl] = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
-                       dbgH ? dbgH + (size_t)rid * NV * NV : nullptr, NV);
+            const Blk Hb = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
+                                      dbgH ? dbgH + (size_t)rid * NV * NV : nullptr, NV);
+            // parked in its final M slot: keeps the 18 VGPRs per block out of the build's register budget
+            double *dst = Mb + pid * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dst[i] = Hb.m[i];
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the blocks' temporaries from overlapping (register pressure)
     }
@@ -412,12 +415,22 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         if (dbgG) dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
     for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
-    tstamp[2] = clock64();
+    QR_TS(2);
 
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
     // Pivot leg-step k:  P = A_kk,  C_i = A_ik (i > k) or A_ki' (i < k);
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
     // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
+    Blk A[MAXB];
+#pragma unroll
+    for (int sl = 0; sl < MAXB; ++sl) {
+        if (ba[sl] >= 0) {
+            const double *src = Mb + (tid + QR_MPC_THREADS * sl) * 9;        // own slot: no barrier needed
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A[sl].m[i] = src[i];
+        }
+    }
+    __syncthreads();               // every block is in registers: the M region can now carry the pivot panels
     {
         double *panel0 = Mb, *panel1 = Mb + NL * 9;
         for (int k = 0; k < nls; ++k) {
@@ -489,7 +502,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
         __syncthreads();
     }
-    tstamp[3] = clock64();
+    QR_TS(3);
     if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below
 
     // ---------------- phase 4: x = -M g  (lane k owns leg-step k) ----------------
@@ -505,7 +518,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             x2 -= B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
         }
     }
-    tstamp[4] = clock64();
+    QR_TS(4);
 
     // ---------------- phase 5: dual active set (wave 0) ----------------
     const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
@@ -725,7 +738,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             }
         }
     }
-    tstamp[5] = clock64();
+    QR_TS(5);
 
     // ---------------- phase 6: outputs ----------------
     // f(axis,leg) = q_soln[3*leg+axis] for horizon step 0 (GetMPCSolution, :446-451); swing legs are 0.
@@ -766,7 +779,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
     }
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
-    if (lane == 0 && dbgT) { tstamp[6] = clock64(); for (int i = 0; i < 7; ++i) dbgT[(size_t)rid * 16 + i] = tstamp[i]; dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
+    QR_TS(6);
+    if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
 }
 
 template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,

@@ -1,0 +1,91 @@
+"""CPU: the oracle's rigid-body model and WBC tick (K8-K14): analytic invariants, float64 cross-checks,
+golden fixtures (tests/golden/wbc_golden.npz)."""
+import numpy as np
+import pytest
+
+import golden_io
+
+
+def test_pinv_and_lu_match_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for r, c in ((3, 18), (6, 18), (12, 18), (12, 12), (3, 3), (18, 6)):
+        A = rng.normal(size=(r, c)).astype(np.float32)
+        P = oracle.pinv(A, 1e-3)
+        assert np.abs(P - np.linalg.pinv(A.astype(np.float64))).max() < 2e-5
+    # singular values at/below the threshold are dropped (strict '>'), 1x1 compares the entry itself
+    U, _ = np.linalg.qr(rng.normal(size=(6, 6))); V, _ = np.linalg.qr(rng.normal(size=(18, 18)))
+    s = np.array([2.0, 1.0, 0.5, 0.1, 5e-4, 1e-5])
+    A = (U * s) @ V[:6]
+    P = oracle.pinv(A.astype(np.float32), 1e-3)
+    ref = (V[:6].T * np.where(s > 1e-3, 1 / s, 0.0)) @ U.T
+    assert np.abs(P - ref).max() < 1e-3
+    assert oracle.pinv(np.array([[-5.0]], np.float32), 1e-4)[0, 0] == 0.0          # quirk 7
+    assert abs(oracle.pinv(np.array([[4.0]], np.float32), 1e-4)[0, 0] - 0.25) < 1e-7
+    M = rng.normal(size=(18, 18)); M = (M @ M.T + 18 * np.eye(18)).astype(np.float32)
+    assert np.abs(oracle.lu_inverse(M) - np.linalg.inv(M.astype(np.float64))).max() < 1e-6
+
+
+def test_rigid_body_invariants(oracle, pkg):
+    md = pkg.model_desc("a1")
+    b = pkg.make_batch(6, 10, "a1", seed=3)
+    for i in range(6):
+        s = b["fb_state"][i].astype(np.float64)
+        s[:4] /= np.linalg.norm(s[:4])
+        r = oracle.fb_compute(md, s, np.float64)
+        H = r["H"]
+        assert np.abs(H - H.T).max() < 1e-12 and np.linalg.eigvalsh(H).min() > 0
+        m_tot = 6 + 4 * (np.float32(0.696) + np.float32(1.013) + np.float32(0.166)) + 12 * np.float32(1e-8)
+        assert np.allclose(np.diag(H)[3:6], m_tot, rtol=1e-7)              # total mass incl. rotors, body frame
+        assert abs(np.linalg.norm(r["G"][3:6]) - m_tot * 9.81) < 1e-4
+        qd = np.r_[s[7:13], s[25:37]]
+        for leg in range(4):                                               # v_foot = Jc * qdot
+            assert np.abs(r["Jc"][leg] @ qd - r["vGC"][leg]).max() < 1e-9
+            for j in range(12):                                            # Jc = d p_foot / d q
+                s2 = s.copy(); s2[13 + j] += 1e-6
+                num = (oracle.fb_compute(md, s2, np.float64)["pGC"][leg] - r["pGC"][leg]) / 1e-6
+                assert np.abs(num - r["Jc"][leg][:, 6 + j]).max() < 1e-5
+        # zero velocity => no Coriolis
+        s0 = s.copy(); s0[7:13] = 0; s0[25:37] = 0
+        assert np.abs(oracle.fb_compute(md, s0, np.float64)["C"]).max() < 1e-14
+        # kinetic energy from H equals the sum over the analytic leg/foot picture only loosely; check positivity
+        assert qd @ H @ qd > 0
+
+
+def test_wbc_satisfies_floating_base_dynamics(oracle, pkg):
+    """The relaxation QP's equality rows: (A qdd + C + G - Jc' f)[0:6] = 0 for the returned qdd, f."""
+    md = pkg.model_desc("a1")
+    b = pkg.make_batch(12, 10, "a1", seed=8)
+    for i in range(12):
+        s = b["fb_state"][i].astype(np.float64); c = b["wbc_cmd"][i].astype(np.float64)
+        w = oracle.wbc_run(md, s, c, dtype=np.float64)
+        assert w["rc"] == 0
+        fb = oracle.fb_compute(md, s, np.float64)
+        stance = [l for l in range(4) if c[63 + l] != 0]
+        gen = fb["H"] @ w["qddot"] + fb["C"] + fb["G"]
+        for k, leg in enumerate(stance):
+            gen -= fb["Jc"][leg].T @ w["fr"][3 * k:3 * k + 3]
+        assert np.abs(gen[:6]).max() < 1e-8
+        assert np.abs(gen[6:] - w["tau"]).max() < 1e-9
+        for k, leg in enumerate(stance):                                   # friction pyramid, mu = 0.4
+            f = w["fr"][3 * k:3 * k + 3]
+            assert f[2] >= -1e-9 and abs(f[0]) <= 0.4 * f[2] + 1e-8 and abs(f[1]) <= 0.4 * f[2] + 1e-8
+        # fp32 evaluation (what the reference does) stays within 1e-4 * max(1,|tau|) of the fp64 one
+        w32 = oracle.wbc_run(md, b["fb_state"][i], b["wbc_cmd"][i], dtype=np.float32)
+        assert np.all(np.abs(w32["tau"] - w["tau"]) <= 1e-4 * np.maximum(1, np.abs(w["tau"])))
+
+
+def test_golden_wbc(oracle):
+    rows = golden_io.load("wbc_golden.npz")
+    assert len(rows) == 16
+    active = 0
+    for r in rows:
+        w = oracle.wbc_run(r["model"], r["fb_state"].astype(np.float64), r["wbc_cmd"].astype(np.float64),
+                           r["prev"].astype(np.float64), dtype=np.float64)
+        assert w["rc"] == 0
+        assert np.abs(w["tau"] - r["tau64"]).max() <= 1e-9 and np.abs(w["qdes"] - r["qdes64"]).max() <= 1e-9
+        assert np.abs(w["fr"] - r["fr64"]).max() <= 1e-8
+        fb = oracle.fb_compute(r["model"], r["fb_state"].astype(np.float64), np.float64)
+        for k in ("H", "G", "C", "Jc", "Jcdqd", "pGC"):
+            assert np.abs(fb[k] - r[k]).max() <= 1e-10
+        active += int(r["n_active"][0]) > 0
+    assert active >= 2        # the fixtures exercise binding friction rows

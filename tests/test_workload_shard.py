@@ -1,0 +1,78 @@
+"""CPU: synthetic workload generator and the multi-rank sharding / all-gather path (gloo, world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def test_workload_is_deterministic_and_consistent(pkg, oracle):
+    a = pkg.make_batch(32, 10, "a1", seed=9); b = pkg.make_batch(32, 10, "a1", seed=9)
+    for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd"):
+        assert np.array_equal(a[k], b[k]) and a[k].dtype == np.float32
+    assert a["mpc_state"].shape == (32, 28) and a["traj"].shape == (32, 120) and a["gait"].shape == (32, 40)
+    assert a["fb_state"].shape == (32, 37) and a["wbc_cmd"].shape == (32, 67)
+    assert np.allclose(np.linalg.norm(a["fb_state"][:, :4], axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(a["gait"][:, :4], a["wbc_cmd"][:, 63:67])                    # row 0 = current contact
+    assert set(np.unique(a["gait"])) <= {0.0, 1.0}
+    # quaternion and foot vectors agree with the reference's conventions (rpyToQuat, FootPositionsInBaseFrame)
+    for i in range(4):
+        q = oracle.rpy_to_quat(a["mpc_state"][i, 25:28])
+        assert np.abs(q - a["mpc_state"][i, 6:10]).max() < 1e-6 or np.abs(q + a["mpc_state"][i, 6:10]).max() < 1e-6
+        r = pkg.ROBOTS["a1"]
+        fp = oracle.foot_positions(pkg.model_desc("a1")[:3], np.array(r["hip_offset"], np.float32).reshape(12), a["fb_state"][i, 13:25])
+        w, x, y, z = a["mpc_state"][i, 6:10].astype(np.float64)
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        rw = (R @ (fp.reshape(4, 3) - np.array(r["com_offset"])).T).T
+        assert np.abs(rw.reshape(12) - a["mpc_state"][i, 13:25]).max() < 1e-5
+    assert np.array_equal(pkg.to_soa(a["traj"]), a["traj"].T) and pkg.to_soa(a["traj"]).flags["C_CONTIGUOUS"]
+
+
+def test_shard_ranges(pkg):
+    sh = pkg.shard
+    for n, w in ((8192, 8), (1000, 3), (5, 8), (1024, 1)):
+        rs = [sh.shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        sizes = sh.shard_sizes(n, w)
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+    t = sh.interleave_types(16, 2)
+    assert t.tolist() == [0, 1] * 8
+
+
+def _gloo_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import load_pkg
+    pkg = load_pkg()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = pkg.shard.shard_range(n_total, rank, world)
+    # stand-in for the per-rank kernel output: torque[j, i] = 100*j + global robot index
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    tau_local = torch.arange(12, dtype=torch.float32)[:, None] * 100 + idx[None, :]
+    full = pkg.shard.allgather_torques(tau_local, n_total)
+    expect = torch.arange(12, dtype=torch.float32)[:, None] * 100 + torch.arange(n_total, dtype=torch.float32)[None, :]
+    ok = bool(torch.equal(full, expect))
+    t = torch.tensor([1.0 + rank]); dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the bench's max-over-ranks timing reduction
+    q.put((rank, ok, float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [64, 37])
+def test_allgather_torques_world2_gloo(n_total):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and all(t == 2.0 for _, _, t in res)
