@@ -39,9 +39,14 @@ namespace qrgpu {
 
 __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
 {
+#pragma clang fp contract(off)
     return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, a0 * b0));
 }
-__device__ __forceinline__ float det2(float a, float b, float c, float d) { return __builtin_fmaf(a, b, -(c * d)); }
+__device__ __forceinline__ float det2(float a, float b, float c, float d)
+{
+#pragma clang fp contract(off)
+    return __builtin_fmaf(a, b, -(c * d));
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -51,6 +56,15 @@ __device__ __forceinline__ void wave_sync()
 }
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 __device__ __forceinline__ int pidx(int i, int j) { return i >= j ? tri(i) + j : tri(j) + i; }
+
+// 1/x by v_rcp_f64 + two Newton steps (<= 1 ulp-ish; the active-set step lengths do not need IEEE division)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
 
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
@@ -123,6 +137,7 @@ __device__ __forceinline__ void load_block(const double *Mb, int k, int kc, Blk 
 __device__ __forceinline__ Blk hess_block(const float *sT, const float *sU, int la, int lb, int h, float dt, float dt2, float minv,
                                         const float *weights, float alpha, float *Hd, int NV)
 {
+#pragma clang fp contract(off)      // the fp32 chain must be exactly the written sequence (bit-identical to the oracle)
     Blk out;
     const int ia = la >> 2, pa = la & 3, ib = lb >> 2, pb = lb & 3;   // horizon step, leg
     float w2[12];
@@ -259,6 +274,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // ---------------- phase 1: SRBD terms (every thread keeps R in registers) ----------------
     float R[3][3];
     {
+#pragma clang fp contract(off)
         const float w = sSt[6], x = sSt[7], y = sSt[8], z = sSt[9];
         const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
         const float twx = tx * w, twy = ty * w, twz = tz * w;
@@ -270,6 +286,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     }
     const float dt = C.dt, dt2 = C.dt * C.dt, minv = 1.0f / C.mass;
     if (tid < 4) {
+#pragma clang fp contract(off)
         const int p = tid;
         float RI[3][3], Iw[3][3], cof[3][3], Iinv[3][3];
 #pragma unroll
@@ -324,6 +341,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     }
     // v = Aqp x0 - X_d, one horizon step per thread (wave 1 so it overlaps the above)
     if (tid >= 64 && tid < 64 + h) {
+#pragma clang fp contract(off)
         const int r = tid - 64;
         const float grav = -9.8f;
         const float kd = (float)(r + 1) * dt;
@@ -394,6 +412,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     }
     // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread
     for (int e = tid; e < ns; e += QR_MPC_THREADS) {
+#pragma clang fp contract(off)
         const int ls = sLs[e / 3], j = e % 3, ia = ls >> 2, p = ls & 3;
         const float t0 = sT[9 * p + j], t1 = sT[9 * p + 3 + j], t2 = sT[9 * p + 6 + j];
         const float u0 = (dt * sU[9 * p + j]) * w2[6], u1 = (dt * sU[9 * p + 3 + j]) * w2[7], u2 = (dt * sU[9 * p + 6 + j]) * w2[8];
@@ -457,7 +476,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
                 const double det = p00 * c00 + p01 * c01 + p02 * c02;
                 if (!(det > 0.0) || !(p00 > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
-                const double id = 1.0 / det;
+                const double id = fast_rcp(det);
                 Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
                 Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
                 Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
@@ -609,9 +628,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             const double zc = delta - dr;                    // z'c_p
             // dual step length: min u_j / r_j over r_j > 0
             double tt = INF;
-            if (lane < q && r0 > 0.0) tt = u0 / r0;
+            if (lane < q && r0 > 0.0) tt = u0 * fast_rcp(r0);
             double tt1 = INF;
-            if (lane + 64 < q && r1 > 0.0) tt1 = u1 / r1;
+            if (q > 64 && lane + 64 < q && r1 > 0.0) tt1 = u1 * fast_rcp(r1);
             const double t1 = wave_min_d(fmin(tt, tt1));
             int lpos = -1;
             if (t1 < INF) {
@@ -620,7 +639,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             }
             const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
             const bool have_z = zc > 1e-13 * delta;
-            const double t2 = have_z ? -sp / zc : INF;
+            const double izc = fast_rcp(zc);
+            const double t2 = have_z ? -sp * izc : INF;
             const double t = t1 < t2 ? t1 : t2;
             if (!(t < INF)) { st |= QRGPU_ST_MPC_INFEAS_D; done = true; break; }
             QR_STAMP(3);
@@ -665,7 +685,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             if (have_z && t == t2) {
                 // full step: p joins the working set; bordered update of S^-1
                 if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
-                const double isg = 1.0 / zc;
+                const double isg = izc;
                 {
                     // row i of the lower triangle belongs to lane i: S^-1(i, j) += r_i r_j / sigma for j <= i
                     const int q0 = q < 64 ? q : 64;
@@ -704,7 +724,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 double s0 = 0.0, s1 = 0.0;                    // column l of S^-1
                 if (lane < q) s0 = Sinv[pidx(lane, l)];
                 if (lane + 64 < q) s1 = Sinv[pidx(lane + 64, l)];
-                const double isl = 1.0 / ((l < 64) ? readlane_d(s0, l) : readlane_d(s1, l - 64));
+                const double isl = fast_rcp((l < 64) ? readlane_d(s0, l) : readlane_d(s1, l - 64));
                 wave_sync();
                 {
                     const int i0 = lane, i1 = lane + 64;
