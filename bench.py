@@ -154,6 +154,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # PCIe-inclusive rate (never `value`): host buffers in, torques out, every step
+    pcie_value = None
+    if world == 1 and args.mode == "tick":
+        host_in = [torch.from_numpy(S(b[k])).pin_memory() for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd")]
+        dev_in = [d_state, d_traj, d_gait, d_fb, d_cmd]
+        host_tau = torch.empty((12, n), dtype=torch.float32).pin_memory()
+        ctx.enable_timing(False)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(20):
+            for hsrc, ddst in zip(host_in, dev_in):
+                ddst.copy_(hsrc, non_blocking=True)
+            step()
+            host_tau.copy_(d_tau, non_blocking=True)
+            torch.cuda.synchronize()
+        pcie_value = n * 20 / (time.perf_counter() - tp0)
+
     status = d_status.cpu().numpy()
     iters = (status >> 8).astype(np.float64)
     flags = status & 0xff
@@ -183,7 +200,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
                        "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques" % world,
-                       "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum())},
+                       "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
+                       "pcie_inclusive_ticks_per_s": pcie_value},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel_ms": dom_ms, "kernel_launches": mpc_cnt if dom_name == "qr_mpc_kernel" else wbc_cnt,

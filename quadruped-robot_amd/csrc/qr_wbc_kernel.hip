@@ -90,7 +90,13 @@ __device__ __forceinline__ m3 quat_to_rot_wb(const real *q)
 
 // Rigid-body spatial inertia [[Ibar, [h]x],[[h]x^T, m 1]] as (m, h, Ibar sym: xx yy zz xy xz yz).
 struct rbi { real m; v3 h; real I[6]; };
-__device__ __forceinline__ rbi rbi_load(const real *p) { rbi r; r.m = p[0]; r.h = mk(p[1], p[2], p[3]); for (int i = 0; i < 6; ++i) r.I[i] = p[4 + i]; return r; }
+__device__ __forceinline__ rbi rbi_load(const real *p)
+{
+    rbi r; r.m = p[0]; r.h = mk(p[1], p[2], p[3]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.I[i] = p[4 + i];
+    return r;
+}
 __device__ __forceinline__ v3 rbi_Iw(const rbi &a, v3 w)
 {
     return mk(a.I[0] * w.x + a.I[3] * w.y + a.I[4] * w.z, a.I[3] * w.x + a.I[1] * w.y + a.I[5] * w.z, a.I[4] * w.x + a.I[5] * w.y + a.I[2] * w.z);
@@ -98,6 +104,7 @@ __device__ __forceinline__ v3 rbi_Iw(const rbi &a, v3 w)
 __device__ __forceinline__ rbi rbi_add(const rbi &a, const rbi &b)
 {
     rbi r; r.m = a.m + b.m; r.h = a.h + b.h;
+#pragma unroll
     for (int i = 0; i < 6; ++i) r.I[i] = a.I[i] + b.I[i];
     return r;
 }
@@ -244,7 +251,8 @@ __device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real th
 
 #define QR_WBC_LDS_DOUBLES 4608
 
-__global__ __launch_bounds__(64)
+// 37 KB of LDS per robot allows 4 wavefronts per CU = 1 per SIMD, so each may take the whole 512-entry register file
+__global__ __launch_bounds__(64, 1)
 void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
@@ -295,6 +303,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     real *qx = qc0 + 32;           // 18 z
     real *qw = qx + 18;            // 18
     real *qz = qw + 18;            // 18
+    real *sRT = qz + 18;           // 9  Rot^T (body -> world), read with run-time indices by the task Jacobian loader
     __shared__ int sI[64];         // task kinds / active list
 
     // ---------------- load ----------------
@@ -394,12 +403,14 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         const rbi ICa_b = rbi_to_parent(ICa, Ea, r_a);
         real *LB = legB + 16 * leg;
         LB[0] = ICa_b.m; LB[1] = ICa_b.h.x; LB[2] = ICa_b.h.y; LB[3] = ICa_b.h.z;
+#pragma unroll
         for (int i = 0; i < 6; ++i) LB[4 + i] = ICa_b.I[i];
         // mass-matrix columns (massMatrix :774-806)
         const real kr = K.k_rot;
         const int ja = 6 + 3 * leg, jh = ja + 1, jk = ja + 2;
         auto base_col = [&](int j, sv6 f) {     // f expressed in the base frame
             const real fv[6] = {f.a.x, f.a.y, f.a.z, f.l.x, f.l.y, f.l.z};
+#pragma unroll
             for (int i = 0; i < 6; ++i) { A[i * 18 + j] = fv[i]; A[j * 18 + i] = fv[i]; }
         };
         {   // knee
@@ -465,7 +476,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         // H[0:6,0:6] = IC5 as a 6x6
         const real I6[3][3] = {{IC5.I[0], IC5.I[3], IC5.I[4]}, {IC5.I[3], IC5.I[1], IC5.I[5]}, {IC5.I[4], IC5.I[5], IC5.I[2]}};
         const real hx[3][3] = {{0, -IC5.h.z, IC5.h.y}, {IC5.h.z, 0, -IC5.h.x}, {-IC5.h.y, IC5.h.x, 0}};
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
                 A[i * 18 + j] = I6[i][j];
                 A[i * 18 + 3 + j] = hx[i][j];
@@ -501,12 +514,14 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     // ---------------- K11 tasks and contacts ----------------
     // task list: 0 = body orientation, 1 = body position, then swing feet in leg order; contacts: stance feet.
     int nc = 0, nt = 2;
-    int cleg[4], tleg[4];
+    unsigned cpack = 0, tpack = 0;      // leg ids of the contacts / swing-foot tasks, 4 bits each (no indexed local arrays -> no scratch)
 #pragma unroll
     for (int l = 0; l < 4; ++l) {       // readfirstlane: LDS loads count as divergent, the contact pattern is wave-uniform
         const int in_contact = __builtin_amdgcn_readfirstlane(cm[63 + l] != 0.0 ? 1 : 0);
-        if (in_contact) cleg[nc++] = l; else tleg[nt++ - 2] = l;
+        if (in_contact) { cpack |= (unsigned)l << (4 * nc); ++nc; } else { tpack |= (unsigned)l << (4 * (nt - 2)); ++nt; }
     }
+#define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
+#define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
     if (lane == 0) {
         const m3 RotT = transpose(Rwb);
         // --- orientation task (qr_task_body_orientation.cpp:43-81)
@@ -544,6 +559,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             const v3 pv = mk((real)g_prev[(size_t)0 * n + rid], (real)g_prev[(size_t)1 * n + rid], (real)g_prev[(size_t)2 * n + rid]);
             const v3 ve = mul(RotT, pv - mk(bv[0], bv[1], bv[2]));
             const real so[3] = {so3.x, so3.y, so3.z}, vev[3] = {ve.x, ve.y, ve.z};
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
                 tkE[i] = so[i];
                 tkV[i] = cm[12 + i];
@@ -556,6 +572,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         {
             const v3 vw = mul(RotT, mk(bv[3], bv[4], bv[5]));
             const real vwv[3] = {vw.x, vw.y, vw.z};
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const real pe = cm[i] - pos[i];
                 tkE[3 + i] = pe;
@@ -566,7 +583,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
         // --- swing-foot tasks (qr_task_link_position.cpp:45-68), no clamp
         for (int t = 2; t < nt; ++t) {
-            const int l = tleg[t - 2];
+            const int l = TLEG(t - 2);
             for (int i = 0; i < 3; ++i) {
                 const real pe = cm[15 + 3 * l + i] - pGC[3 * l + i];
                 tkE[3 * t + i] = pe;
@@ -576,18 +593,21 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
     }
     // stacked contact Jacobian
-    for (int e = lane; e < 54 * nc; e += 64) { const int k = e / 54; JC[e] = JcA[54 * cleg[k] + (e - 54 * k)]; }
+    for (int e = lane; e < 54 * nc; e += 64) { const int k = e / 54; JC[e] = JcA[54 * CLEG(k) + (e - 54 * k)]; }
     wsync();
     const int dimFr = 3 * nc;
-    const m3 RotT = transpose(Rwb);
+    // RotT[i][j] = Rwb[j][i]; static indices only (a register array indexed at run time would be demoted to scratch)
+#pragma unroll
+    for (int e = 0; e < 9; ++e) if (lane == e) sRT[e] = Rwb.m[e % 3][e / 3];
+    wsync();
     // task Jacobian loader: Jt <- task t
     auto load_Jt = [&](int t) {
         for (int e = lane; e < 54; e += 64) {
             const int i = e / 18, j = e - 18 * i;
             real v = 0.0;
-            if (t == 0) { if (j < 3) v = RotT.m[i][j]; }
-            else if (t == 1) { if (j >= 3 && j < 6) v = RotT.m[i][j - 3]; }
-            else { v = (j < 6) ? 0.0 : JcA[54 * tleg[t - 2] + e]; }        // virtualDepend = false: base columns zeroed
+            if (t == 0) { if (j < 3) v = sRT[3 * i + j]; }
+            else if (t == 1) { if (j >= 3 && j < 6) v = sRT[3 * i + j - 3]; }
+            else { v = (j < 6) ? 0.0 : JcA[54 * TLEG(t - 2) + e]; }        // virtualDepend = false: base columns zeroed
             Jt[e] = v;
         }
         wsync();
@@ -658,7 +678,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         gemm(lane, lam, dimFr, JC, 18, false, T1, dimFr, false, dimFr, dimFr, 18);       // lambda = Jc temp
         psd_pinv(lane, lam, dimFr, thrW, lamI, scr);
         gemm(lane, JB, dimFr, T1, dimFr, false, lamI, dimFr, false, 18, dimFr, dimFr);   // JcBar
-        if (lane < 18) { real acc = 0.0; for (int k = 0; k < dimFr; ++k) acc -= JB[lane * dimFr + k] * Jcd[3 * cleg[k / 3] + k % 3]; qdd[lane] = acc; }
+        if (lane < 18) { real acc = 0.0; for (int k = 0; k < dimFr; ++k) acc -= JB[lane * dimFr + k] * Jcd[3 * CLEG(k / 3) + k % 3]; qdd[lane] = acc; }
         gemm(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
         for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
         wsync();
@@ -675,7 +695,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         psd_pinv(lane, lam, 3, thrW, lamI, scr);
         gemm(lane, JtB, 3, T1, 3, false, lamI, 3, false, 18, 3, 3);                      // JtBar
         if (lane < 3) {
-            real acc = tkX[3 * t + lane] - ((t >= 2) ? Jcd[3 * tleg[t - 2] + lane] : 0.0);
+            real acc = tkX[3 * t + lane] - ((t >= 2) ? Jcd[3 * TLEG(t - 2) + lane] : 0.0);
             for (int k = 0; k < 18; ++k) acc -= Jt[lane * 18 + k] * qdd[k];
             tv[lane] = acc;
         }
@@ -701,7 +721,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     if (lane < 18) {
         real acc = Cv[lane] + Gv[lane];
         for (int k = 0; k < 18; ++k) acc += A[lane * 18 + k] * qdd[k];
-        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * cleg[k / 3] + k % 3];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * CLEG(k / 3) + k % 3];
         tv[lane] = acc;
     }
     // constraint normals Nq[c][0:nz], offsets qc0[c]
@@ -729,7 +749,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         else {
             const int u = c - 6, k = u / 6, tt = u - 6 * k;
             real acc = 0.0;
-            for (int ax = 0; ax < 3; ++ax) acc += Nq[c * 18 + 6 + 3 * k + ax] * cm[51 + 3 * cleg[k] + ax];     // Uf Fr_des
+            for (int ax = 0; ax < 3; ++ax) acc += Nq[c * 18 + 6 + 3 * k + ax] * cm[51 + 3 * CLEG(k) + ax];     // Uf Fr_des
             v = acc - ((tt == 5) ? -(real)K.max_fz : 0.0);                                                    // - ineqVec
         }
         qc0[c] = v;

@@ -1,0 +1,51 @@
+// Drives the header-only adapters exactly the way MPCStanceLegController::SolveDenseMPC and
+// qrWbcLocomotionController::Run do, on inputs read from stdin; prints forces and torques.
+// TEST INFRASTRUCTURE (tests/test_adapters.py).
+#include <cstdio>
+#include "ref_stubs.hpp"
+#include "qrgpu_adapters.hpp"
+
+int main()
+{
+    int h;
+    float cfg[20], s[28], traj[12 * 16], gait[4 * 16], fb[37], cmd[67];
+    if (scanf("%d", &h) != 1) return 2;
+    for (float &x : cfg) if (scanf("%f", &x) != 1) return 2;
+    for (float &x : s) if (scanf("%f", &x) != 1) return 2;
+    for (int i = 0; i < 12 * h; ++i) if (scanf("%f", &traj[i]) != 1) return 2;
+    for (int i = 0; i < 4 * h; ++i) if (scanf("%f", &gait[i]) != 1) return 2;
+    for (float &x : fb) if (scanf("%f", &x) != 1) return 2;
+    for (float &x : cmd) if (scanf("%f", &x) != 1) return 2;
+
+    printf("before %g\n", Quadruped::GetMPCSolution(0));
+    Quadruped::SetupProblem(cfg[0], h, cfg[1], cfg[2], cfg[3], cfg + 4, cfg + 7, cfg[19]);       // Reset(), :90
+    Vec3<float> p{{s[0], s[1], s[2]}}, v{{s[3], s[4], s[5]}}, w{{s[10], s[11], s[12]}}, rpy{{s[25], s[26], s[27]}};
+    Quat<float> q{{s[6], s[7], s[8], s[9]}};
+    Mat34f r;
+    for (int i = 0; i < 12; ++i) r.m[i] = s[13 + i];
+    Quadruped::SolveMPCKernel(p, v, q, w, r, rpy, traj, gait);                                      // SolveDenseMPC, :399
+    printf("force");
+    for (int leg = 0; leg < 4; ++leg) for (int ax = 0; ax < 3; ++ax) printf(" %.9g", Quadruped::GetMPCSolution(leg * 3 + ax));   // :404
+    printf("\n");
+
+    if (qrgpu_adapters::WbcSetup(0.08505f, 0.2f, 0.2f) != 0) return 3;
+    qrRobotStub robot;
+    for (int i = 0; i < 4; ++i) robot.ori[i] = fb[i];
+    for (int i = 0; i < 3; ++i) { robot.pos[i] = fb[4 + i]; robot.rpyrate[i] = fb[7 + i]; robot.vb[i] = fb[10 + i]; }
+    for (int i = 0; i < 12; ++i) { robot.q[i] = fb[13 + i]; robot.dq[i] = fb[25 + i]; }
+    qrWbcCtrlData d;
+    for (int i = 0; i < 3; ++i) { d.pBody_des[i] = cmd[i]; d.vBody_des[i] = cmd[3 + i]; d.aBody_des[i] = cmd[6 + i]; d.pBody_RPY_des[i] = cmd[9 + i]; d.vBody_Ori_des[i] = cmd[12 + i]; }
+    for (int l = 0; l < 4; ++l) {
+        for (int i = 0; i < 3; ++i) {
+            d.pFoot_des[l][i] = cmd[15 + 3 * l + i]; d.vFoot_des[l][i] = cmd[27 + 3 * l + i]; d.aFoot_des[l][i] = cmd[39 + 3 * l + i];
+            d.Fr_des[l][i] = (float)Quadruped::GetMPCSolution(3 * l + i);                            // wbcData.Fr_des[leg] = f.col(leg), :408
+        }
+        d.contact_state.v[l] = cmd[63 + l] != 0.f;
+    }
+    Vec12<float> tau, qd, qdd;
+    int st = qrgpu_adapters::WbcRun(&robot, &d, tau, qd, qdd);
+    printf("status %d\ntau", st);
+    for (int i = 0; i < 12; ++i) printf(" %.9g", tau[i]);
+    printf("\n");
+    return 0;
+}
