@@ -16,6 +16,18 @@ namespace qrgpu {
 #define QRGPU_ST_WBC_MAXITER_D  0x10
 #define QRGPU_ST_WBC_INFEAS_D   0x20
 
+// XCD-aware robot index.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8
+// share an XCD) and each XCD has its own L2.  The SoA inputs put 32 consecutive robots in one 128-B line, so with
+// rid = blockIdx every line was fetched (and partially written) by all 8 L2s: 8-10x the algorithmic HBM bytes
+// (profiles/r01_rocprofv3_summary.md).  Mapping XCD x to the contiguous robot range [x*chunk, (x+1)*chunk) keeps
+// a line inside one L2.  Speed only: any placement gives the same results.  Launch with grid = 8*ceil(n/8).
+__device__ static inline int xcd_robot_index(int block, int n)
+{
+    const int chunk = (n + 7) >> 3;
+    const int rid = (block & 7) * chunk + (block >> 3);
+    return ((block >> 3) < chunk && rid < n) ? rid : -1;
+}
+
 // SetupProblem arguments (QI/controllers/mpc/qr_mpc_interface.h:157) + leg geometry for J^T f.
 struct MpcType {
     float dt, mu, fmax, mass;

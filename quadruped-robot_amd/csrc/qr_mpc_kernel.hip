@@ -234,11 +234,11 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                    float *__restrict__ dbgH, float *__restrict__ dbgG, float *__restrict__ g_force_wbc, int force_stride,
                    long long *__restrict__ dbgT)
 {
-    const int rid = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n = P.n;
-    if (rid >= n) return;
+    const int rid = xcd_robot_index(blockIdx.x, n);
+    if (rid < 0) return;
     const MpcType &C = P.type[type_id ? type_id[rid] : 0];
     const int h = P.horizon;
     const int NV = 12 * h, NL = 4 * h;

@@ -258,9 +258,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
                    float *__restrict__ g_dbg, int merge_tau, int status_or)
 {
-    const int rid = blockIdx.x;
+    const int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x;
-    if (rid >= n) return;
+    if (rid < 0) return;
     const WbcConst &K = types[type_id ? type_id[rid] : 0];
 
     __shared__ real sm[QR_WBC_LDS_DOUBLES];

@@ -299,10 +299,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     {
         TimerScope ts(c, 0);
         if (small)
-            hipLaunchKernelGGL(qr_mpc_kernel<4>, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
+            hipLaunchKernelGGL(qr_mpc_kernel<4>, dim3(8 * ((n + 7) / 8)), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
                                d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
         else
-            hipLaunchKernelGGL(qr_mpc_kernel<9>, dim3(n), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
+            hipLaunchKernelGGL(qr_mpc_kernel<9>, dim3(8 * ((n + 7) / 8)), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
                                d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
     }
     HIPCHK(c, hipGetLastError());
@@ -320,7 +320,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     if (rc) return rc;
     {
         TimerScope ts(c, 1);
-        hipLaunchKernelGGL(qr_wbc_kernel, dim3(n), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
+        hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or);
     }
     HIPCHK(c, hipGetLastError());
