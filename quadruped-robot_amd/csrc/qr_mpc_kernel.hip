@@ -549,6 +549,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #define QR_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
     int q = 0, iter = 0;
     unsigned amask = 0;                               // active rows of my leg-step (6 bits)
+    unsigned xmask = 0;                               // rows found numerically dependent on the working set (skipped until the set changes)
     double u0 = 0.0, u1 = 0.0;                        // multipliers of working-set positions lane, lane+64
     const int maxit = 40 * nls + 100;
     bool done = (nls == 0);
@@ -559,7 +560,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         if (own) {
             const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
 #pragma unroll
-            for (int t = 0; t < 6; ++t) if (!((amask >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
+            for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
         }
         const double smin = wave_min_d(bs);
         if (!(smin < -tol)) break;
@@ -642,7 +643,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             const double izc = fast_rcp(zc);
             const double t2 = have_z ? -sp * izc : INF;
             const double t = t1 < t2 ? t1 : t2;
-            if (!(t < INF)) { st |= QRGPU_ST_MPC_INFEAS_D; done = true; break; }
+            if (!(t < INF)) {
+                // The row is (numerically) in the span of the working set and no multiplier blocks: u = 0 is always
+                // feasible, so this is a degenerate corner (e.g. f = 0 with five rows on three unknowns), its violation
+                // is rounding.  Leave it out until the working set changes (what QuadProg++ does, QuadProg++.cc "iaexcl").
+                if (lane == kp) xmask |= 1u << tp;
+                break;
+            }
             QR_STAMP(3);
             if (have_z) {
                 // y_k = sum of active rows of my leg-step times r;  z = w - M y;  x += t z
@@ -713,6 +720,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 if (lane == 0) { Sinv[tri(q) + q] = isg; sAct[q] = p; sPos[p] = (short)q; }
                 if (lane == (q & 63)) { if (q < 64) u0 = up; else u1 = up; }
                 if (lane == kp) amask |= 1u << tp;
+                xmask = 0;
                 ++q;
                 wave_sync();
                 QR_STAMP(5);
@@ -753,6 +761,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     if (l != last) { sAct[l] = clast; sPos[clast] = (short)l; }
                 }
                 if (lane == cl / 6) amask &= ~(1u << (cl - 6 * (cl / 6)));
+                xmask = 0;
                 --q;
                 wave_sync();
             }

@@ -143,3 +143,31 @@ def test_full_tick(gpu_ctx, pkg, oracle):
     assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
     assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
     assert np.array_equal(out["prev"], prev)
+
+
+def test_full_tick_h16_mixed_a1_lite3(gpu_ctx, pkg, oracle):
+    """Config 5 of BASELINE.json in small: horizon 16, A1 and Lite3 interleaved (type_id per robot), full tick."""
+    h, n = 16, 64
+    gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    gpu_ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h); gpu_ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
+    ba = pkg.make_batch(n // 2, h, "a1", seed=501); bl = pkg.make_batch(n // 2, h, "lite3", seed=502)
+    b = dict(ba)
+    for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+        b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+    b["n"] = n
+    tid = pkg.shard.interleave_types(n, 2)
+    out = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
+    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    for i in range(n):
+        robot = "a1" if tid[i] == 0 else "lite3"
+        u, st, rc = oracle.mpc_solve(pkg.mpc_cfg(robot), h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        assert rc == 0
+        assert np.abs(out["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max())
+        cmd = b["wbc_cmd"][i].copy(); cmd[51:63] = u[:12].astype(np.float32)
+        w = oracle.wbc_run(pkg.model_desc(robot), b["fb_state"][i].astype(np.float64), cmd.astype(np.float64), dtype=np.float64)
+        tau = oracle.mpc_force_to_torque(pkg.model_desc(robot)[:3], b["fb_state"][i, :4], b["fb_state"][i, 13:25], u[:12]).astype(np.float64)
+        for l in range(4):
+            if cmd[63 + l]:
+                tau[3 * l:3 * l + 3] = w["tau"][3 * l:3 * l + 3]
+        assert np.all(np.abs(out["tau"][i] - tau) <= G.tau_tol(tau, 1e-4))
+    G.setup_a1(gpu_ctx, pkg, 10)
