@@ -59,7 +59,8 @@ typedef enum {
     QRGPU_ERR_ALLOC = 5
 } qrgpu_error;
 
-/* Per-robot status word written by the kernels (bit field). */
+/* Per-robot status word written by the kernels: bits 0-7 are the flags below (0 = converged), bits 8 and up
+ * hold the number of MPC active-set iterations (diagnostic).  Test `(status & 0xff) == 0`. */
 #define QRGPU_ST_OK            0
 #define QRGPU_ST_MPC_MAXITER   0x1    /* active-set iteration cap reached            */
 #define QRGPU_ST_MPC_INFEAS    0x2    /* QP reported infeasible (cannot happen: u=0 is feasible) */
@@ -92,7 +93,9 @@ const char *qrgpu_last_error(const qrgpu_ctx *ctx);
 /* Device facts for reports: returns CU count, writes name (<= len). */
 int  qrgpu_device_info(const qrgpu_ctx *ctx, char *name, int len, int *lds_per_cu_bytes);
 
-/* ---- setup (SetupProblem / BuildDynamicModel) ------------------------------- */
+/* ---- setup (SetupProblem / BuildDynamicModel) -------------------------------
+ * A context has ONE horizon (the reference has one global problem size): setting a type up with a different
+ * horizon invalidates the MPC setup of the other types until they are set up again with the new horizon. */
 int qrgpu_mpc_setup(qrgpu_ctx *ctx, int type_id, float dt, int horizon, float mu, float fmax, float mass,
                     const float inertia[3], const float weights[12], float alpha);
 int qrgpu_wbc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_model_desc *desc);

@@ -246,8 +246,9 @@ int qrgpu_mpc_setup(qrgpu_ctx *c, int type_id, float dt, int horizon, float mu, 
 {
     if (!c || type_id < 0 || type_id >= QR_MAX_TYPES || !inertia || !weights) return QRGPU_ERR_BAD_ARG;
     if (horizon <= 0 || horizon > c->horizon_max) return QRGPU_ERR_BAD_ARG;
-    // one horizon per context (the reference has one global problem size, qr_mpc_interface.cpp:35-104)
-    for (int t = 0; t < QR_MAX_TYPES; ++t) if (t != type_id && c->mpc_ready[t] && c->mpc.horizon != horizon) return QRGPU_ERR_BAD_ARG;
+    // one horizon per context (the reference has one global problem size, qr_mpc_interface.cpp:35-104):
+    // a different horizon re-sizes the problem and invalidates the other types' setup, as a second SetupProblem would
+    if (c->mpc.horizon != horizon) for (int t = 0; t < QR_MAX_TYPES; ++t) if (t != type_id) c->mpc_ready[t] = false;
     MpcType &T = c->mpc.type[type_id];
     T.dt = dt; T.mu = mu; T.fmax = fmax; T.mass = mass; T.alpha = alpha;
     for (int i = 0; i < 3; ++i) T.inertia[i] = inertia[i];
