@@ -44,15 +44,20 @@ struct MpcLaunch {
     int lds_bytes;
 };
 
-// Bytes of LDS in front of the packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
+// Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
+// h <= 11 runs the four-wave active set (exchange buffers xz[4][NV], xr[4][64]); larger horizons the single-wave one
+// (staging wl, yl, rl and the sAct / sPos tables).
+__host__ __device__ static inline bool mpc_multi_wave(int h) { return 4 * h <= 44; }
 __host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h)
 {
     const size_t NV = 12 * (size_t)h, NL = 4 * (size_t)h;
-    size_t b = 8 * (3 * NV + QR_QH + NL);                        // gl wl yl rl fmk
-    b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);          // sT sU sSt sTraj sGait sV
-    b += 4 * (NL + QR_QH);                                       // sLs sAct
-    b += 2 * (6 * NL + ((6 * NL) & 1));                          // sPos
-    b += 4 * 4;                                                  // sMisc
+    size_t b;
+    if (mpc_multi_wave(h)) b = 8 * (NV + 4 * NV + 4 * 64 + NL);       // gl xz xr fmk
+    else b = 8 * (3 * NV + QR_QH + NL);                                // gl wl yl rl fmk
+    b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);                // sT sU sSt sTraj sGait sV
+    b += 4 * (NL + QR_QH);                                             // sLs sAct
+    b += 2 * (6 * NL + ((6 * NL) & 1));                                // sPos
+    b += 4 * 4;                                                        // sMisc
     return (b + 7) & ~(size_t)7;
 }
 

@@ -226,6 +226,46 @@ __device__ __forceinline__ Blk hess_block(const float *sT, const float *sU, int 
     return out;
 }
 
+// Phase 6: first-step forces (staged in LDS, 12 doubles) -> force[12][n], and tau = J^T (-R^T f) per leg
+// (qr_mpc_stance_leg_controller.cpp:402-409,139-153; AnalyticalLegJacobian QS/robots/qr_robot.cpp:148-172).
+__device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const double *yl, const float (&R)[3][3], const MpcType &C,
+                                            const float *__restrict__ g_q, float *__restrict__ g_force, float *__restrict__ g_force_wbc,
+                                            int force_stride, float *__restrict__ g_tau)
+{
+    if (lane < 12) {
+        const int leg = lane / 3, j = lane - 3 * leg;
+        const float fx = (float)yl[3 * leg], fy = (float)yl[3 * leg + 1], fz = (float)yl[3 * leg + 2];
+        g_force[(size_t)lane * n + rid] = (float)yl[lane];
+        if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yl[lane];
+        if (g_tau) {
+            // f_ff = -R^T f  (R^T = quaternionToRotationMatrix(quat)), tau = J^T f_ff
+            float fff[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fff[i] = (-R[0][i]) * fx + (-R[1][i]) * fy + (-R[2][i]) * fz;
+            const float t0 = g_q[(size_t)(3 * leg) * n + rid], t1 = g_q[(size_t)(3 * leg + 1) * n + rid], t2 = g_q[(size_t)(3 * leg + 2) * n + rid];
+            const float lu = C.upper_l, ll = C.lower_l;
+            const float sh = C.hip_l * ((leg & 1) ? 1.f : -1.f);
+            const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
+            const float tEff = t1 + t2 / 2;
+            float J0, J1, J2;     // column j of the leg Jacobian
+            if (j == 0) {
+                J0 = 0;
+                J1 = -sh * sinf(t0) + lEff * cosf(t0) * cosf(tEff);
+                J2 = sh * cosf(t0) + lEff * sinf(t0) * cosf(tEff);
+            } else if (j == 1) {
+                J0 = -lEff * cosf(tEff);
+                J1 = -lEff * sinf(t0) * sinf(tEff);
+                J2 = lEff * sinf(tEff) * cosf(t0);
+            } else {
+                J0 = ll * lu * sinf(t2) * sinf(tEff) / lEff - lEff * cosf(tEff) / 2;
+                J1 = -ll * lu * sinf(t0) * sinf(t2) * cosf(tEff) / lEff - lEff * sinf(t0) * sinf(tEff) / 2;
+                J2 = ll * lu * sinf(t2) * cosf(t0) * cosf(tEff) / lEff + lEff * sinf(tEff) * cosf(t0) / 2;
+            }
+            g_tau[(size_t)lane * n + rid] = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
+        }
+    }
+}
+
 template <int MAXB>
 __global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
 void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
@@ -245,11 +285,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 
     // ---------------- LDS carve (must match mpc_lds_fixed_bytes) ----------------
     extern __shared__ double smem[];
+    constexpr bool MULTI = (MAXB <= 4);   // four-wave active set (h <= 11), see mpc_multi_wave()
     double *gl = smem;                 // [NV] gradient (free variables, leg-step major)
-    double *wl = gl + NV;              // [NV] staging of w
-    double *yl = wl + NV;              // [NV] staging of y = N r
-    double *rl = yl + NV;              // [QH] staging of r
-    double *fmk = rl + QR_QH;          // [NL] f_z upper bound per free leg-step
+    double *wl = gl + NV;              // single-wave: [NV] staging of w          | four-wave: xz[4][NV] partial x / z exchange
+    double *yl = wl + NV;              // single-wave: [NV] staging of y = N r
+    double *rl = yl + NV;              // single-wave: [QH] staging of r
+    double *xz = gl + NV;
+    double *xr = xz + 4 * NV;          // four-wave: xr[4][64] partial r exchange
+    double *fmk = MULTI ? xr + 4 * 64 : rl + QR_QH;   // [NL] f_z upper bound per free leg-step
     float *sT = (float *)(fmk + NL);   // [4][3][3]
     float *sU = sT + 36;               // [4][3][3]
     float *sSt = sU + 36;              // [28]
@@ -522,6 +565,243 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         __syncthreads();
     }
     QR_TS(3);
+    // =====================================================================================================
+    // Four-wave active set (h <= 11).  All four wavefronts run the SAME control flow on the SAME data, so every
+    // decision is identical without communication (same code, same inputs, deterministic reductions); only the
+    // three loops whose cost grows with the working set are split four ways and recombined through LDS:
+    //   r = S^-1 d        wave v takes columns j = v (mod 4)      -> partial r   -> xr[4][64]  -> barrier -> sum
+    //   z = w - M (N r)   wave v takes every 4th active leg-step  -> partial z   -> xz[4][NV]  -> barrier -> sum
+    //   S^-1 +/- update   wave v updates columns j = v (mod 4) of every row (disjoint), visible after the next barrier
+    // Bookkeeping lives in registers, replicated per wave: working-set position i belongs to lane i (q <= 64):
+    // constraint (ck, ct), multiplier u, and d, r during an iteration; lane k knows its leg-step's active rows (amask)
+    // and their positions (posk).  Per-lane gathers use ds_bpermute (__shfl), uniform ones v_readlane.
+    // =====================================================================================================
+    if constexpr (MULTI) {
+        const int wv = tid >> 6;
+        const bool own = lane < nls;
+        const int kme = own ? lane : 0;
+        const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
+        const double fmaxk = own ? fmk[kme] : 0.0;
+        const int tril = tri(lane);
+        const double tol = 1e-9;
+        const double INF = __builtin_inf();
+        if (qcap > 64) qcap = 64;
+        // ---- phase 4: x = -M g, block columns kc = wv (mod 4) per wave
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        {
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+            if (own) {
+                for (int kc = wv; kc < nls; kc += 4) {
+                    Blk B; load_block(Mb, kme, kc, B);
+                    const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
+                    p0 += B.m[0] * g0 + B.m[1] * g1 + B.m[2] * g2;
+                    p1 += B.m[3] * g0 + B.m[4] * g1 + B.m[5] * g2;
+                    p2 += B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
+                }
+                xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2;
+            }
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { x0 -= xz[v * NV + 3 * kme]; x1 -= xz[v * NV + 3 * kme + 1]; x2 -= xz[v * NV + 3 * kme + 2]; }
+            }
+            __syncthreads();
+        }
+        QR_TS(4);
+        // ---- phase 5
+        int q = 0, iter = 0;
+        unsigned amask = 0, xmask = 0;
+        unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
+        int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
+        double uq = 0.0;                                  // its multiplier
+        const int maxit = 40 * nls + 100;
+        bool done = (nls == 0);
+        while (!done) {
+            // step 1: most violated inactive row (ties -> lowest id)
+            double bs = INF; int bt = 0;
+            if (own) {
+                const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+#pragma unroll
+                for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
+            }
+            const double smin = wave_min_d(bs);
+            if (!(smin < -tol)) break;
+            const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
+            const int tp = __builtin_amdgcn_readlane(bt, kp);
+            double c0, c1, c2;
+            cons_vec(tp, im, c0, c1, c2);
+            const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
+            double up = 0.0;
+            for (;;) {
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
+                // w_k = M_{k,kp} c_p
+                double w0 = 0.0, w1 = 0.0, w2_ = 0.0;
+                if (own) {
+                    Blk B; load_block(Mb, kme, kp, B);
+                    w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
+                    w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
+                    w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
+                }
+                const double delta = c0 * readlane_d(w0, kp) + c1 * readlane_d(w1, kp) + c2 * readlane_d(w2_, kp);
+                // d = N' w : position i needs w of leg-step ck(i)
+                double dq = 0.0;
+                {
+                    double a0, a1, a2;
+                    cons_vec(ct, im, a0, a1, a2);
+                    const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
+                    if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
+                }
+                // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
+                __syncthreads();                                  // B1: S^-1 updates of the previous iteration are visible
+                double rq = 0.0;
+                {
+                    const int i0 = (lane < q) ? lane : 0;
+                    double pr = 0.0;
+                    int j = wv;
+                    for (; j + 12 < q; j += 16) {
+                        double sv[4], dj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int jj = j + 4 * u;
+                            sv[u] = Sinv[(jj <= i0) ? tril + jj : tri(jj) + i0];
+                            dj[u] = readlane_d(dq, jj);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pr += sv[u] * dj[u];
+                    }
+                    for (; j < q; j += 4) pr += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(dq, j);
+                    if (lane < q) xr[wv * 64 + lane] = pr;
+                    __syncthreads();                              // B2
+                    if (lane < q) rq = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]);
+                }
+                const double dr = wave_sum_d(rq * dq);
+                const double zc = delta - dr;                    // z'c_p
+                // dual step length: min u_j / r_j over r_j > 0
+                double tt = INF;
+                if (lane < q && rq > 0.0) tt = uq * fast_rcp(rq);
+                const double t1 = wave_min_d(tt);
+                const int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
+                const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
+                const bool have_z = zc > 1e-13 * delta;
+                const double izc = fast_rcp(zc);
+                const double t2 = have_z ? -sp * izc : INF;
+                const double t = t1 < t2 ? t1 : t2;
+                if (!(t < INF)) {
+                    // degenerate corner (see the single-wave path): leave the row out until the working set changes
+                    if (lane == kp) xmask |= 1u << tp;
+                    break;
+                }
+                if (have_z) {
+                    // y_k = sum over the active rows of my leg-step of c_row * r(position)
+                    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+                    for (int tq = 0; tq < 6; ++tq) {
+                        const int ps = (int)((posk >> (8 * tq)) & 0x3full);
+                        const double rr = __shfl(rq, ps, 64);
+                        if ((amask >> tq) & 1u) {
+                            double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
+                            y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
+                        }
+                    }
+                    // partial z over every 4th active leg-step
+                    unsigned long long km = __ballot(own && amask != 0);
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+                    int idx = 0;
+                    while (km) {
+                        const int kc = (int)__builtin_ctzll(km);
+                        km &= km - 1;
+                        if (((idx++) & 3) != wv) continue;
+                        if (own) {
+                            Blk B; load_block(Mb, kme, kc, B);
+                            const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
+                            p0 += B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2;
+                            p1 += B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2;
+                            p2 += B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2;
+                        }
+                    }
+                    if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
+                    __syncthreads();                              // B3
+                    if (own) {
+                        double z0 = w0, z1 = w1, z2 = w2_;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) { z0 -= xz[v * NV + 3 * kme]; z1 -= xz[v * NV + 3 * kme + 1]; z2 -= xz[v * NV + 3 * kme + 2]; }
+                        x0 += t * z0; x1 += t * z1; x2 += t * z2;
+                    }
+                }
+                uq -= t * rq;
+                up += t;
+                if (have_z && t == t2) {
+                    // full step: the row joins the working set at position q; bordered update of S^-1
+                    if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
+                    const double isg = izc;
+                    {
+                        const bool act0 = lane < q;
+                        const double ri = rq * isg;
+                        int j = wv;
+                        for (; j + 12 < q; j += 16) {
+                            double sv[4], rj[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; rj[u] = readlane_d(rq, jj); sv[u] = (act0 && jj <= lane) ? Sinv[tril + jj] : 0.0; }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; if (act0 && jj <= lane) Sinv[tril + jj] = sv[u] + ri * rj[u]; }
+                        }
+                        for (; j < q; j += 4) { const double rj = readlane_d(rq, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
+                        if (wv == 0) {
+                            if (act0) Sinv[tri(q) + lane] = -rq * isg;
+                            if (lane == 0) Sinv[tri(q) + q] = isg;
+                        }
+                    }
+                    if (lane == q) { uq = up; ck = kp; ct = tp; }
+                    if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); }
+                    xmask = 0;
+                    ++q;
+                    break;
+                }
+                // partial or dual-only step: the constraint at lpos leaves; downdate S^-1, move the last one into its slot
+                {
+                    const int l = lpos, last = q - 1;
+                    double sl = 0.0;                              // column l of S^-1
+                    if (lane < q) sl = Sinv[pidx(lane, l)];
+                    const double isl = fast_rcp(readlane_d(sl, l));
+                    __syncthreads();                              // everyone has column l before anyone changes S^-1
+                    for (int j = wv; j < q; j += 4) {
+                        if (j == l) continue;
+                        const double sj = readlane_d(sl, j) * isl;
+                        if (lane < q && lane != l && j <= lane) Sinv[tril + j] -= sl * sj;
+                    }
+                    __syncthreads();
+                    const int clk = __builtin_amdgcn_readlane(ck, l), clt = __builtin_amdgcn_readlane(ct, l);
+                    const int cmk = __builtin_amdgcn_readlane(ck, last), cmt = __builtin_amdgcn_readlane(ct, last);
+                    if (l != last) {
+                        double m0 = 0.0;
+                        if (wv == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
+                        __syncthreads();
+                        if (wv == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
+                        const double ulast = readlane_d(uq, last);
+                        if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
+                    }
+                    if (lane == clk) amask &= ~(1u << clt);
+                    if (l != last && lane == cmk) posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt));
+                    xmask = 0;
+                    --q;
+                }
+            }
+        }
+        QR_TS(5);
+        if (wv != 0) return;
+        // ---- phase 6 (wave 0): stage the first-step forces through LDS, then the shared output code below
+        wave_sync();
+        if (lane < 12) xz[lane] = 0.0;
+        wave_sync();
+        if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
+        wave_sync();
+        mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+        if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+        QR_TS(6);
+        if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
+        return;
+    }
     if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below
 
     // ---------------- phase 4: x = -M g  (lane k owns leg-step k) ----------------
@@ -775,38 +1055,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     wave_sync();
     if (own) { const int ls = sLs[kme]; if (ls < 4) { yl[3 * ls] = x0; yl[3 * ls + 1] = x1; yl[3 * ls + 2] = x2; } }
     wave_sync();
-    if (lane < 12) {
-        const int leg = lane / 3, j = lane - 3 * leg;
-        const float fx = (float)yl[3 * leg], fy = (float)yl[3 * leg + 1], fz = (float)yl[3 * leg + 2];
-        g_force[(size_t)lane * n + rid] = (float)yl[lane];
-        if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yl[lane];
-        if (g_tau) {
-            // f_ff = -R^T f  (R^T = quaternionToRotationMatrix(quat)), tau = J^T f_ff
-            float fff[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) fff[i] = (-R[0][i]) * fx + (-R[1][i]) * fy + (-R[2][i]) * fz;
-            const float t0 = g_q[(size_t)(3 * leg) * n + rid], t1 = g_q[(size_t)(3 * leg + 1) * n + rid], t2 = g_q[(size_t)(3 * leg + 2) * n + rid];
-            const float lu = C.upper_l, ll = C.lower_l;
-            const float sh = C.hip_l * ((leg & 1) ? 1.f : -1.f);
-            const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
-            const float tEff = t1 + t2 / 2;
-            float J0, J1, J2;     // column j of the leg Jacobian
-            if (j == 0) {
-                J0 = 0;
-                J1 = -sh * sinf(t0) + lEff * cosf(t0) * cosf(tEff);
-                J2 = sh * cosf(t0) + lEff * sinf(t0) * cosf(tEff);
-            } else if (j == 1) {
-                J0 = -lEff * cosf(tEff);
-                J1 = -lEff * sinf(t0) * sinf(tEff);
-                J2 = lEff * sinf(tEff) * cosf(t0);
-            } else {
-                J0 = ll * lu * sinf(t2) * sinf(tEff) / lEff - lEff * cosf(tEff) / 2;
-                J1 = -ll * lu * sinf(t0) * sinf(t2) * cosf(tEff) / lEff - lEff * sinf(t0) * sinf(tEff) / 2;
-                J2 = ll * lu * sinf(t2) * cosf(t0) * cosf(tEff) / lEff + lEff * sinf(tEff) * cosf(t0) / 2;
-            }
-            g_tau[(size_t)lane * n + rid] = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
-        }
-    }
+    mpc_outputs(lane, rid, n, yl, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
     QR_TS(6);
     if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
