@@ -32,6 +32,7 @@
 // ============================================================================
 #include <hip/hip_runtime.h>
 #include "qr_device_types.h"
+#include "qr_wave_helpers.h"
 
 namespace qrgpu {
 
@@ -56,55 +57,6 @@ __device__ __forceinline__ void wave_sync()
 }
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 __device__ __forceinline__ int pidx(int i, int j) { return i >= j ? tri(i) + j : tri(j) + i; }
-
-// 1/x by v_rcp_f64 + two Newton steps (<= 1 ulp-ish; the active-set step lengths do not need IEEE division)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-// ---- cross-lane helpers (wave64) ---------------------------------------------------------------
-template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// srclane must be wave-uniform
-__device__ __forceinline__ double readlane_d(double v, int srclane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
-}
-// All-reduce inside each 16-lane row: xor 1, xor 2 (quad_perm), rotate by 4 and 8 (row_ror); then
-// the four row results are combined through v_readlane.  Result is wave-uniform.
-__device__ __forceinline__ double wave_min_d(double v)
-{
-    v = fmin(v, dpp_d<0xB1>(v));      // quad_perm [1,0,3,2]
-    v = fmin(v, dpp_d<0x4E>(v));      // quad_perm [2,3,0,1]
-    v = fmin(v, dpp_d<0x124>(v));     // row_ror:4
-    v = fmin(v, dpp_d<0x128>(v));     // row_ror:8
-    const double a = readlane_d(v, 0), b = readlane_d(v, 16), c = readlane_d(v, 32), d = readlane_d(v, 48);
-    return fmin(fmin(a, b), fmin(c, d));
-}
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x124>(v);
-    v += dpp_d<0x128>(v);
-    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
-}
-// lowest lane whose predicate holds (or -1); uniform
-__device__ __forceinline__ int first_lane(bool pred)
-{
-    const unsigned long long m = __ballot(pred);
-    return m ? (int)__builtin_ctzll(m) : -1;
-}
 
 // Pyramid row `t` of a leg-step (rows of f_block, :232-236, with the two-sided f_z row split):
 //   c'f + ci0 >= 0,  c = (c0, c1, c2)

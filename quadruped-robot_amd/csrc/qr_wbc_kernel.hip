@@ -25,6 +25,7 @@
 // ============================================================================
 #include <hip/hip_runtime.h>
 #include "qr_device_types.h"
+#include "qr_wave_helpers.h"
 
 namespace qrgpu {
 
@@ -147,23 +148,48 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ real wsum(real v)
+__device__ __forceinline__ real wsum(real v) { return wave_sum_d(v); }
+
+// sum_{t<k} a[t*as] b[t*bs], k <= 18: every load is issued before the first use
+__device__ __forceinline__ real dot18(const real *a, int as, const real *b, int bs, int k)
 {
+    real av[18], bv[18];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    for (int t = 0; t < 18; ++t) { const bool ok = t < k; av[t] = ok ? a[t * as] : 0.0; bv[t] = ok ? b[t * bs] : 0.0; }
+    real s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 18; t += 3) { s0 += av[t] * bv[t]; s1 += av[t + 1] * bv[t + 1]; s2 += av[t + 2] * bv[t + 2]; }
+    return (s0 + s1) + s2;
 }
 
+// e / n for 0 <= e < 1024, 1 <= n <= 32 with rcp = ceil(65536 / n): one multiply and a shift.
+__device__ __forceinline__ int fdiv16(int e, int rcp) { return (e * rcp) >> 16; }
+__device__ __forceinline__ int rcp16(int n) { return (65536 + n - 1) / n; }
+
 // C(m x n) = alpha * op(A)(m x k) * op(B)(k x n) + beta * C0 ; lane-parallel over outputs, ends with wsync.
-// tA: A stored k x m (use A^T);  tB: B stored n x k (use B^T).
+// tA: A stored k x m (use A^T);  tB: B stored n x k (use B^T).  k <= KMAX: the k-loop is fully unrolled and
+// predicated so that all 2k LDS loads of an output are in flight together (one wave per SIMD: latency is everything).
+template <int KMAX>
 __device__ __forceinline__ void gemm(int lane, real *C, int ldc, const real *A, int lda, bool tA, const real *B, int ldb, bool tB,
                                      int m, int n, int k, real alpha = 1.0, real beta = 0.0, const real *C0 = nullptr, int ldc0 = 0)
 {
+    const int rn = rcp16(n);
+    const int as = tA ? lda : 1, bs = tB ? 1 : ldb;
     for (int e = lane; e < m * n; e += 64) {
-        const int i = e / n, j = e - i * n;
-        real acc = 0.0;
-        for (int t = 0; t < k; ++t) acc += (tA ? A[t * lda + i] : A[i * lda + t]) * (tB ? B[j * ldb + t] : B[t * ldb + j]);
-        real v = alpha * acc;
+        const int i = fdiv16(e, rn), j = e - i * n;
+        const real *ap = tA ? A + i : A + i * lda;
+        const real *bp = tB ? B + j * ldb : B + j;
+        real av[KMAX], bv[KMAX];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) { const bool ok = t < k; av[t] = ok ? ap[t * as] : 0.0; bv[t] = ok ? bp[t * bs] : 0.0; }
+        real a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < KMAX; t += 3) {
+            a0 += av[t] * bv[t];
+            if (t + 1 < KMAX) a1 += av[t + 1] * bv[t + 1];
+            if (t + 2 < KMAX) a2 += av[t + 2] * bv[t + 2];
+        }
+        real v = alpha * ((a0 + a1) + a2);
         if (C0) v += beta * C0[i * ldc0 + j];
         C[i * ldc + j] = v;
     }
@@ -171,27 +197,43 @@ __device__ __forceinline__ void gemm(int lane, real *C, int ldc, const real *A, 
 }
 
 // In-place inverse of a symmetric positive definite n x n matrix (full storage, ld) by symmetric sweeps.
-// col: scratch n.  Returns (uniform) the smallest pivot seen.
+// Each lane keeps its <= UMAX elements (e = lane + 64 u) in registers for all n pivots; only the pivot column goes
+// through LDS (`col`, n doubles).  n * n <= 64 * UMAX.  Returns (uniform) the smallest pivot seen.
+template <int UMAX>
 __device__ __forceinline__ real spd_inverse(int lane, real *A, int ld, int n, real *col)
 {
+    const int rn = rcp16(n);
+    int ei[UMAX], ej[UMAX];
+    real a[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+        const int e = lane + 64 * u;
+        const bool ok = e < n * n;
+        ei[u] = ok ? fdiv16(e, rn) : -1;
+        ej[u] = ok ? e - ei[u] * n : -1;
+        a[u] = ok ? A[ei[u] * ld + ej[u]] : 0.0;
+    }
     real minpiv = 1e300;
     for (int k = 0; k < n; ++k) {
-        for (int i = lane; i < n; i += 64) col[i] = A[i * ld + k];
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) if (ej[u] == k) col[ei[u]] = a[u];
         wsync();
         const real piv = col[k];
         minpiv = piv < minpiv ? piv : minpiv;
-        const real ip = 1.0 / piv;
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            real v;
-            if (i == k) v = (j == k) ? -ip : col[j] * ip;
-            else if (j == k) v = col[i] * ip;
-            else v = A[i * ld + j] - col[i] * col[j] * ip;
-            A[i * ld + j] = v;
+        const real ip = fast_rcp(piv);
+        real ci[UMAX], cj[UMAX];
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) { const bool ok = ei[u] >= 0; ci[u] = ok ? col[ei[u]] : 0.0; cj[u] = ok ? col[ej[u]] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            if (ei[u] == k) a[u] = (ej[u] == k) ? -ip : cj[u] * ip;
+            else if (ej[u] == k) a[u] = ci[u] * ip;
+            else a[u] -= ci[u] * cj[u] * ip;
         }
-        wsync();
+        wsync();                                   // col is rewritten by the next pivot
     }
-    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; A[i * ld + j] = -A[i * ld + j]; }
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) if (ei[u] >= 0) A[ei[u] * ld + ej[u]] = -a[u];
     wsync();
     return minpiv;
 }
@@ -209,7 +251,7 @@ __device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real th
     }
     for (int e = lane; e < n * n; e += 64) Winv[e] = W[e];
     wsync();
-    const real minpiv = spd_inverse(lane, Winv, n, n, scr);
+    const real minpiv = spd_inverse<3>(lane, Winv, n, n, scr);        // n <= 12: 144 elements
     real fro = 0.0;
     for (int e = lane; e < n * n; e += 64) fro += Winv[e] * Winv[e];
     fro = wsum(fro);
@@ -256,8 +298,10 @@ __global__ __launch_bounds__(64, 1)
 void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
-                   float *__restrict__ g_dbg, int merge_tau, int status_or)
+                   float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT)
 {
+#define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+    QW_TS(0);
     const int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x;
     if (rid < 0) return;
@@ -315,6 +359,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     const real *quat = st, *pos = st + 4, *bv = st + 7, *qj = st + 13, *qdj = st + 25;
     const m3 Rwb = quat_to_rot_wb(quat);        // world -> body  (E of Xup[5])
 
+    QW_TS(1);
     // ---------------- K8-K10 per leg (lanes 0-3) ----------------
     if (lane < 4) {
         const int leg = lane, side = leg & 1;   // side 0: right (legs 0,2; sideSign<0), 1: left
@@ -463,6 +508,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
     }
     wsync();
+    QW_TS(2);
     // ---------------- base block (lane 0) ----------------
     if (lane == 0) {
         rbi IC5 = rbi_load(K.rb[QR_RB_BASE_EFF]);
@@ -506,11 +552,13 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (!g_tau) return;
     }
 
+    QW_TS(3);
     // ---------------- K13 GetModelRes: A^-1 ----------------
     for (int e = lane; e < 324; e += 64) Ai[e] = A[e];
     wsync();
-    spd_inverse(lane, Ai, 18, 18, tv);
+    spd_inverse<6>(lane, Ai, 18, 18, tv);                // 324 elements, 6 per lane
 
+    QW_TS(4);
     // ---------------- K11 tasks and contacts ----------------
     // task list: 0 = body orientation, 1 = body position, then swing feet in leg order; contacts: stance feet.
     int nc = 0, nt = 2;
@@ -613,15 +661,16 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         wsync();
     };
 
+    QW_TS(5);
     // ---------------- K12 kinematic multitask projection (only when its outputs are requested) ----------------
     if (g_qdes) {
         const real thr2 = 1e-6;       // singular value > 1e-3  <=>  eigenvalue of J J^T > 1e-6
         // Nc = I - pinv(Jc) Jc
         if (nc > 0) {
-            gemm(lane, lam, dimFr, JC, 18, false, JC, 18, true, dimFr, dimFr, 18);          // Jc Jc^T
+            gemm<18>(lane, lam, dimFr, JC, 18, false, JC, 18, true, dimFr, dimFr, 18);          // Jc Jc^T
             psd_pinv(lane, lam, dimFr, thr2, lamI, scr);
-            gemm(lane, JB, dimFr, JC, 18, true, lamI, dimFr, false, 18, dimFr, dimFr);        // pinv = Jc^T W^+
-            gemm(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
+            gemm<12>(lane, JB, dimFr, JC, 18, true, lamI, dimFr, false, 18, dimFr, dimFr);        // pinv = Jc^T W^+
+            gemm<12>(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
             for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
             wsync();
         } else {
@@ -630,10 +679,10 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
         for (int t = 0; t < nt; ++t) {
             load_Jt(t);
-            gemm(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                   // JtPre = Jt N_pre
-            gemm(lane, lam, 3, JtP, 18, false, JtP, 18, true, 3, 3, 18);
+            gemm<18>(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                   // JtPre = Jt N_pre
+            gemm<18>(lane, lam, 3, JtP, 18, false, JtP, 18, true, 3, 3, 18);
             psd_pinv(lane, lam, 3, thr2, lamI, scr);
-            gemm(lane, JtB, 3, JtP, 18, true, lamI, 3, false, 18, 3, 3);                    // pinv(JtPre) 18x3
+            gemm<3>(lane, JtB, 3, JtP, 18, true, lamI, 3, false, 18, 3, 3);                    // pinv(JtPre) 18x3
             // delta_q = prev + pinv (posErr - Jt prev),  qdot likewise
             if (lane < 6) {
                 const int which = lane / 3, i = lane - 3 * which;
@@ -656,12 +705,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             wsync();
             if (t < nt - 1) {
                 // N_pre <- N_pre (I - pinv JtPre)
-                gemm(lane, T1, 18, JtB, 3, false, JtP, 18, false, 18, 18, 3, -1.0);
-                for (int i = lane; i < 18; i += 64) T1[i * 18 + i] += 1.0;
-                wsync();
-                gemm(lane, T2, 18, Np, 18, false, T1, 18, false, 18, 18, 18);
-                for (int e = lane; e < 324; e += 64) Np[e] = T2[e];
-                wsync();
+                // N_pre (I - pinv JtPre) = N_pre - (N_pre pinv) JtPre : an 18x3 and a rank-3 product instead of 18x18x18
+                gemm<18>(lane, T1, 3, Np, 18, false, JtB, 3, false, 18, 3, 18);
+                gemm<3>(lane, Np, 18, T1, 3, false, JtP, 18, false, 18, 18, 3, -1.0, 1.0, Np, 18);
             }
         }
         if (lane < 12) {
@@ -671,15 +717,16 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         wsync();
     }
 
+    QW_TS(6);
     // ---------------- K13 MakeTorque: prioritized acceleration recursion ----------------
     const real thrW = 1e-4;       // WeightedInverse default threshold (qr_wholebody_impulse_ctrl.hpp:110)
     if (dimFr > 0) {
-        gemm(lane, T1, dimFr, Ai, 18, false, JC, 18, true, 18, dimFr, 18);               // temp = Ainv Jc^T   (18 x dimFr)
-        gemm(lane, lam, dimFr, JC, 18, false, T1, dimFr, false, dimFr, dimFr, 18);       // lambda = Jc temp
+        gemm<18>(lane, T1, dimFr, Ai, 18, false, JC, 18, true, 18, dimFr, 18);               // temp = Ainv Jc^T   (18 x dimFr)
+        gemm<18>(lane, lam, dimFr, JC, 18, false, T1, dimFr, false, dimFr, dimFr, 18);       // lambda = Jc temp
         psd_pinv(lane, lam, dimFr, thrW, lamI, scr);
-        gemm(lane, JB, dimFr, T1, dimFr, false, lamI, dimFr, false, 18, dimFr, dimFr);   // JcBar
+        gemm<12>(lane, JB, dimFr, T1, dimFr, false, lamI, dimFr, false, 18, dimFr, dimFr);   // JcBar
         if (lane < 18) { real acc = 0.0; for (int k = 0; k < dimFr; ++k) acc -= JB[lane * dimFr + k] * Jcd[3 * CLEG(k / 3) + k % 3]; qdd[lane] = acc; }
-        gemm(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
+        gemm<12>(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
         for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
         wsync();
     } else {
@@ -689,11 +736,11 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     }
     for (int t = 0; t < nt; ++t) {
         load_Jt(t);
-        gemm(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                    // JtPre = Jt Npre
-        gemm(lane, T1, 3, Ai, 18, false, JtP, 18, true, 18, 3, 18);                      // temp = Ainv JtPre^T (18x3)
-        gemm(lane, lam, 3, JtP, 18, false, T1, 3, false, 3, 3, 18);
+        gemm<18>(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                    // JtPre = Jt Npre
+        gemm<18>(lane, T1, 3, Ai, 18, false, JtP, 18, true, 18, 3, 18);                      // temp = Ainv JtPre^T (18x3)
+        gemm<18>(lane, lam, 3, JtP, 18, false, T1, 3, false, 3, 3, 18);
         psd_pinv(lane, lam, 3, thrW, lamI, scr);
-        gemm(lane, JtB, 3, T1, 3, false, lamI, 3, false, 18, 3, 3);                      // JtBar
+        gemm<3>(lane, JtB, 3, T1, 3, false, lamI, 3, false, 18, 3, 3);                      // JtBar
         if (lane < 3) {
             real acc = tkX[3 * t + lane] - ((t >= 2) ? Jcd[3 * TLEG(t - 2) + lane] : 0.0);
             for (int k = 0; k < 18; ++k) acc -= Jt[lane * 18 + k] * qdd[k];
@@ -703,15 +750,13 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (lane < 18) qdd[lane] += JtB[lane * 3] * tv[0] + JtB[lane * 3 + 1] * tv[1] + JtB[lane * 3 + 2] * tv[2];
         wsync();
         if (t < nt - 1) {
-            gemm(lane, T1, 18, JtB, 3, false, JtP, 18, false, 18, 18, 3, -1.0);
-            for (int i = lane; i < 18; i += 64) T1[i * 18 + i] += 1.0;
-            wsync();
-            gemm(lane, T2, 18, Np, 18, false, T1, 18, false, 18, 18, 18);
-            for (int e = lane; e < 324; e += 64) Np[e] = T2[e];
-            wsync();
+            // Npre (I - JtBar JtPre) = Npre - (Npre JtBar) JtPre
+            gemm<18>(lane, T2, 3, Np, 18, false, JtB, 3, false, 18, 3, 18);
+            gemm<3>(lane, Np, 18, T2, 3, false, JtP, 18, false, 18, 18, 3, -1.0, 1.0, Np, 18);
         }
     }
 
+    QW_TS(7);
     // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
     //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
     //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
@@ -760,7 +805,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     {
         // Goldfarb-Idnani, Schur-complement form, M = W^-1 diagonal, dense normals.
         int q = 0;
-        auto Minv = [&](int j) -> real { return (j < 6) ? 1.0 / (real)K.w_fb : 1.0 / (real)K.w_fr; };
+        const real iw_fb = 1.0 / (real)K.w_fb, iw_fr = 1.0 / (real)K.w_fr;
+        auto Minv = [&](int j) -> real { return (j < 6) ? iw_fb : iw_fr; };
         // one "add constraint c" attempt; returns 0 added, 1 dropped-one-and-retry, 2 failure/infeasible, 3 dependent
         int iter = 0;
         const int maxit = 200;
@@ -776,14 +822,13 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             else {
                 real bs = -1e-10; int bc = 0x7fffffff;
                 if (lane >= 6 && lane < np_ + mi && posi[lane] < 0) {
-                    real s = qc0[lane];
-                    for (int j = 0; j < nz; ++j) s += Nq[lane * 18 + j] * qx[j];
+                    const real s = qc0[lane] + dot18(Nq + lane * 18, 1, qx, 1, nz);
                     if (s < bs) { bs = s; bc = lane; }
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const real os = __shfl_xor(bs, m, 64); const int oc = __shfl_xor(bc, m, 64);
-                    if (os < bs || (os == bs && oc < bc)) { bs = os; bc = oc; }
+                {   // lowest-id lane holding the minimum (lane == constraint id here)
+                    const real mn = wave_min_d(bs);
+                    bc = (mn < -1e-10) ? first_lane(bs == mn && bc != 0x7fffffff) : 0x7fffffff;
+                    if (bc < 0) bc = 0x7fffffff;
                 }
                 if (bc == 0x7fffffff) break;
                 p = bc;
@@ -793,27 +838,26 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                 if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
                 if (lane < nz) qw[lane] = Minv(lane) * Nq[p * 18 + lane];
                 wsync();
-                real delta = 0.0;
-                for (int j = 0; j < nz; ++j) delta += Nq[p * 18 + j] * qw[j];
-                if (lane < q) { real acc = 0.0; for (int j = 0; j < nz; ++j) acc += Nq[act[lane] * 18 + j] * qw[j]; qd_[lane] = acc; }
+                const real delta = wsum((lane < nz) ? Nq[p * 18 + lane] * qw[lane] : 0.0);
+                if (lane < q) qd_[lane] = dot18(Nq + act[lane] * 18, 1, qw, 1, nz);
                 wsync();
                 real dr = 0.0;
-                if (lane < q) { real acc = 0.0; for (int j = 0; j < q; ++j) acc += Sq[lane * 18 + j] * qd_[j]; qr_[lane] = acc; dr = acc * qd_[lane]; }
+                if (lane < q) { const real acc = dot18(Sq + lane * 18, 1, qd_, 1, q); qr_[lane] = acc; dr = acc * qd_[lane]; }
                 dr = wsum(dr);
                 wsync();
                 const real zc = delta - dr;
                 real t1 = __builtin_inf(); int lpos = 0x7fffffff;
-                if (lane < q && act[lane] >= np_) { const real rj = qr_[lane]; if (rj > 0.0) { t1 = qu_[lane] / rj; lpos = lane; } }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const real ot = __shfl_xor(t1, m, 64); const int ol = __shfl_xor(lpos, m, 64);
-                    if (ot < t1 || (ot == t1 && ol < lpos)) { t1 = ot; lpos = ol; }
+                if (lane < q && act[lane] >= np_) { const real rj = qr_[lane]; if (rj > 0.0) { t1 = qu_[lane] * fast_rcp(rj); lpos = lane; } }
+                {
+                    const real mn = wave_min_d(t1);
+                    lpos = (mn < __builtin_inf()) ? first_lane(t1 == mn && lpos != 0x7fffffff) : 0x7fffffff;
+                    t1 = mn;
                 }
-                real sp = qc0[p];
-                for (int j = 0; j < nz; ++j) sp += Nq[p * 18 + j] * qx[j];
+                const real sp = qc0[p] + wsum((lane < nz) ? Nq[p * 18 + lane] * qx[lane] : 0.0);
                 const bool have_z = zc > 1e-13 * delta;
                 const bool is_eq = p < np_;
-                const real t2 = have_z ? -sp / zc : __builtin_inf();
+                const real izc = fast_rcp(zc);
+                const real t2 = have_z ? -sp * izc : __builtin_inf();
                 if (is_eq && !have_z) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }     // dependent equalities
                 const real t = is_eq ? t2 : (t1 < t2 ? t1 : t2);        // equalities take the full (signed) step
                 if (!is_eq && !(t < __builtin_inf())) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
@@ -821,7 +865,15 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                     // z = w - M N r ; x += t z
                     if (lane < nz) {
                         real acc = 0.0;
-                        for (int j = 0; j < q; ++j) acc += Nq[act[j] * 18 + lane] * qr_[j];
+                        {   // sum_j Nq[act[j]][lane] r_j, all loads first
+                            int aj[18]; real nv[18], rv2[18];
+#pragma unroll
+                            for (int j = 0; j < 18; ++j) aj[j] = (j < q) ? act[j] : 0;
+#pragma unroll
+                            for (int j = 0; j < 18; ++j) { nv[j] = (j < q) ? Nq[aj[j] * 18 + lane] : 0.0; rv2[j] = (j < q) ? qr_[j] : 0.0; }
+#pragma unroll
+                            for (int j = 0; j < 18; ++j) acc += nv[j] * rv2[j];
+                        }
                         qz[lane] = qw[lane] - Minv(lane) * acc;
                         qx[lane] += t * qz[lane];
                     }
@@ -830,7 +882,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                 up += t;
                 wsync();
                 if (have_z && (is_eq || t == t2)) {
-                    const real isg = 1.0 / zc;
+                    const real isg = izc;
                     for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; }
                     if (lane < q) { Sq[q * 18 + lane] = -qr_[lane] * isg; Sq[lane * 18 + q] = -qr_[lane] * isg; }
                     if (lane == 0) { Sq[q * 18 + q] = isg; act[q] = p; posi[p] = q; qu_[q] = up; }
@@ -863,6 +915,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
     }
 
+    QW_TS(8);
     // ---------------- GetSolution (:210-228) + store ----------------
     // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
     if (lane < 12) {
@@ -874,6 +927,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (!merge_tau || cm[63 + leg] != 0.0) g_tau[(size_t)lane * n + rid] = (float)acc;
     }
     if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
+    QW_TS(9);
 }
 
 }  // namespace qrgpu

@@ -23,7 +23,7 @@ extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const f
                                                  float *, int *, float *, float *, float *, int, long long *);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
-                              float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or);
+                              float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT);
 }
 using namespace qrgpu;
 
@@ -43,6 +43,7 @@ struct qrgpu_ctx {
     float *d_out1 = nullptr;      // staging: single-robot outputs
     int *d_st1 = nullptr;
     float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
+    void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
     int lds_per_cu = 0, num_cu = 0;
     std::string name;
@@ -322,7 +323,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     {
         TimerScope ts(c, 1);
         hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
-                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or);
+                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -436,7 +437,16 @@ int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const fl
 int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to disable */, int n)
 {   // undocumented diagnostic: phase cycle stamps of the last MPC launch (enable by calling once with NULL first)
     if (!c) return QRGPU_ERR_BAD_ARG;
-    if (!c->d_dbg_cycles) { HIPCHK(c, hipMalloc(&c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)c->max_batch)); return QRGPU_OK; }
+    if (!c->d_dbg_cycles) {
+        HIPCHK(c, hipMalloc(&c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)c->max_batch));
+        HIPCHK(c, hipMalloc(&c->d_dbg_cycles_wbc, sizeof(long long) * 16 * (size_t)(c->max_batch + 8)));
+        return QRGPU_OK;
+    }
+    if (host_out && n < 0) {   // n < 0: fetch the WBC kernel's stamps instead (indexed by workgroup)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(host_out, c->d_dbg_cycles_wbc, sizeof(long long) * 16 * (size_t)(-n), hipMemcpyDeviceToHost));
+        return QRGPU_OK;
+    }
     if (host_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(host_out, c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)n, hipMemcpyDeviceToHost)); }
     return QRGPU_OK;
 }

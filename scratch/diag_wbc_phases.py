@@ -1,0 +1,22 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+ctx = pkg.Context(0, 4096, 16)
+G.setup_a1(ctx, pkg, 10)
+lib = ctx._lib
+lib.qrgpu_debug_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.qrgpu_debug_cycles(ctx._h, None, 0)
+n = 1024
+b = pkg.make_batch(n, 10, "a1", seed=0xA3)
+out = G.run_tick(ctx, pkg, b); out = G.run_tick(ctx, pkg, b)
+buf = np.zeros((n, 16), np.int64)
+lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, -n)
+d = np.diff(buf[:, :10], axis=1).astype(np.float64)
+names = ["load", "per-leg dyn", "base block", "dbg", "A^-1", "tasks", "K12", "WBIC recursion", "QP", "store"]
+for k, nm in enumerate(names[:9]):
+    print("  %-16s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, k].mean(), np.median(d[:, k]), d[:, k].max()))
+print("total mean %.0f max %.0f" % ((buf[:, 9] - buf[:, 0]).mean(), (buf[:, 9] - buf[:, 0]).max()))
