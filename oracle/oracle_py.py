@@ -219,3 +219,12 @@ def tick_batch(mode, cfg, horizon, geom, model, mpc_state, traj, gait, fb_state,
                                _fp(np.ascontiguousarray(model, _f)), _fp(arrs[0]), _fp(arrs[1]), _fp(arrs[2]), _fp(arrs[3]),
                                _fp(arrs[4]), _fp(prev), _fp(force), _fp(tau), _ip(status))
     return force, tau, status, sec, prev
+
+
+def mpc_frontend(horizon, num_horizon_l, in64, st8):
+    """-> traj[12h] (or None when this tick does not re-plan), gait[4h], wbc15, contact4, new state, updated flag"""
+    i = np.ascontiguousarray(in64, _f); st = np.ascontiguousarray(st8, _f).copy()
+    traj = np.full(12 * horizon, np.nan, _f); gait = np.zeros(4 * horizon, _f); wbc = np.zeros(15, _f); ct = np.zeros(4, _f)
+    upd = C.c_int(0)
+    lib().qro_mpc_frontend(int(horizon), int(num_horizon_l), _fp(i), _fp(st), _fp(traj), _fp(gait), _fp(wbc), _fp(ct), C.byref(upd))
+    return dict(traj=traj, gait=gait, wbc15=wbc, contact=ct, state=st, updated=upd.value)

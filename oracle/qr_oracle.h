@@ -192,4 +192,15 @@ template <typename T> struct WbcOut {
 template <typename T> void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd,
                                    T prev_ori_vel[3], WbcOut<T> &out);
 
+
+// ---------------------------------------------------------------------------
+// MPC front-end.  qr_oracle_frontend.cpp
+// in[64] = des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd, basePosition[3], yawCurrent,
+//          quat_wxyz[4], footPosWorld[12] (leg major), footTargetWorld[12], contacts[4], phaseInFullCycle[4],
+//          dutyFactor[4], normalizedPhase[4], desiredLegState[4], legState[4], firstSwingBaseState x, y
+// st[8]  = xVelDes, yVelDes, yawTurnRate, yawDesTrue, posDesiredinWorld[3], iterationCounter   (in/out)
+// ---------------------------------------------------------------------------
+void mpc_frontend(int horizon, int numHorizonL, const float in[64], float st[8], float *traj, float *gait, float *wbc15,
+                  float contact_out[4], int *mpc_updated);
+
 }  // namespace qro

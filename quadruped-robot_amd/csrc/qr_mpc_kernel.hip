@@ -568,6 +568,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         double uq = 0.0;                                  // its multiplier
         const int maxit = 40 * nls + 100;
         bool done = (nls == 0);
+        bool after_drop = false;
         while (!done) {
             // step 1: most violated inactive row (ties -> lowest id)
             double bs = INF; int bt = 0;
@@ -605,7 +606,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
                 }
                 // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
-                __syncthreads();                                  // B1: S^-1 updates of the previous iteration are visible
+                if (after_drop) { __syncthreads(); after_drop = false; }   // B1: wave 0's row move of the last drop is visible
                 double rq = 0.0;
                 {
                     const int i0 = (lane < q) ? lane : 0;
@@ -643,6 +644,27 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     // degenerate corner (see the single-wave path): leave the row out until the working set changes
                     if (lane == kp) xmask |= 1u << tp;
                     break;
+                }
+                const bool full = have_z && t == t2;
+                if (full) {
+                    // bordered update of S^-1 (needs only r and 1/z'c): columns j = wv (mod 4); published by B3 below
+                    if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
+                    const double isg = izc;
+                    const bool act0 = lane < q;
+                    const double ri = rq * isg;
+                    int j = wv;
+                    for (; j + 12 < q; j += 16) {
+                        double sv[4], rj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; rj[u] = readlane_d(rq, jj); sv[u] = (act0 && jj <= lane) ? Sinv[tril + jj] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; if (act0 && jj <= lane) Sinv[tril + jj] = sv[u] + ri * rj[u]; }
+                    }
+                    for (; j < q; j += 4) { const double rj = readlane_d(rq, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
+                    if (wv == 0) {
+                        if (act0) Sinv[tri(q) + lane] = -rq * isg;
+                        if (lane == 0) Sinv[tri(q) + q] = isg;
+                    }
                 }
                 if (have_z) {
                     // y_k = sum over the active rows of my leg-step of c_row * r(position)
@@ -683,27 +705,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
                 uq -= t * rq;
                 up += t;
-                if (have_z && t == t2) {
-                    // full step: the row joins the working set at position q; bordered update of S^-1
-                    if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
-                    const double isg = izc;
-                    {
-                        const bool act0 = lane < q;
-                        const double ri = rq * isg;
-                        int j = wv;
-                        for (; j + 12 < q; j += 16) {
-                            double sv[4], rj[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; rj[u] = readlane_d(rq, jj); sv[u] = (act0 && jj <= lane) ? Sinv[tril + jj] : 0.0; }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; if (act0 && jj <= lane) Sinv[tril + jj] = sv[u] + ri * rj[u]; }
-                        }
-                        for (; j < q; j += 4) { const double rj = readlane_d(rq, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
-                        if (wv == 0) {
-                            if (act0) Sinv[tri(q) + lane] = -rq * isg;
-                            if (lane == 0) Sinv[tri(q) + q] = isg;
-                        }
-                    }
+                if (full) {
+                    // full step: the row joined the working set at position q (S^-1 already updated above)
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
                     if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); }
                     xmask = 0;
@@ -737,6 +740,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     if (l != last && lane == cmk) posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt));
                     xmask = 0;
                     --q;
+                    after_drop = true;
                 }
             }
         }
