@@ -14,6 +14,8 @@
  *                             QS/robots/qr_robot_a1_sim.cpp:176-343, QS/controllers/wbc/qr_wbc_locomotion_controller.cpp:29-77
  *   qrgpu_wbc_run1         <- qrWbcLocomotionController<float>::Run   QI/controllers/wbc/qr_wbc_locomotion_controller.hpp:59
  *   qrgpu_wbc_run_batch    <- the same, for n robots
+ *   qrgpu_mpc_frontend_batch <- MPCStanceLegController::SetupCommand/Run/UpdateMPC (reference trajectory + contact table)
+ *                             QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-382
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
  *
@@ -37,6 +39,12 @@
  *                       (stateful quirk of task_set/qr_task_body_orientation.cpp:68 vs :73)
  *   force     [12][n] : MPC ground-reaction forces of horizon step 0, world frame (= wbcData.Fr_des)
  *   tau       [12][n] : joint torques
+ *   fe_in     [64][n] : front-end inputs per control tick: des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd
+ *                       (stateDes 2,3,4,6,7,11 after UpdateDesCommand), basePosition[3], yaw, quat_wxyz[4], footPosWorld[12]
+ *                       (leg-major), footTargetPositionsInWorldFrame[12], contacts[4], phaseInFullCycle[4], dutyFactor[4],
+ *                       normalizedPhase[4], desiredLegState[4], legState[4] (LegState enum values as floats),
+ *                       firstSwingBaseState x, y
+ *   fe_state  [8][n]  : in/out controller memory: xVelDes, yVelDes, yawTurnRate, yawDesTrue, posDesiredinWorld[3], iterationCounter
  * ========================================================================== */
 #ifndef QRGPU_H
 #define QRGPU_H
@@ -115,6 +123,15 @@ int qrgpu_wbc_run_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float
 int qrgpu_tick_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_mpc_state,
                      const float *d_traj, const float *d_gait, const float *d_fb_state,
                      const float *d_wbc_cmd, float *d_prev_ori, float *d_force, float *d_tau, int *d_status);
+
+/* MPC front-end of n robots for one control tick: MPCStanceLegController::SetupCommand + Run + UpdateMPC without the solve
+ * (QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-204, 207-334, 337-382).  Writes the contact table d_gait every tick,
+ * the reference trajectory d_traj only for robots that re-plan this tick (iterationCounter % (round(dt_mpc/dt_ctrl)/2) == 0
+ * or < 50; d_mpc_updated[i] = 1, may be NULL), and rows 0-14 and 63-66 of d_wbc_cmd (may be NULL): pBody_des, vBody_des,
+ * aBody_des = 0, pBody_RPY_des, vBody_Ori_des, contact_state.  The horizon is the one of qrgpu_mpc_setup.
+ * Reference values: dt_ctrl 0.002, dt_mpc 0.06, num_horizon_l = max(2, int(fullCyclePeriod/0.4)) (:43-50). */
+int qrgpu_mpc_frontend_batch(qrgpu_ctx *ctx, int n, int num_horizon_l, float dt_ctrl, float dt_mpc, const float *d_fe_in,
+                             float *d_fe_state, float *d_traj, float *d_gait, float *d_wbc_cmd, int *d_mpc_updated);
 
 /* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */
 int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float v[3], const float quat_wxyz[4],

@@ -221,10 +221,10 @@ def tick_batch(mode, cfg, horizon, geom, model, mpc_state, traj, gait, fb_state,
     return force, tau, status, sec, prev
 
 
-def mpc_frontend(horizon, num_horizon_l, in64, st8):
+def mpc_frontend(horizon, num_horizon_l, in64, st8, dt=0.002, dt_mpc=0.06):
     """-> traj[12h] (or None when this tick does not re-plan), gait[4h], wbc15, contact4, new state, updated flag"""
     i = np.ascontiguousarray(in64, _f); st = np.ascontiguousarray(st8, _f).copy()
     traj = np.full(12 * horizon, np.nan, _f); gait = np.zeros(4 * horizon, _f); wbc = np.zeros(15, _f); ct = np.zeros(4, _f)
     upd = C.c_int(0)
-    lib().qro_mpc_frontend(int(horizon), int(num_horizon_l), _fp(i), _fp(st), _fp(traj), _fp(gait), _fp(wbc), _fp(ct), C.byref(upd))
+    lib().qro_mpc_frontend(int(horizon), int(num_horizon_l), C.c_float(dt), C.c_float(dt_mpc), _fp(i), _fp(st), _fp(traj), _fp(gait), _fp(wbc), _fp(ct), C.byref(upd))
     return dict(traj=traj, gait=gait, wbc15=wbc, contact=ct, state=st, updated=upd.value)

@@ -200,7 +200,7 @@ template <typename T> void wbc_run(const ModelDesc &md, const FBState<T> &st, co
 //          dutyFactor[4], normalizedPhase[4], desiredLegState[4], legState[4], firstSwingBaseState x, y
 // st[8]  = xVelDes, yVelDes, yawTurnRate, yawDesTrue, posDesiredinWorld[3], iterationCounter   (in/out)
 // ---------------------------------------------------------------------------
-void mpc_frontend(int horizon, int numHorizonL, const float in[64], float st[8], float *traj, float *gait, float *wbc15,
+void mpc_frontend(int horizon, int numHorizonL, float dt, float dtMPC, const float in[64], float st[8], float *traj, float *gait, float *wbc15,
                   float contact_out[4], int *mpc_updated);
 
 }  // namespace qro

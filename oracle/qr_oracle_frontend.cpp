@@ -12,10 +12,10 @@ namespace qro {
 
 static inline float clipf(float c, float lo, float hi) { return c < lo ? lo : (c > hi ? hi : c); }   // QI/utils/qr_algebra.h:57-65
 
-void mpc_frontend(int horizon, int numHorizonL, const float in[64], float st[8], float *traj, float *gait, float *wbc15 /*pBody vBody aBody rpy ori*/,
+void mpc_frontend(int horizon, int numHorizonL, float dt, float dtMPC, const float in[64], float st[8], float *traj, float *gait, float *wbc15 /*pBody vBody aBody rpy ori*/,
                   float contact_out[4], int *mpc_updated)
 {
-    const float dt = 0.002f, dtMPC = 0.06f;                       // :43-44
+    // dt = 0.002, dtMPC = 0.06 in the reference (:43-44)
     const double kPI = 3.14159265358979323846, k2PI = 6.28318530718;   // M_PI, M_2PI (QI/utils/qr_ctypes.h:51)
     const float des_height = in[0], des_pitch = in[2];
     const float x_vel_cmd = in[3], y_vel_cmd = in[4], yaw_vel_cmd = in[5];
@@ -116,8 +116,8 @@ void mpc_frontend(int horizon, int numHorizonL, const float in[64], float st[8],
 
 }  // namespace qro
 
-extern "C" void qro_mpc_frontend(int horizon, int numHorizonL, const float *in64, float *st8, float *traj, float *gait, float *wbc15,
+extern "C" void qro_mpc_frontend(int horizon, int numHorizonL, float dt, float dtMPC, const float *in64, float *st8, float *traj, float *gait, float *wbc15,
                                  float *contact4, int *mpc_updated)
 {
-    qro::mpc_frontend(horizon, numHorizonL, in64, st8, traj, gait, wbc15, contact4, mpc_updated);
+    qro::mpc_frontend(horizon, numHorizonL, dt, dtMPC, in64, st8, traj, gait, wbc15, contact4, mpc_updated);
 }

@@ -22,6 +22,8 @@ extern template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const f
 extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
                                                  float *, int *, float *, float *, float *, int, long long *);
 __global__ void qr_selftest_kernel(double *out);
+__global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
+                                   float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT);
 }
@@ -358,6 +360,19 @@ int qrgpu_fb_debug_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float 
 {
     if (!d_out) return QRGPU_ERR_BAD_ARG;
     return launch_wbc(c, n, d_type_id, d_fb_state, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, 0, 0);
+}
+
+int qrgpu_mpc_frontend_batch(qrgpu_ctx *c, int n, int num_horizon_l, float dt_ctrl, float dt_mpc, const float *d_fe_in, float *d_fe_state,
+                             float *d_traj, float *d_gait, float *d_wbc_cmd, int *d_mpc_updated)
+{
+    if (!c || n <= 0 || n > c->max_batch || !d_fe_in || !d_fe_state || !d_traj || !d_gait) return QRGPU_ERR_BAD_ARG;
+    if (num_horizon_l <= 0 || !(dt_ctrl > 0.f) || !(dt_mpc > 0.f)) return QRGPU_ERR_BAD_ARG;
+    if (!c->mpc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(qr_frontend_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->mpc.horizon, num_horizon_l, dt_ctrl, dt_mpc,
+                       d_fe_in, d_fe_state, d_traj, d_gait, d_wbc_cmd, d_mpc_updated);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
 }
 
 int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,

@@ -48,7 +48,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
-           "qrgpu_memcpy_d2h"]
+           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch"]
 
 
 def load_library():
@@ -73,6 +73,7 @@ def load_library():
     lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 10
     lib.qrgpu_mpc_assemble_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_mpc_frontend_batch.argtypes = [vp, ip, ip, C.c_float, C.c_float] + [vp] * 6
     lib.qrgpu_fb_debug_batch.argtypes = [vp, ip, vp, vp, vp]
     lib.qrgpu_mpc_solve1.argtypes = [vp, ip] + [fp] * 9 + [C.POINTER(C.c_double), fp, C.POINTER(ip)]
     lib.qrgpu_wbc_run1.argtypes = [vp, ip] + [fp] * 6 + [C.POINTER(ip)]
@@ -207,6 +208,11 @@ class Context:
     def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None):
         self._chk(self._lib.qrgpu_tick_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(fb_state),
                                              _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(status)))
+
+    def mpc_frontend_batch(self, n, fe_in, fe_state, traj, gait, wbc_cmd=None, mpc_updated=None, num_horizon_l=2, dt_ctrl=0.002, dt_mpc=0.06):
+        """SetupCommand + Run + UpdateMPC (without the solve) of n robots: qr_mpc_stance_leg_controller.cpp:158-382."""
+        self._chk(self._lib.qrgpu_mpc_frontend_batch(self._h, n, int(num_horizon_l), float(dt_ctrl), float(dt_mpc), _dp(fe_in), _dp(fe_state),
+                                                     _dp(traj), _dp(gait), _dp(wbc_cmd), _dp(mpc_updated)))
 
     def mpc_assemble_batch(self, n, mpc_state, traj, gait, H, g, type_id=None):
         self._chk(self._lib.qrgpu_mpc_assemble_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(H), _dp(g)))

@@ -174,3 +174,57 @@ def make_batch(n, horizon=10, robot="a1", seed=0xA1, frac_all_stance=0.05, frac_
 def to_soa(a):
     """[n,k] robot-major -> [k,n] field-major contiguous (robot index fastest: coalesced device loads)."""
     return np.ascontiguousarray(np.asarray(a).T)
+
+
+def make_frontend_batch(n, seed=0xFE, tick=0):
+    """Synthetic per-tick inputs of the MPC front-end (layout: include/qrgpu.h fe_in / fe_state), AoS [n][64] and [n][8].
+
+    A trot-like gait generator state: diagonal leg pairs half a cycle apart, duty factor 0.6, legs past the duty
+    factor swinging; a few robots carry an EARLY_CONTACT / lost-contact leg, yaw near +-pi and backwards commands so
+    every branch of SetupCommand / Run is taken somewhere in the batch."""
+    rng = np.random.default_rng(seed)
+    fe = np.zeros((n, 64), f32)
+    st = np.zeros((n, 8), f32)
+    fe[:, 0] = 0.28 + 0.02 * rng.standard_normal(n)                     # des height
+    fe[:, 1] = 0.02 * rng.standard_normal(n)
+    fe[:, 2] = 0.05 * rng.standard_normal(n)
+    fe[:, 3] = rng.uniform(-1.5, 2.5, n)                                # x vel cmd (clipped to [-1, 2] by the filter state)
+    fe[:, 4] = rng.uniform(-0.8, 0.8, n)
+    fe[:, 5] = rng.uniform(-1.0, 1.0, n)
+    fe[:, 6:8] = rng.uniform(-5, 5, (n, 2))
+    fe[:, 8] = 0.28 + 0.03 * rng.standard_normal(n)
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    yaw[: n // 8] = np.sign(yaw[: n // 8]) * rng.uniform(3.0, np.pi, n // 8)      # near the +-pi seam
+    rpy = np.stack([0.05 * rng.standard_normal(n), 0.05 * rng.standard_normal(n), yaw], 1)
+    fe[:, 9] = yaw
+    fe[:, 10:14] = _quat_from_rpy(rpy)
+    hip = np.array([[0.18, -0.13], [0.18, 0.13], [-0.18, -0.13], [-0.18, 0.13]])
+    phase0 = rng.uniform(0, 1, n)
+    duty = 0.6
+    for leg in range(4):
+        ph = (phase0 + (0.0 if leg in (0, 3) else 0.5)) % 1.0
+        c, s = np.cos(yaw), np.sin(yaw)
+        fx = fe[:, 6] + c * hip[leg, 0] - s * hip[leg, 1] + 0.03 * rng.standard_normal(n)
+        fy = fe[:, 7] + s * hip[leg, 0] + c * hip[leg, 1] + 0.03 * rng.standard_normal(n)
+        fe[:, 14 + 3 * leg] = fx; fe[:, 15 + 3 * leg] = fy; fe[:, 16 + 3 * leg] = 0.01 * rng.standard_normal(n)
+        fe[:, 26 + 3 * leg] = fx + 0.1 * rng.standard_normal(n); fe[:, 27 + 3 * leg] = fy + 0.1 * rng.standard_normal(n)
+        stance = ph < duty
+        fe[:, 42 + leg] = ph
+        fe[:, 46 + leg] = duty
+        fe[:, 50 + leg] = np.where(stance, ph / duty, (ph - duty) / (1 - duty))
+        des = np.where(stance, 1, 0)                                     # LegState: SWING 0, STANCE 1
+        leg_state = des.copy()
+        early = (~stance) & (rng.uniform(0, 1, n) < 0.1)
+        leg_state[early] = 2                                            # EARLY_CONTACT
+        lost = stance & (rng.uniform(0, 1, n) < 0.05)
+        leg_state[lost] = 3                                             # LOSE_CONTACT
+        fe[:, 54 + leg] = des
+        fe[:, 58 + leg] = leg_state
+        fe[:, 38 + leg] = ((leg_state == 1) | (leg_state == 2)).astype(f32)
+    fe[:, 62:64] = fe[:, 6:8] + 0.05 * rng.standard_normal((n, 2))
+    st[:, 0] = rng.uniform(-1.2, 2.2, n); st[:, 1] = rng.uniform(-0.7, 0.7, n); st[:, 2] = rng.uniform(-1, 1, n)
+    st[:, 3] = yaw + 0.02 * rng.standard_normal(n)
+    st[:, 4:6] = fe[:, 6:8] + 0.2 * rng.standard_normal((n, 2))        # some beyond the +-0.1 clip of UpdateMPC
+    st[:, 6] = fe[:, 0]
+    st[:, 7] = tick + rng.integers(0, 120, n)                          # both sides of the <50 / %15 cadence
+    return fe, st
