@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--excite", type=float, default=1.0)
     ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +112,8 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     # every rank owns its own contiguous shard of the global robot population (seed offset by rank)
-    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite)
+    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite,
+                       **(dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}))
     S = pkg.to_soa
     T = lambda a: torch.from_numpy(S(a)).to(dev)
     d_state, d_traj, d_gait = T(b["mpc_state"]), T(b["traj"]), T(b["gait"])
@@ -154,6 +156,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same loop without the longest-first dispatch history (DESIGN.md "tail"): what a batch with no temporal coherence gets
+    value_no_lpt = None
+    if world == 1:
+        ctx.set_lpt_schedule(False)
+        for _ in range(3):
+            step()
+        fence()
+        tq0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        value_no_lpt = n * args.steps / (time.perf_counter() - tq0)
+        ctx.set_lpt_schedule(True)
+
     # PCIe-inclusive rate (never `value`): host buffers in, torques out, every step
     pcie_value = None
     if world == 1 and args.mode == "tick":
@@ -170,6 +186,23 @@ def main():
             host_tau.copy_(d_tau, non_blocking=True)
             torch.cuda.synchronize()
         pcie_value = n * 20 / (time.perf_counter() - tp0)
+
+    # MPC front-end timed on its own: it is a streaming kernel in front of the tick, not part of `value`
+    fe_us = None
+    if world == 1:
+        fe, fst = pkg.workload.make_frontend_batch(n, seed=0xFE)
+        d_fe, d_fst = T(fe), T(fst)
+        d_traj2, d_gait2, d_cmd2 = torch.empty_like(d_traj), torch.empty_like(d_gait), torch.empty_like(d_cmd)
+        d_upd = torch.zeros((n,), dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            ctx.mpc_frontend_batch(n, d_fe, d_fst, d_traj2, d_gait2, d_cmd2, d_upd)
+        e0.record(stream)
+        for _ in range(50):
+            ctx.mpc_frontend_batch(n, d_fe, d_fst, d_traj2, d_gait2, d_cmd2, d_upd)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        fe_us = 1e3 * e0.elapsed_time(e1) / 50
 
     status = d_status.cpu().numpy()
     iters = (status >> 8).astype(np.float64)
@@ -201,7 +234,8 @@ def main():
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
                        "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
-                       "pcie_inclusive_ticks_per_s": pcie_value},
+                       "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us,
+                       "dispatch": "longest-first from the previous step's per-robot solve time", "ticks_per_s_slot_order_dispatch": value_no_lpt},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel_ms": dom_ms, "kernel_launches": mpc_cnt if dom_name == "qr_mpc_kernel" else wbc_cnt,

@@ -97,6 +97,11 @@ int  qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out
 void qrgpu_destroy(qrgpu_ctx *ctx);
 /* Launch on this hipStream_t (NULL = the default stream). */
 int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
+/* Longest-first dispatch of the batched MPC solve (default on): robot i's solve time in one call orders the workgroup
+ * dispatch of the next call with the same n (control ticks are temporally coherent).  Scheduling only -- results do not
+ * depend on it; a batch whose robots were reshuffled between calls merely loses the speed-up.  Turning it on or off
+ * forgets the history. */
+int  qrgpu_set_lpt_schedule(qrgpu_ctx *ctx, int on);
 const char *qrgpu_last_error(const qrgpu_ctx *ctx);
 /* Device facts for reports: returns CU count, writes name (<= len). */
 int  qrgpu_device_info(const qrgpu_ctx *ctx, char *name, int len, int *lds_per_cu_bytes);

@@ -42,6 +42,10 @@ struct MpcLaunch {
     int n;
     int horizon;
     int lds_bytes;
+    // Longest-first dispatch (DESIGN.md "tail"): slot j of an XCD's chunk solves robot order[j]; the kernel records what
+    // the robot cost this time (clock64 ticks >> 12, saturated) for qr_lpt_order_kernel.  Either may be null.
+    const int *order;
+    int *cost;
 };
 
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).

@@ -229,8 +229,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n = P.n;
-    const int rid = xcd_robot_index(blockIdx.x, n);
-    if (rid < 0) return;
+    const int slot = xcd_robot_index(blockIdx.x, n);
+    if (slot < 0) return;
+    const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+    const long long t_begin = P.cost ? clock64() : 0;
     const MpcType &C = P.type[type_id ? type_id[rid] : 0];
     const int h = P.horizon;
     const int NV = 12 * h, NL = 4 * h;
@@ -754,6 +756,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         wave_sync();
         mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
         if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+        if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
         QR_TS(6);
         if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
         return;
@@ -1013,6 +1016,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     wave_sync();
     mpc_outputs(lane, rid, n, yl, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+    if (tid == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
     QR_TS(6);
     if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
 }
@@ -1021,6 +1025,29 @@ template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *,
                                           int *, float *, float *, float *, int, long long *);
 template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,
                                           int *, float *, float *, float *, int, long long *);
+
+// Longest-processing-time-first dispatch order for the next launch.  A robot's solve time varies 10x with its active-set
+// iteration count, and with two resident workgroups per CU a long solve that starts late sets the kernel time.  Block
+// dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
+// the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
+// leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
+__global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
+{
+    __shared__ int hist[256];
+    const int chunk = (n + 7) >> 3;
+    const int lo = blockIdx.x * chunk;
+    const int hi = (lo + chunk < n) ? lo + chunk : n;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < 256; ++b) { const int c = hist[b]; hist[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 256) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
+}
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

@@ -22,6 +22,7 @@ extern template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const f
 extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
                                                  float *, int *, float *, float *, float *, int, long long *);
 __global__ void qr_selftest_kernel(double *out);
+__global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
@@ -44,6 +45,10 @@ struct qrgpu_ctx {
     float *d_in1 = nullptr;       // staging: single-robot inputs
     float *d_out1 = nullptr;      // staging: single-robot outputs
     int *d_st1 = nullptr;
+    int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
+    int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
+    int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
+    bool lpt = true;
     float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
     void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
@@ -211,7 +216,8 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
     const size_t in1 = 28 + 12 * QRGPU_MAX_HORIZON + 4 * QRGPU_MAX_HORIZON + 12 + 37 + 67 + 3;
     if (hipMalloc(&c->d_in1, in1 * sizeof(float)) != hipSuccess || hipMalloc(&c->d_out1, 64 * sizeof(float)) != hipSuccess ||
         hipMalloc(&c->d_st1, 4 * sizeof(int)) != hipSuccess || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
-        hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess) {
+        hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
@@ -231,9 +237,18 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_st1) hipFree(c->d_st1);
     if (c->d_wbc) hipFree(c->d_wbc);
     if (c->d_cmd_tick) hipFree(c->d_cmd_tick);
+    if (c->d_order) hipFree(c->d_order);
+    if (c->d_cost) hipFree(c->d_cost);
     delete c;
 }
 
+int qrgpu_set_lpt_schedule(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->lpt = on != 0;
+    c->lpt_n = 0;
+    return QRGPU_OK;
+}
 int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; return QRGPU_OK; }
 const char *qrgpu_last_error(const qrgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
 int qrgpu_device_info(const qrgpu_ctx *c, char *name, int len, int *lds)
@@ -292,6 +307,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     MpcLaunch P = c->mpc;
     P.n = n;
     P.lds_bytes = mpc_lds_bytes(c, P.horizon);
+    // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
+    const bool lpt = c->lpt && n >= 64 && !dH;
+    P.order = (lpt && c->lpt_n == n) ? c->d_order : nullptr;
+    P.cost = lpt ? c->d_cost : nullptr;
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
     static int configured_lds[2] = {0, 0};
@@ -310,6 +329,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
                                d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
     }
     HIPCHK(c, hipGetLastError());
+    if (lpt) {
+        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
+        HIPCHK(c, hipGetLastError());
+        c->lpt_n = n;
+    }
     return QRGPU_OK;
 }
 
