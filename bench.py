@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--excite", type=float, default=1.0)
     ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compare-dispatch", action="store_true",
+                    help="also time the loop with slot-order dispatch (no longest-first history); off by default so that a profile of the "
+                         "default command holds only launches of the measured configuration")
     ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
     args = ap.parse_args()
 
@@ -158,7 +161,7 @@ def main():
 
     # the same loop without the longest-first dispatch history (DESIGN.md "tail"): what a batch with no temporal coherence gets
     value_no_lpt = None
-    if world == 1:
+    if world == 1 and args.compare_dispatch:
         ctx.set_lpt_schedule(False)
         for _ in range(3):
             step()

@@ -26,13 +26,14 @@ def build(force=False, verbose=False):
     """hipcc cross-compiles without a GPU.  Returns the path of the shared library."""
     if not force and not _stale():
         return SO
+    flags = FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else [])
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -571,6 +571,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         const int maxit = 40 * nls + 100;
         bool done = (nls == 0);
         bool after_drop = false;
+        long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = dbgT ? clock64() : 0;
+#ifdef QR_GI_STAMPS      // sub-phase cycle accounting of the loop below (build.py: QRGPU_GI_STAMPS=1); costs ~15 % when compiled in
+#define QM_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
+#else
+#define QM_STAMP(i) do { } while (0)
+#endif
         while (!done) {
             // step 1: most violated inactive row (ties -> lowest id)
             double bs = INF; int bt = 0;
@@ -587,6 +593,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             cons_vec(tp, im, c0, c1, c2);
             const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
             double up = 0.0;
+            QM_STAMP(0);
             for (;;) {
                 q = __builtin_amdgcn_readfirstlane(q);
                 if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
@@ -607,6 +614,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
                     if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
                 }
+                QM_STAMP(1);
                 // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
                 if (after_drop) { __syncthreads(); after_drop = false; }   // B1: wave 0's row move of the last drop is visible
                 double rq = 0.0;
@@ -630,6 +638,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     __syncthreads();                              // B2
                     if (lane < q) rq = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]);
                 }
+                QM_STAMP(2);
                 const double dr = wave_sum_d(rq * dq);
                 const double zc = delta - dr;                    // z'c_p
                 // dual step length: min u_j / r_j over r_j > 0
@@ -648,6 +657,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     break;
                 }
                 const bool full = have_z && t == t2;
+                QM_STAMP(3);
                 if (full) {
                     // bordered update of S^-1 (needs only r and 1/z'c): columns j = wv (mod 4); published by B3 below
                     if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
@@ -668,6 +678,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (lane == 0) Sinv[tri(q) + q] = isg;
                     }
                 }
+                QM_STAMP(4);
                 if (have_z) {
                     // y_k = sum over the active rows of my leg-step of c_row * r(position)
                     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
@@ -707,6 +718,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
                 uq -= t * rq;
                 up += t;
+                QM_STAMP(5);
                 if (full) {
                     // full step: the row joined the working set at position q (S^-1 already updated above)
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
@@ -758,7 +770,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
         if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
         QR_TS(6);
-        if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
+        if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
         return;
     }
     if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below

@@ -27,7 +27,7 @@ print("total per WG mean %.0f max %.0f ; GI ticks per iteration mean %.0f ; iter
 print("span first start -> last end: %.0f ticks" % (buf[:, 6].max() - buf[:, 0].min()))
 
 sub = buf[:, 8:14].astype(np.float64)
-nm2 = ["scan+select", "w+delta", "d,r", "zc,t1,t2", "y,z,x", "S^-1 add"]
+nm2 = ["scan+select(+bookkeeping)", "w,delta,d", "r loop+B2", "dr,t1,sp,t2", "S^-1 add", "y,z loop,B3,x,u"]
 for k, nm in enumerate(nm2):
     print("  GI %-12s per-iter mean %8.0f   share %.2f" % (nm, (sub[:, k] / np.maximum(it, 1)).mean(), sub[:, k].sum() / d[:, 4].sum()))
 print("final q mean %.1f max %d" % (buf[:, 14].mean(), buf[:, 14].max()))
