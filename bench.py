@@ -206,6 +206,23 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         fe_us = 1e3 * e0.elapsed_time(e1) / 50
+    # force-balance (VMC) stance QP, also timed on its own
+    vmc_us = None
+    if world == 1:
+        ctx.vmc_setup_packed(0, pkg.workload.vmc_cfg("a1"), pkg.model_desc("a1")[:3])
+        vin, vq = pkg.workload.make_vmc_batch(n, seed=0xB2)
+        d_vin, d_vq = T(vin), T(vq)
+        d_vf, d_vt = torch.empty((12, n), dtype=torch.float32, device=dev), torch.empty((12, n), dtype=torch.float32, device=dev)
+        d_vs = torch.zeros((n,), dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
+        e0.record(stream)
+        for _ in range(20):
+            ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        vmc_us = 1e3 * e0.elapsed_time(e1) / 20
 
     status = d_status.cpu().numpy()
     iters = (status >> 8).astype(np.float64)
@@ -237,7 +254,7 @@ def main():
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
                        "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
-                       "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us,
+                       "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us, "vmc_qp_kernel_us": vmc_us,
                        "dispatch": "longest-first from the previous step's per-robot solve time", "ticks_per_s_slot_order_dispatch": value_no_lpt},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,

@@ -16,6 +16,9 @@
  *   qrgpu_wbc_run_batch    <- the same, for n robots
  *   qrgpu_mpc_frontend_batch <- MPCStanceLegController::SetupCommand/Run/UpdateMPC (reference trajectory + contact table)
  *                             QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-382
+ *   qrgpu_vmc_setup / qrgpu_vmc_force_batch <- Quadruped::ComputeContactForce (control-frame overload) + qrRobot::MapContactForceToJointTorques
+ *                             QS/controllers/balance_controller/qr_qp_torque_optimizer.cpp:190-301, QS/robots/qr_robot.cpp:241-251
+ *                             (what TorqueStanceLegController::GetAction calls, qr_torque_stance_leg_controller.cpp:500-507)
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
  *
@@ -39,6 +42,8 @@
  *                       (stateful quirk of task_set/qr_task_body_orientation.cpp:68 vs :73)
  *   force     [12][n] : MPC ground-reaction forces of horizon step 0, world frame (= wbcData.Fr_des)
  *   tau       [12][n] : joint torques
+ *   vmc_in    [37][n] : force-balance QP inputs: footPositionsInBaseFrame[12] (3*leg+axis), desiredAcc[6], contacts[4],
+ *                       Rcb[9] (row-major; identity on PLANE / PLUM_PILES terrain), g.head(3) ((0,0,9.8) on a plane), surfaceNormal[3]
  *   fe_in     [64][n] : front-end inputs per control tick: des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd
  *                       (stateDes 2,3,4,6,7,11 after UpdateDesCommand), basePosition[3], yaw, quat_wxyz[4], footPosWorld[12]
  *                       (leg-major), footTargetPositionsInWorldFrame[12], contacts[4], phaseInFullCycle[4], dutyFactor[4],
@@ -76,6 +81,9 @@ typedef enum {
 #define QRGPU_ST_MPC_NOTSPD    0x8    /* Hessian pivot <= 0                          */
 #define QRGPU_ST_WBC_MAXITER   0x10
 #define QRGPU_ST_WBC_INFEAS    0x20
+#define QRGPU_ST_VMC_MAXITER   0x40
+#define QRGPU_ST_VMC_INFEAS    0x80   /* QuadProg++ would have returned +inf (e.g. the 1e-7 window of a swing foot, qr_qp_torque_optimizer.cpp:79-81);
+                                         the force is the iterate QuadProg++ stops at, which is what the reference goes on to use (:281-297) */
 
 /* What BuildDynamicModel reads from YAML plus what the WBC controller hard-codes.
  * Defaults (qrgpu_model_desc_default) are the A1 values. */
@@ -90,6 +98,17 @@ typedef struct {
 } qrgpu_model_desc;
 
 void qrgpu_model_desc_default(qrgpu_model_desc *d);
+
+/* Per-type constants of the force-balance (VMC) QP: ComputeContactForce's non-per-tick arguments.  Defaults: A1 + the header defaults
+ * (QI/controllers/balance_controller/qr_qp_torque_optimizer.h:144-153), acc_weight of config/a1_sim/stance_leg_controller.yaml. */
+typedef struct {
+    float mass;                           /* robot->totalMass */
+    float inertia[9];                     /* robot->totalInertia, Eigen column-major (the YAML list as mapped by MatrixXf::Map) */
+    float acc_weight[6];
+    float reg_weight, friction, fmin_ratio, fmax_ratio;   /* 1e-4, 0.5, 0.01, 10 */
+    float hip_l, upper_l, lower_l;        /* leg geometry for the J^T f torque map */
+} qrgpu_vmc_desc;
+void qrgpu_vmc_desc_default(qrgpu_vmc_desc *d);
 
 /* ---- lifetime -------------------------------------------------------------- */
 /* device_id: HIP device ordinal.  max_batch: largest n of any batched call. */
@@ -138,6 +157,12 @@ int qrgpu_tick_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d
 int qrgpu_mpc_frontend_batch(qrgpu_ctx *ctx, int n, int num_horizon_l, float dt_ctrl, float dt_mpc, const float *d_fe_in,
                              float *d_fe_state, float *d_traj, float *d_gait, float *d_wbc_cmd, int *d_mpc_updated);
 
+/* Force-balance stance forces of n robots: contact forces in the base frame, force[3*leg+axis] (the 3x4 matrix ComputeContactForce
+ * returns, column-major) and, when d_q and d_tau are given, the joint torques J^T f of MapContactForceToJointTorques. */
+int qrgpu_vmc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_vmc_desc *desc);
+int qrgpu_vmc_force_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q /*[12][n], may be NULL*/,
+                          float *d_force, float *d_tau /*may be NULL*/, int *d_status /*may be NULL*/);
+
 /* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */
 int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float v[3], const float quat_wxyz[4],
                      const float w[3], const float r_3x4_colmajor[12], const float rpy[3],
@@ -145,6 +170,9 @@ int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float 
                      double f_out[12], float tau_out[12] /*may be NULL*/, int *status);
 int qrgpu_wbc_run1(qrgpu_ctx *ctx, int type_id, const float fb_state[37], const float wbc_cmd[67],
                    float prev_ori_vel[3], float tau_out[12], float qdes_out[12], float qddes_out[12], int *status);
+
+int qrgpu_vmc_force1(qrgpu_ctx *ctx, int type_id, const float vmc_in[37], const float q[12] /*may be NULL*/,
+                     float force_out[12], float tau_out[12] /*may be NULL*/, int *status);
 
 /* ---- inspection (parity tests): the fp32 QP data the MPC kernel assembled ----- */
 /* d_H: [n][12h*12h] row-major per robot, d_g: [n][12h]; entries that involve a swing

@@ -138,4 +138,36 @@ inline int WbcSetup(float hip_l, float upper_l, float lower_l)
     return qrgpu_wbc_setup(g.ctx, 0, &d);
 }
 
+// Body of Quadruped::ComputeContactForce, control-frame overload (quadruped/src/controllers/balance_controller/
+// qr_qp_torque_optimizer.cpp:190-301), for the call TorqueStanceLegController::GetAction makes (:500).  The caller keeps the terrain
+// branch of :214-223 and hands over what it produced: Rcb (row-major 3x3; identity on PLANE / PLUM_PILES), g.head(3), surfaceNormal.
+// Robot: GetFootPositionsInBaseFrame() -> something with (row, col) access like Eigen::Matrix<float,3,4>.  Writes the 3x4 force matrix
+// through out(row, col).  Per-type constants (mass, inertia, weights, ratios) go in once through VmcSetup.
+template <class Robot, class V6, class V4, class M34>
+inline int VmcContactForce(Robot *robot, const float Rcb[9], const float g3[3], const float normal[3], const V6 &desiredAcc, const V4 &contacts, M34 &out)
+{
+    auto &g = global();
+    if (!g.ctx) return QRGPU_ERR_NO_DEVICE;
+    float in[37];
+    auto fp = robot->GetFootPositionsInBaseFrame();
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) in[3 * l + i] = fp(i, l);
+    for (int i = 0; i < 6; ++i) in[12 + i] = desiredAcc[i];
+    for (int l = 0; l < 4; ++l) in[18 + l] = contacts[l] ? 1.f : 0.f;
+    for (int i = 0; i < 9; ++i) in[22 + i] = Rcb[i];
+    for (int i = 0; i < 3; ++i) { in[31 + i] = g3[i]; in[34 + i] = normal[i]; }
+    float f[12];
+    int status = 0;
+    int rc = qrgpu_vmc_force1(g.ctx, 0, in, nullptr, f, nullptr, &status);
+    if (rc != QRGPU_OK) return rc;
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) out(i, l) = f[3 * l + i];
+    return status;
+}
+
+inline int VmcSetup(const qrgpu_vmc_desc &d)
+{
+    auto &g = global();
+    if (!g.ctx) return QRGPU_ERR_NO_DEVICE;
+    return qrgpu_vmc_setup(g.ctx, 0, &d);
+}
+
 }  // namespace qrgpu_adapters

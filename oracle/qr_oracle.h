@@ -194,6 +194,24 @@ template <typename T> void wbc_run(const ModelDesc &md, const FBState<T> &st, co
 
 
 // ---------------------------------------------------------------------------
+// Force-balance (VMC) stance QP.  qr_oracle_vmc.cpp
+// ---------------------------------------------------------------------------
+struct VmcConfig {                // ComputeContactForce defaults (QI/controllers/balance_controller/qr_qp_torque_optimizer.h:144-153)
+    float mass = 13.f; float inertia[9] = {0.24f, 0, 0, 0, 0.80f, 0, 0, 0, 1.0f};
+    float acc_weight[6] = {1, 1, 1, 10, 10, 1}; float reg_weight = 1e-4f, friction = 0.5f, fmin_ratio = 0.01f, fmax_ratio = 10.f;
+};
+struct VmcInput {                 // per tick
+    float foot_pos_base[12];      // 3*leg+axis, GetFootPositionsInBaseFrame
+    float desired_acc[6];         // KP/KD output (ddqDes.head(6))
+    float contacts[4];
+    float Rcb[9];                 // row-major; identity on PLANE / PLUM_PILES terrain (:217-223)
+    float gvec[3];                // g.head(3): (0,0,9.8) on a plane
+    float normal[3];              // surfaceNormal
+};
+void vmc_assemble(const VmcConfig &c, const VmcInput &in, float G[144], float a[12], float CI[12 * 24], float b[24]);
+int vmc_solve(const VmcConfig &c, const VmcInput &in, float force[12], double xout[12], QpStats *st);
+
+// ---------------------------------------------------------------------------
 // MPC front-end.  qr_oracle_frontend.cpp
 // in[64] = des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd, basePosition[3], yawCurrent,
 //          quat_wxyz[4], footPosWorld[12] (leg major), footTargetWorld[12], contacts[4], phaseInFullCycle[4],

@@ -15,6 +15,8 @@ namespace qrgpu {
 #define QRGPU_ST_MPC_NOTSPD_D   0x8
 #define QRGPU_ST_WBC_MAXITER_D  0x10
 #define QRGPU_ST_WBC_INFEAS_D   0x20
+#define QRGPU_ST_VMC_MAXITER_D  0x40
+#define QRGPU_ST_VMC_INFEAS_D   0x80
 
 // XCD-aware robot index.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8
 // share an XCD) and each XCD has its own L2.  The SoA inputs put 32 consecutive robots in one 128-B line, so with
@@ -46,6 +48,19 @@ struct MpcLaunch {
     // the robot cost this time (clock64 ticks >> 12, saturated) for qr_lpt_order_kernel.  Either may be null.
     const int *order;
     int *cost;
+};
+
+// Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.
+struct VmcType {
+    float mass;
+    float inertia[9];          // robot->totalInertia, Eigen column-major
+    float acc_weight[6];
+    float reg_weight, friction, fmin_ratio, fmax_ratio;
+    float hip_l, upper_l, lower_l;
+};
+struct VmcLaunch {
+    VmcType type[QR_MAX_TYPES];
+    int n;
 };
 
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).

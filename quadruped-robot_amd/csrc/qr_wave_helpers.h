@@ -55,4 +55,24 @@ __device__ __forceinline__ int first_lane(bool pred)
 }
 
 
+// Column j of the analytic leg Jacobian (AnalyticalLegJacobian, quadruped/src/robots/qr_robot.cpp:148-172) in fp32.
+__device__ __forceinline__ void leg_jacobian_column(int j, float t0, float t1, float t2, float sh, float lu, float ll, float &J0, float &J1, float &J2)
+{
+    const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
+    const float tEff = t1 + t2 / 2;
+    if (j == 0) {
+        J0 = 0;
+        J1 = -sh * sinf(t0) + lEff * cosf(t0) * cosf(tEff);
+        J2 = sh * cosf(t0) + lEff * sinf(t0) * cosf(tEff);
+    } else if (j == 1) {
+        J0 = -lEff * cosf(tEff);
+        J1 = -lEff * sinf(t0) * sinf(tEff);
+        J2 = lEff * sinf(tEff) * cosf(t0);
+    } else {
+        J0 = ll * lu * sinf(t2) * sinf(tEff) / lEff - lEff * cosf(tEff) / 2;
+        J1 = -ll * lu * sinf(t0) * sinf(t2) * cosf(tEff) / lEff - lEff * sinf(t0) * sinf(tEff) / 2;
+        J2 = ll * lu * sinf(t2) * cosf(t0) * cosf(tEff) / lEff + lEff * sinf(tEff) * cosf(t0) / 2;
+    }
+}
+
 }  // namespace qrgpu

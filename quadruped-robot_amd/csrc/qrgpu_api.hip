@@ -23,6 +23,7 @@ extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const f
                                                  float *, int *, float *, float *, float *, int, long long *);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
 __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
@@ -38,6 +39,8 @@ struct qrgpu_ctx {
     MpcLaunch mpc{};
     bool mpc_ready[QR_MAX_TYPES] = {false, false, false, false};
     bool wbc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    VmcLaunch vmc{};
+    bool vmc_ready[QR_MAX_TYPES] = {false, false, false, false};
     WbcConst wbc_host[QR_MAX_TYPES];
     WbcConst *d_wbc = nullptr;
     bool wbc_dirty = true;
@@ -386,6 +389,46 @@ int qrgpu_fb_debug_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float 
     return launch_wbc(c, n, d_type_id, d_fb_state, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, 0, 0);
 }
 
+void qrgpu_vmc_desc_default(qrgpu_vmc_desc *d)
+{
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    d->mass = 13.f;
+    d->inertia[0] = 0.24f; d->inertia[4] = 0.80f; d->inertia[8] = 1.0f;
+    const float w[6] = {1.f, 1.f, 1.f, 10.f, 10.f, 1.f};
+    memcpy(d->acc_weight, w, sizeof(w));
+    d->reg_weight = 1e-4f; d->friction = 0.5f; d->fmin_ratio = 0.01f; d->fmax_ratio = 10.f;
+    d->hip_l = 0.08505f; d->upper_l = 0.2f; d->lower_l = 0.2f;
+}
+
+int qrgpu_vmc_setup(qrgpu_ctx *c, int type_id, const qrgpu_vmc_desc *d)
+{
+    if (!c || !d || type_id < 0 || type_id >= QR_MAX_TYPES) return QRGPU_ERR_BAD_ARG;
+    if (!(d->mass > 0.f)) return QRGPU_ERR_BAD_ARG;
+    VmcType &t = c->vmc.type[type_id];
+    t.mass = d->mass;
+    memcpy(t.inertia, d->inertia, sizeof(t.inertia));
+    memcpy(t.acc_weight, d->acc_weight, sizeof(t.acc_weight));
+    t.reg_weight = d->reg_weight; t.friction = d->friction; t.fmin_ratio = d->fmin_ratio; t.fmax_ratio = d->fmax_ratio;
+    t.hip_l = d->hip_l; t.upper_l = d->upper_l; t.lower_l = d->lower_l;
+    c->vmc_ready[type_id] = true;
+    return QRGPU_OK;
+}
+
+int qrgpu_vmc_force_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q, float *d_force, float *d_tau,
+                          int *d_status)
+{
+    if (!c || n <= 0 || n > c->max_batch || !d_vmc_in || !d_force) return QRGPU_ERR_BAD_ARG;
+    if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
+    if (!c->vmc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    HIPCHK(c, hipSetDevice(c->device));
+    VmcLaunch P = c->vmc;
+    P.n = n;
+    hipLaunchKernelGGL(qr_vmc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, P, d_type_id, d_vmc_in, d_q, d_force, d_tau, d_status);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
 int qrgpu_mpc_frontend_batch(qrgpu_ctx *c, int n, int num_horizon_l, float dt_ctrl, float dt_mpc, const float *d_fe_in, float *d_fe_state,
                              float *d_traj, float *d_gait, float *d_wbc_cmd, int *d_mpc_updated)
 {
@@ -469,6 +512,34 @@ int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const fl
     memcpy(tau_out, out, 48);
     if (qdes_out) memcpy(qdes_out, out + 12, 48);
     if (qddes_out) memcpy(qddes_out, out + 24, 48);
+    if (status) *status = st;
+    return QRGPU_OK;
+}
+
+int qrgpu_vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const float q[12], float force_out[12], float tau_out[12], int *status)
+{
+    if (!c || !vmc_in || !force_out) return QRGPU_ERR_BAD_ARG;
+    if (tau_out && !q) return QRGPU_ERR_BAD_ARG;
+    if (type_id < 0 || type_id >= QR_MAX_TYPES || !c->vmc_ready[type_id]) return QRGPU_ERR_NOT_SETUP;
+    float in[37 + 12];
+    memcpy(in, vmc_in, 37 * 4);
+    if (q) memcpy(in + 37, q, 48);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_in1, in, sizeof(in), hipMemcpyHostToDevice, c->stream));
+    int *d_type = nullptr;
+    int tid_host = type_id;
+    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
+    VmcLaunch P = c->vmc;
+    P.n = 1;
+    hipLaunchKernelGGL(qr_vmc_kernel, dim3(8), dim3(64), 0, c->stream, P, d_type, c->d_in1, q ? c->d_in1 + 37 : nullptr, c->d_out1,
+                       (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1);
+    HIPCHK(c, hipGetLastError());
+    float out[24]; int st = 0;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(force_out, out, 48);
+    if (q && tau_out) memcpy(tau_out, out + 12, 48);
     if (status) *status = st;
     return QRGPU_OK;
 }

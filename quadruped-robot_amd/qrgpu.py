@@ -40,6 +40,12 @@ class model_desc_struct(C.Structure):
                 ("kp_foot", C.c_float), ("kd_foot", C.c_float), ("weight_fb", C.c_float), ("weight_fr", C.c_float), ("mu", C.c_float)]
 
 
+class vmc_desc_struct(C.Structure):
+    _fields_ = [("mass", C.c_float), ("inertia", C.c_float * 9), ("acc_weight", C.c_float * 6), ("reg_weight", C.c_float),
+                ("friction", C.c_float), ("fmin_ratio", C.c_float), ("fmax_ratio", C.c_float),
+                ("hip_l", C.c_float), ("upper_l", C.c_float), ("lower_l", C.c_float)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libqrgpu.so")
 
@@ -48,7 +54,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
-           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule"]
+           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1"]
 
 
 def load_library():
@@ -74,6 +80,10 @@ def load_library():
     lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 10
     lib.qrgpu_mpc_assemble_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_vmc_desc_default.argtypes = [C.POINTER(vmc_desc_struct)]; lib.qrgpu_vmc_desc_default.restype = None
+    lib.qrgpu_vmc_setup.argtypes = [vp, ip, C.POINTER(vmc_desc_struct)]
+    lib.qrgpu_vmc_force_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_vmc_force1.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(ip)]
     lib.qrgpu_mpc_frontend_batch.argtypes = [vp, ip, ip, C.c_float, C.c_float] + [vp] * 6
     lib.qrgpu_fb_debug_batch.argtypes = [vp, ip, vp, vp, vp]
     lib.qrgpu_mpc_solve1.argtypes = [vp, ip] + [fp] * 9 + [C.POINTER(C.c_double), fp, C.POINTER(ip)]
@@ -209,6 +219,28 @@ class Context:
     def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None):
         self._chk(self._lib.qrgpu_tick_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(fb_state),
                                              _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(status)))
+
+    def vmc_setup_packed(self, type_id, cfg20, geom3):
+        """cfg20 = workload.vmc_cfg(): mass, inertia[9], acc_weight[6], reg_weight, friction, fmin_ratio, fmax_ratio; geom3 = hip/upper/lower length."""
+        d = vmc_desc_struct()
+        cfg20 = np.asarray(cfg20, np.float32)
+        d.mass = float(cfg20[0])
+        for i in range(9): d.inertia[i] = float(cfg20[1 + i])
+        for i in range(6): d.acc_weight[i] = float(cfg20[10 + i])
+        d.reg_weight, d.friction, d.fmin_ratio, d.fmax_ratio = (float(v) for v in cfg20[16:20])
+        d.hip_l, d.upper_l, d.lower_l = (float(v) for v in geom3[:3])
+        self._chk(self._lib.qrgpu_vmc_setup(self._h, type_id, C.byref(d)))
+
+    def vmc_force_batch(self, n, vmc_in, q, force, tau=None, status=None, type_id=None):
+        """ComputeContactForce (+ MapContactForceToJointTorques) of n robots: qr_qp_torque_optimizer.cpp:190-301."""
+        self._chk(self._lib.qrgpu_vmc_force_batch(self._h, n, _dp(type_id), _dp(vmc_in), _dp(q), _dp(force), _dp(tau), _dp(status)))
+
+    def vmc_force1(self, vmc_in, q=None, type_id=0):
+        a = np.ascontiguousarray(vmc_in, np.float32); qa = np.ascontiguousarray(q, np.float32) if q is not None else None
+        f = np.zeros(12, np.float32); tau = np.zeros(12, np.float32); st = C.c_int(0)
+        self._chk(self._lib.qrgpu_vmc_force1(self._h, type_id, _fp(a), _fp(qa) if qa is not None else None, _fp(f),
+                                             _fp(tau) if qa is not None else None, C.byref(st)))
+        return f, (tau if qa is not None else None), st.value
 
     def mpc_frontend_batch(self, n, fe_in, fe_state, traj, gait, wbc_cmd=None, mpc_updated=None, num_horizon_l=2, dt_ctrl=0.002, dt_mpc=0.06):
         """SetupCommand + Run + UpdateMPC (without the solve) of n robots: qr_mpc_stance_leg_controller.cpp:158-382."""

@@ -228,3 +228,56 @@ def make_frontend_batch(n, seed=0xFE, tick=0):
     st[:, 6] = fe[:, 0]
     st[:, 7] = tick + rng.integers(0, 120, n)                          # both sides of the <50 / %15 cadence
     return fe, st
+
+
+def vmc_cfg(robot="a1", acc_weight=(1., 1., 1., 10., 10., 1.), reg_weight=1e-4, friction=0.5, fmin_ratio=0.01, fmax_ratio=10.0):
+    """Packed force-balance QP parameters (qrgpu_vmc_setup): mass, total_inertia[9] (Eigen column-major map of the YAML list),
+    acc_weight[6] (stance_leg_controller.yaml), regWeight, frictionCoef, fMinRatio, fMaxRatio (qr_qp_torque_optimizer.h:144-153)."""
+    r = ROBOTS[robot]
+    I = np.diag(np.asarray(r["inertia"], f32)).reshape(-1, order="F")
+    return np.array([r["mass"], *I, *acc_weight, reg_weight, friction, fmin_ratio, fmax_ratio], dtype=f32)
+
+
+def make_vmc_batch(n, robot="a1", seed=0xB2, sloped=0.0, excite=1.0):
+    """Synthetic per-tick inputs of the force-balance QP, AoS [n][37] (layout: include/qrgpu.h vmc_in) plus joint angles [n][12].
+
+    Stance patterns: all four, trot pairs, three legs and a single leg; desired accelerations up to `excite` x (6 m/s^2, 20 rad/s^2)
+    so that friction and force-window rows bind on part of the batch.  `sloped` > 0 gives a fraction of robots a pitched control frame
+    (Rcb != I, tilted normal and gravity) as the non-PLANE terrain branch builds it."""
+    rng = np.random.default_rng(seed)
+    r = ROBOTS[robot]
+    q = np.tile(np.array([0.0, 0.9, -1.8], f32), (n, 4)) + 0.25 * rng.standard_normal((n, 12)).astype(f32)
+    vin = np.zeros((n, 37), f32)
+    hip_off = np.array([[0.1805, -0.047, 0], [0.1805, 0.047, 0], [-0.1805, -0.047, 0], [-0.1805, 0.047, 0]], f32)
+    # foot positions in the base frame from the leg kinematics (qr_robot.cpp:127-146)
+    for leg in range(4):
+        tab, thip, tknee = q[:, 3 * leg], q[:, 3 * leg + 1], q[:, 3 * leg + 2]
+        sh = r["hip_l"] * (1.0 if leg % 2 == 1 else -1.0)
+        ld = np.sqrt(r["upper_l"] ** 2 + r["lower_l"] ** 2 + 2 * r["upper_l"] * r["lower_l"] * np.cos(tknee))
+        eff = thip + tknee / 2
+        ox, oz, oy = -ld * np.sin(eff), -ld * np.cos(eff), sh
+        vin[:, 3 * leg + 0] = ox + hip_off[leg, 0]
+        vin[:, 3 * leg + 1] = np.cos(tab) * oy - np.sin(tab) * oz + hip_off[leg, 1]
+        vin[:, 3 * leg + 2] = np.sin(tab) * oy + np.cos(tab) * oz + hip_off[leg, 2]
+    scale = np.array([6, 6, 6, 20, 20, 20], f32) * excite
+    vin[:, 12:18] = scale * rng.uniform(-1, 1, (n, 6)).astype(f32)
+    pat = rng.integers(0, 10, n)
+    contacts = np.ones((n, 4), f32)
+    contacts[pat == 0] = (1, 0, 0, 1); contacts[pat == 1] = (0, 1, 1, 0)
+    contacts[pat == 2] = (1, 0, 0, 1); contacts[pat == 3] = (0, 1, 1, 0)
+    contacts[pat == 4] = (0, 1, 1, 1); contacts[pat == 5] = (1, 1, 0, 1)
+    contacts[pat == 6] = (1, 0, 0, 0)
+    vin[:, 18:22] = contacts
+    vin[:, 22:31] = np.eye(3, dtype=f32).reshape(-1)
+    vin[:, 31:34] = (0, 0, 9.8)
+    vin[:, 34:37] = (0, 0, 1)
+    ns = int(sloped * n)
+    if ns:
+        pitch = rng.uniform(-0.4, 0.4, ns)
+        for i in range(ns):
+            c, s = np.cos(pitch[i]), np.sin(pitch[i])
+            Rc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], f32)              # control frame pitched about y
+            vin[i, 22:31] = Rc.T.reshape(-1)
+            vin[i, 31:34] = Rc.T @ np.array([0, 0, 9.8], f32)
+            vin[i, 34:37] = (-s, 0, c)
+    return vin, q

@@ -107,6 +107,20 @@ def qp_cases():
     return rows
 
 
+def vmc_golden():
+    """Force-balance QP: fp32 data from our assembly, x from the reference's QuadProg++ called as qr_qp_torque_optimizer.cpp:242-276 does."""
+    cfg = W.vmc_cfg("a1"); geom = W.model_desc("a1")[:3]
+    vin, q = W.make_vmc_batch(48, sloped=0.25, seed=3003)
+    Gs, As, xs, infs = [], [], [], []
+    for i in range(48):
+        G, a, CI, b = O.vmc_assemble(cfg, vin[i])
+        x, f = O.ref_quadprog(G.T.astype(np.float64), -a.astype(np.float64), np.zeros((12, 0)), np.zeros(0), CI.astype(np.float64), -b.astype(np.float64))
+        Gs.append(G); As.append(a); xs.append(x); infs.append(not np.isfinite(f))
+    np.savez_compressed(os.path.join(OUT, "vmc_golden.npz"), cfg=cfg, geom=geom, vin=vin, q=q, G=np.array(Gs), a=np.array(As),
+                        x_quadprog=np.array(xs), quadprog_inf=np.array(infs))
+    print("vmc_golden.npz: 48 cases, %d with QuadProg++ returning +inf" % int(np.sum(infs)))
+
+
 def save(name, rows):
     flat = {"count": np.array([len(rows)])}
     for i, r in enumerate(rows):
@@ -120,4 +134,5 @@ if __name__ == "__main__":
     assert O.ref() is not None, "oracle/_ref is required to generate fixtures"
     save("mpc_golden.npz", mpc_cases())
     save("wbc_golden.npz", wbc_cases())
+    vmc_golden()
     save("qp_golden.npz", qp_cases())

@@ -47,5 +47,23 @@ int main()
     printf("status %d\ntau", st);
     for (int i = 0; i < 12; ++i) printf(" %.9g", tau[i]);
     printf("\n");
+
+    // force-balance controller: TorqueStanceLegController::GetAction -> ComputeContactForce (qr_torque_stance_leg_controller.cpp:500)
+    float vin[37];
+    bool have_vmc = true;
+    for (float &x : vin) if (scanf("%f", &x) != 1) { have_vmc = false; break; }
+    if (have_vmc) {
+        qrgpu_vmc_desc vd; qrgpu_vmc_desc_default(&vd);
+        if (qrgpu_adapters::VmcSetup(vd) != 0) return 4;
+        for (int i = 0; i < 12; ++i) robot.footBase.m[i] = vin[i];
+        float acc[6]; bool ct[4];
+        for (int i = 0; i < 6; ++i) acc[i] = vin[12 + i];
+        for (int i = 0; i < 4; ++i) ct[i] = vin[18 + i] != 0.f;
+        Mat34f F;
+        int vst = qrgpu_adapters::VmcContactForce(&robot, vin + 22, vin + 31, vin + 34, acc, ct, F);
+        printf("vmcstatus %d\nvmcforce", vst);
+        for (int i = 0; i < 12; ++i) printf(" %.9g", F.m[i]);
+        printf("\n");
+    }
     return 0;
 }

@@ -7,7 +7,7 @@
 template <typename T> struct Vec3 { T v[3]; T &operator[](int i) { return v[i]; } const T &operator[](int i) const { return v[i]; } };
 template <typename T> struct Quat { T v[4]; T &operator[](int i) { return v[i]; } const T &operator[](int i) const { return v[i]; } };   // (w,x,y,z), qr_cpptypes.h:83-84
 template <typename T> struct Vec4b { bool v[4]; bool operator[](int i) const { return v[i]; } };
-struct Mat34f { float m[12]; float *data() { return m; } float &operator()(int r, int c) { return m[3 * c + r]; } };                  // column-major like Eigen
+struct Mat34f { float m[12]; float *data() { return m; } float &operator()(int r, int c) { return m[3 * c + r]; } float operator()(int r, int c) const { return m[3 * c + r]; } };                  // column-major like Eigen
 template <typename T> struct Vec12 { T v[12]; T &operator[](int i) { return v[i]; } const T &operator[](int i) const { return v[i]; } };
 
 struct qrWbcCtrlData {          // quadruped/include/quadruped/controllers/qr_state_dataflow.h:133-192
@@ -25,4 +25,6 @@ struct qrRobotStub {            // the getters qrWbcLocomotionController::Update
     Vec3<float> GetBaseRollPitchYawRate() const { return rpyrate; }
     Vec12<float> GetMotorAngles() const { return q; }
     Vec12<float> GetMotorVelocities() const { return dq; }
+    Mat34f footBase;
+    Mat34f GetFootPositionsInBaseFrame() const { return footBase; }
 };

@@ -29,12 +29,14 @@ def test_adapters_drive_the_gpu_path(pkg, oracle):
     exe = _compile(pkg)
     b = pkg.make_batch(3, 10, "a1", seed=17)
     cfg = pkg.mpc_cfg("a1"); md = pkg.model_desc("a1")
+    vin, vq = pkg.workload.make_vmc_batch(3, seed=23)
     for i in range(3):
         vals = [10] + list(cfg) + list(b["mpc_state"][i]) + list(b["traj"][i]) + list(b["gait"][i]) + list(b["fb_state"][i]) + list(b["wbc_cmd"][i])
+        vals += list(vin[i])
         inp = " ".join(repr(float(v)) if not isinstance(v, int) else str(v) for v in vals)
         out = subprocess.run([exe], input=inp.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert out.returncode == 0, out.stderr.decode()
-        lines = {l.split()[0]: l.split()[1:] for l in out.stdout.decode().splitlines() if l and l.split()[0] in ("before", "force", "tau", "status")}
+        lines = {l.split()[0]: l.split()[1:] for l in out.stdout.decode().splitlines() if l and l.split()[0] in ("before", "force", "tau", "status", "vmcforce", "vmcstatus")}
         assert float(lines["before"][0]) == 0.0 and int(lines["status"][0]) == 0
         f = np.array([float(x) for x in lines["force"]]); tau = np.array([float(x) for x in lines["tau"]])
         u, st, rc = oracle.mpc_solve(cfg, 10, b["mpc_state"][i], b["traj"][i], b["gait"][i])
@@ -42,3 +44,8 @@ def test_adapters_drive_the_gpu_path(pkg, oracle):
         cmd = b["wbc_cmd"][i].copy(); cmd[51:63] = u[:12].astype(np.float32)
         w = oracle.wbc_run(md, b["fb_state"][i].astype(np.float64), cmd.astype(np.float64), dtype=np.float64)
         assert np.all(np.abs(tau - w["tau"]) <= 1e-5 * np.maximum(1.0, np.abs(w["tau"])))
+        # force-balance adapter: ComputeContactForce through qrgpu_vmc_force1
+        fv = np.array([float(x) for x in lines["vmcforce"]])
+        fo, _, _, _, rc = oracle.vmc_solve(pkg.workload.vmc_cfg("a1"), md[:3], vin[i], vq[i])
+        assert np.abs(fv - fo).max() <= 1e-5 * max(1.0, np.abs(fo).max())
+        assert bool(int(lines["vmcstatus"][0]) & 0x80) == (rc == 1)
