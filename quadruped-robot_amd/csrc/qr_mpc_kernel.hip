@@ -376,6 +376,18 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         qcap = qc < QR_QH ? qc : QR_QH;
         if (qcap > ns) qcap = ns;
     }
+    // Four-wave path: what is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the
+    // iteration that added it), so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to
+    // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
+    int qW = 0;
+    double *Wc = nullptr;
+    if constexpr (MULTI) {
+        const int qs = qcap < 64 ? qcap : 64;
+        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs);
+        Wc = Sinv + tri(qs);
+        if (rem > 0 && ns > 0) qW = (int)(rem / ns);
+        if (qW > 64) qW = 64;
+    }
     int st = 0;
     if (npairs > MAXB * QR_MPC_THREADS) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
 
@@ -531,7 +543,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // and their positions (posk).  Per-lane gathers use ds_bpermute (__shfl), uniform ones v_readlane.
     // =====================================================================================================
     if constexpr (MULTI) {
-        const int wv = tid >> 6;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the partitioned loops below run on the SALU
         const bool own = lane < nls;
         const int kme = own ? lane : 0;
         const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
@@ -571,6 +583,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         const int maxit = 40 * nls + 100;
         bool done = (nls == 0);
         bool after_drop = false;
+        bool fastz = qW > 0;
         long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = dbgT ? clock64() : 0;
 #ifdef QR_GI_STAMPS      // sub-phase cycle accounting of the loop below (build.py: QRGPU_GI_STAMPS=1); costs ~15 % when compiled in
 #define QM_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
@@ -680,31 +693,58 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
                 QM_STAMP(4);
                 if (have_z) {
-                    // y_k = sum over the active rows of my leg-step of c_row * r(position)
-                    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-#pragma unroll
-                    for (int tq = 0; tq < 6; ++tq) {
-                        const int ps = (int)((posk >> (8 * tq)) & 0x3full);
-                        const double rr = __shfl(rq, ps, 64);
-                        if ((amask >> tq) & 1u) {
-                            double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
-                            y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
-                        }
-                    }
-                    // partial z over every 4th active leg-step
-                    unsigned long long km = __ballot(own && amask != 0);
                     double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-                    int idx = 0;
-                    while (km) {
-                        const int kc = (int)__builtin_ctzll(km);
-                        km &= km - 1;
-                        if (((idx++) & 3) != wv) continue;
-                        if (own) {
-                            Blk B; load_block(Mb, kme, kc, B);
+                    if (fastz) {
+                        // partial W_A r over the positions i = wv (mod 4), two per trip
+                        const double *wk = Wc + 3 * kme;
+                        int i = wv;
+                        for (; i + 4 < q; i += 8) {
+                            const double ra = readlane_d(rq, i), rb = readlane_d(rq, i + 4);
+                            if (own) {
+                                const double *wa = wk + i * ns, *wb = wk + (i + 4) * ns;
+                                const double a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
+                                p0 += a0 * ra + b0 * rb; p1 += a1 * ra + b1 * rb; p2 += a2 * ra + b2 * rb;
+                            }
+                        }
+                        if (i < q) {
+                            const double ra = readlane_d(rq, i);
+                            if (own) { const double *wa = wk + i * ns; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
+                        }
+                    } else {
+                        // y_k = sum over the active rows of my leg-step of c_row * r(position)
+                        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+                        for (int tq = 0; tq < 6; ++tq) {
+                            const int ps = (int)((posk >> (8 * tq)) & 0x3full);
+                            const double rr = __shfl(rq, ps, 64);
+                            if ((amask >> tq) & 1u) {
+                                double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
+                                y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
+                            }
+                        }
+                        // partial z over every 4th active leg-step (rank among the active ones = wv mod 4, found with mbcnt so that every
+                        // wave scans only its own bits), two block
+                        // columns per trip so that the second LDS load is in flight while the first is used
+                        const bool hasrow = own && amask != 0;
+                        const unsigned long long kall = __ballot(hasrow);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(kall >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kall, 0u));
+                        unsigned long long km = __ballot(hasrow && (rank & 3) == wv);
+                        while (km) {
+                            const int kc = (int)__builtin_ctzll(km);
+                            km &= km - 1;
+                            int kc2 = -1;
+                            if (km) { kc2 = (int)__builtin_ctzll(km); km &= km - 1; }
+                            const int kr = kc2 >= 0 ? kc2 : kc;
+                            const double sc = kc2 >= 0 ? 1.0 : 0.0;
+                            Blk B, B2;
+                            if (own) { load_block(Mb, kme, kc, B); load_block(Mb, kme, kr, B2); }
                             const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
-                            p0 += B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2;
-                            p1 += B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2;
-                            p2 += B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2;
+                            const double s0 = sc * readlane_d(y0, kr), s1 = sc * readlane_d(y1, kr), s2 = sc * readlane_d(y2, kr);
+                            if (own) {
+                                p0 += (B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2) + (B2.m[0] * s0 + B2.m[1] * s1 + B2.m[2] * s2);
+                                p1 += (B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2) + (B2.m[3] * s0 + B2.m[4] * s1 + B2.m[5] * s2);
+                                p2 += (B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2) + (B2.m[6] * s0 + B2.m[7] * s1 + B2.m[8] * s2);
+                            }
                         }
                     }
                     if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
@@ -721,6 +761,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 QM_STAMP(5);
                 if (full) {
                     // full step: the row joined the working set at position q (S^-1 already updated above)
+                    if (fastz) {
+                        if (q < qW) { if (wv == 0 && own) { double *wq = Wc + q * ns + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }   // visible after the next barrier
+                        else fastz = false;
+                    }
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
                     if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); }
                     xmask = 0;
@@ -747,6 +791,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (wv == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
                         __syncthreads();
                         if (wv == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
+                        if (fastz && wv == 0 && own) { const double *wl_ = Wc + last * ns + 3 * kme; double *wd_ = Wc + l * ns + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
                         const double ulast = readlane_d(uq, last);
                         if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
                     }

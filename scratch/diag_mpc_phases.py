@@ -31,3 +31,9 @@ nm2 = ["scan+select(+bookkeeping)", "w,delta,d", "r loop+B2", "dr,t1,sp,t2", "S^
 for k, nm in enumerate(nm2):
     print("  GI %-12s per-iter mean %8.0f   share %.2f" % (nm, (sub[:, k] / np.maximum(it, 1)).mean(), sub[:, k].sum() / d[:, 4].sum()))
 print("final q mean %.1f max %d" % (buf[:, 14].mean(), buf[:, 14].max()))
+j = int(np.argmax(it))
+print("worst robot %d: iters %d, final q %d, nls %d, GI ticks %d (%.0f / iter), sweep %d" % (j, it[j], buf[j, 14], buf[j, 7] // 3, d[j, 4], d[j, 4] / it[j], d[j, 2]))
+for k, nm in enumerate(nm2):
+    print("  worst GI %-28s per-iter %8.0f" % (nm, sub[j, k] / it[j]))
+order = np.argsort(-tot)[:8]
+print("top-8 totals:", [(int(o), int(tot[o]), int(it[o]), int(buf[o, 7] // 3)) for o in order])
