@@ -48,6 +48,13 @@ struct MpcLaunch {
     // the robot cost this time (clock64 ticks >> 12, saturated) for qr_lpt_order_kernel.  Either may be null.
     const int *order;
     int *cost;
+    // Rescue pass (DESIGN.md "working-set capacity"): a four-wave solve whose working set outgrows its 64 lanes / its LDS appends the
+    // robot to rescue_list (rescue_count[parity] entries); the single-wave variant then re-solves exactly those robots with the
+    // whole CU's LDS (rescue_mode = 1: workgroup b takes list entry b).  The main launch zeroes the other parity's counter.
+    int *rescue_count;
+    int *rescue_list;
+    int rescue_parity;
+    int rescue_mode;
 };
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.
@@ -64,14 +71,13 @@ struct VmcLaunch {
 };
 
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
-// h <= 11 runs the four-wave active set (exchange buffers xz[4][NV], xr[4][64]); larger horizons the single-wave one
-// (staging wl, yl, rl and the sAct / sPos tables).
-__host__ __device__ static inline bool mpc_multi_wave(int h) { return 4 * h <= 44; }
-__host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h)
+// The four-wave active set needs the exchange buffers xz[4][NV], xr[4][64]; the single-wave one (h > 11 by default, and the
+// rescue pass) the staging arrays wl, yl, rl and the sAct / sPos tables.
+__host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h, bool multi)
 {
     const size_t NV = 12 * (size_t)h, NL = 4 * (size_t)h;
     size_t b;
-    if (mpc_multi_wave(h)) b = 8 * (NV + 4 * NV + 4 * 64 + NL);       // gl xz xr fmk
+    if (multi) b = 8 * (NV + 4 * NV + 4 * 64 + NL);       // gl xz xr fmk
     else b = 8 * (3 * NV + QR_QH + NL);                                // gl wl yl rl fmk
     b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);                // sT sU sSt sTraj sGait sV
     b += 4 * (NL + QR_QH);                                             // sLs sAct

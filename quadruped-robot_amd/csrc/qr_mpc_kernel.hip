@@ -218,7 +218,7 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
     }
 }
 
-template <int MAXB>
+template <int MAXB, bool MULTI>
 __global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
 void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
                    const float *__restrict__ g_traj, const float *__restrict__ g_gait, const float *__restrict__ g_q,
@@ -229,9 +229,19 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n = P.n;
-    const int slot = xcd_robot_index(blockIdx.x, n);
-    if (slot < 0) return;
-    const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+    int rid;
+    if (P.rescue_mode) {
+        // rescue pass: workgroup b re-solves the b-th robot the main pass could not hold
+        int cnt = P.rescue_count[P.rescue_parity];
+        cnt = cnt < n ? cnt : n;
+        if ((int)blockIdx.x >= cnt) return;
+        rid = P.rescue_list[blockIdx.x];
+    } else {
+        const int slot = xcd_robot_index(blockIdx.x, n);
+        if (slot < 0) return;
+        rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+        if (P.rescue_count && blockIdx.x == 0 && tid == 0) P.rescue_count[P.rescue_parity ^ 1] = 0;     // the next call's counter
+    }
     const long long t_begin = P.cost ? clock64() : 0;
     const MpcType &C = P.type[type_id ? type_id[rid] : 0];
     const int h = P.horizon;
@@ -239,7 +249,6 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 
     // ---------------- LDS carve (must match mpc_lds_fixed_bytes) ----------------
     extern __shared__ double smem[];
-    constexpr bool MULTI = (MAXB <= 4);   // four-wave active set (h <= 11), see mpc_multi_wave()
     double *gl = smem;                 // [NV] gradient (free variables, leg-step major)
     double *wl = gl + NV;              // single-wave: [NV] staging of w          | four-wave: xz[4][NV] partial x / z exchange
     double *yl = wl + NV;              // single-wave: [NV] staging of y = N r
@@ -258,7 +267,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> position in sAct, or -1
     int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [4]
     // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
-    double *Mb = smem + (int)(mpc_lds_fixed_bytes(h) / 8);   // block-packed M; the sweep panels live here first
+    double *Mb = smem + (int)(mpc_lds_fixed_bytes(h, MULTI) / 8);   // block-packed M; the sweep panels live here first
 
 #define QR_TS(i) do { if (dbgT && tid == 0) dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
     QR_TS(0);
@@ -813,6 +822,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         wave_sync();
         mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
         if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+        if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
         if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
         QR_TS(6);
         if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
@@ -1078,10 +1088,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
 }
 
-template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,
-                                          int *, float *, float *, float *, int, long long *);
-template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *, float *,
-                                          int *, float *, float *, float *, int, long long *);
+#define QR_MPC_INST(MAXB, MULTI)                                                                                                      \
+    template __global__ void qr_mpc_kernel<MAXB, MULTI>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, \
+                                                        float *, float *, int *, float *, float *, float *, int, long long *);
+QR_MPC_INST(4, true)
+QR_MPC_INST(4, false)
+QR_MPC_INST(9, true)
+QR_MPC_INST(9, false)
 
 // Longest-processing-time-first dispatch order for the next launch.  A robot's solve time varies 10x with its active-set
 // iteration count, and with two resident workgroups per CU a long solve that starts late sets the kernel time.  Block

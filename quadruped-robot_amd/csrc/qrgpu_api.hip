@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -13,14 +14,17 @@
 #include "qr_device_types.h"
 
 namespace qrgpu {
-template <int MAXB>
+template <int MAXB, bool MULTI>
 __global__ void qr_mpc_kernel(MpcLaunch P, const int *type_id, const float *g_state, const float *g_traj, const float *g_gait,
                               const float *g_q, float *g_force, float *g_tau, int *g_status, float *dbgH, float *dbgG,
                               float *g_force_wbc, int force_stride, long long *dbgT);
-extern template __global__ void qr_mpc_kernel<4>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
-                                                 float *, int *, float *, float *, float *, int, long long *);
-extern template __global__ void qr_mpc_kernel<9>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, float *,
-                                                 float *, int *, float *, float *, float *, int, long long *);
+#define QR_MPC_DECL(MAXB, MULTI)                                                                                                             \
+    extern template __global__ void qr_mpc_kernel<MAXB, MULTI>(MpcLaunch, const int *, const float *, const float *, const float *,         \
+                                                               const float *, float *, float *, int *, float *, float *, float *, int, long long *);
+QR_MPC_DECL(4, true)
+QR_MPC_DECL(4, false)
+QR_MPC_DECL(9, true)
+QR_MPC_DECL(9, false)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
@@ -50,8 +54,11 @@ struct qrgpu_ctx {
     int *d_st1 = nullptr;
     int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
+    int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
+    int rescue_parity = 0;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
     bool lpt = true;
+    bool rescue = true;
     float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
     void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
@@ -73,11 +80,20 @@ struct qrgpu_ctx {
         }                                                                                    \
     } while (0)
 
+// h > 11: the single-wave active set (up to 96 active rows in one pass) is the default.  The four-wave variant + rescue pass is 33 %
+// faster when no working set exceeds 64 rows but pays a second, serial solve for every robot that does (5 % of the h = 16 bench
+// batch at SURVEY 8d's ranges: 2.2 ms against 1.5 ms per 1024 robots); QRGPU_H16_MULTI=1 selects it.
+static bool mpc_h16_single()
+{
+    static const bool v = [] { const char *e = getenv("QRGPU_H16_MULTI"); return !(e && e[0] == '1'); }();
+    return v;
+}
+
 static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h)
 {
     // Packed inverse Hessian for the all-stance worst case plus room for S^-1; two workgroups
     // per CU when that fits in half the LDS, otherwise the whole CU.
-    const size_t fixed = mpc_lds_fixed_bytes(h);
+    const size_t fixed = mpc_lds_fixed_bytes(h, 4 * h <= 44 || !mpc_h16_single());
     const size_t nmax = 12 * (size_t)h;
     const size_t mp = 8 * (nmax * (nmax + 1) / 2);
     const size_t want = fixed + mp + 8 * (size_t)(24 * 25 / 2);     // at least a 24-row S^-1 in the worst case
@@ -220,7 +236,8 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
     if (hipMalloc(&c->d_in1, in1 * sizeof(float)) != hipSuccess || hipMalloc(&c->d_out1, 64 * sizeof(float)) != hipSuccess ||
         hipMalloc(&c->d_st1, 4 * sizeof(int)) != hipSuccess || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
         hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess) {
+        hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
@@ -242,6 +259,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_cmd_tick) hipFree(c->d_cmd_tick);
     if (c->d_order) hipFree(c->d_order);
     if (c->d_cost) hipFree(c->d_cost);
+    if (c->d_rescue) hipFree(c->d_rescue);
     delete c;
 }
 
@@ -250,6 +268,12 @@ int qrgpu_set_lpt_schedule(qrgpu_ctx *c, int on)
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->lpt = on != 0;
     c->lpt_n = 0;
+    return QRGPU_OK;
+}
+int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->rescue = on != 0;
     return QRGPU_OK;
 }
 int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; return QRGPU_OK; }
@@ -316,22 +340,56 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.cost = lpt ? c->d_cost : nullptr;
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
-    static int configured_lds[2] = {0, 0};
-    if (configured_lds[small ? 0 : 1] < P.lds_bytes) {
-        if (small) HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
-        else HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
-        configured_lds[small ? 0 : 1] = P.lds_bytes;
+    // rescue pass for the four-wave variants (not for inspection launches or single-robot calls through the staging buffers)
+    const bool rescue = c->rescue && !dH && !(mpc_h16_single() && !small);
+    P.rescue_mode = 0;
+    P.rescue_count = rescue ? c->d_rescue : nullptr;
+    P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
+    P.rescue_parity = c->rescue_parity;
+    // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave> (QRGPU_H16_MULTI=1), 2 = <9, single-wave>
+    const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
+    static int configured_lds[3] = {0, 0, 0};
+    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true> : var == 1 ? (const void *)qr_mpc_kernel<9, true> : (const void *)qr_mpc_kernel<9, false>;
+    if (configured_lds[var] < P.lds_bytes) {
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
+        configured_lds[var] = P.lds_bytes;
     }
     {
         TimerScope ts(c, 0);
-        if (small)
-            hipLaunchKernelGGL(qr_mpc_kernel<4>, dim3(8 * ((n + 7) / 8)), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
-                               d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
+        const dim3 grid(8 * ((n + 7) / 8)), block(256);
+        long long *dbg = (long long *)c->d_dbg_cycles;
+        if (var == 0)
+            hipLaunchKernelGGL((qr_mpc_kernel<4, true>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
+        else if (var == 1)
+            hipLaunchKernelGGL((qr_mpc_kernel<9, true>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
         else
-            hipLaunchKernelGGL(qr_mpc_kernel<9>, dim3(8 * ((n + 7) / 8)), dim3(256), (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait,
-                               d_q, d_force, d_tau, d_status, dH, dG, d_force_wbc, 51, (long long *)c->d_dbg_cycles);
+            hipLaunchKernelGGL((qr_mpc_kernel<9, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
     }
     HIPCHK(c, hipGetLastError());
+    if (rescue) {
+        // re-solve the robots whose working set outgrew the four-wave path (normally none: the workgroups exit at once)
+        MpcLaunch R = P;
+        R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
+        R.lds_bytes = c->lds_per_cu;
+        const int rgrid = n < (small ? 64 : c->num_cu) ? n : (small ? 64 : c->num_cu);
+        static int configured_rescue[2] = {0, 0};
+        const void *rfn = small ? (const void *)qr_mpc_kernel<4, false> : (const void *)qr_mpc_kernel<9, false>;
+        if (configured_rescue[small ? 0 : 1] < R.lds_bytes) {
+            HIPCHK(c, hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
+            configured_rescue[small ? 0 : 1] = R.lds_bytes;
+        }
+        if (small)
+            hipLaunchKernelGGL((qr_mpc_kernel<4, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
+                               d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
+        else
+            hipLaunchKernelGGL((qr_mpc_kernel<9, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
+                               d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
+        HIPCHK(c, hipGetLastError());
+        c->rescue_parity ^= 1;
+    }
     if (lpt) {
         hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
         HIPCHK(c, hipGetLastError());

@@ -54,7 +54,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
-           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1"]
+           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass"]
 
 
 def load_library():
@@ -71,6 +71,7 @@ def load_library():
     lib.qrgpu_destroy.argtypes = [vp]; lib.qrgpu_destroy.restype = None
     lib.qrgpu_set_stream.argtypes = [vp, vp]
     lib.qrgpu_set_lpt_schedule.argtypes = [vp, ip]
+    lib.qrgpu_set_rescue_pass.argtypes = [vp, ip]
     lib.qrgpu_last_error.argtypes = [vp]; lib.qrgpu_last_error.restype = C.c_char_p
     lib.qrgpu_device_info.argtypes = [vp, C.c_char_p, ip, C.POINTER(ip)]
     lib.qrgpu_model_desc_default.argtypes = [C.POINTER(model_desc_struct)]; lib.qrgpu_model_desc_default.restype = None
@@ -256,6 +257,9 @@ class Context:
     def set_lpt_schedule(self, on=True):
         """Longest-first workgroup dispatch from the previous call's per-robot solve time (speed only)."""
         self._chk(self._lib.qrgpu_set_lpt_schedule(self._h, 1 if on else 0))
+
+    def set_rescue_pass(self, on=True):
+        self._chk(self._lib.qrgpu_set_rescue_pass(self._h, 1 if on else 0))
 
     def sync(self):
         self._chk(self._lib.qrgpu_sync(self._h))

@@ -139,3 +139,28 @@ def test_wave_helpers(gpu_ctx):
     assert np.all(out[64:128] == 64 * 65 / 2)
     assert np.all(out[128:192] == np.argmin(v))
     assert np.all(out[192:256] == v[17])
+
+
+def test_rescue_pass_large_working_sets(gpu_ctx, pkg, oracle):
+    """Working sets beyond the 64 rows of the four-wave kernel: flagged QRGPU_ST_MPC_OVERFLOW without the rescue pass, re-solved
+    by the single-wave variant (whole-CU LDS, up to 96 rows) with it.  Three-leg-stance robots (90 free unknowns) driven three times
+    beyond SURVEY 8d's ranges: up to 74 active rows."""
+    h = 10
+    G.setup_a1(gpu_ctx, pkg, h)
+    b = pkg.make_batch(96, h, "a1", seed=0xBEEF, excite=3.0, frac_all_stance=0.0, frac_three_leg=1.0)
+    gpu_ctx.set_rescue_pass(False)
+    try:
+        flagged = (G.run_mpc(gpu_ctx, pkg, b)["status"] & 0x4) != 0
+    finally:
+        gpu_ctx.set_rescue_pass(True)
+    out = G.run_mpc(gpu_ctx, pkg, b)
+    out2 = G.run_mpc(gpu_ctx, pkg, b)                     # second call: the ping-pong counters
+    assert flagged.sum() > 0, "the batch must exercise the overflow path"
+    assert flagged.sum() <= 64
+    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    assert np.array_equal(out["force"], out2["force"]) and np.array_equal(out["status"], out2["status"])
+    cfg = pkg.mpc_cfg("a1")
+    for i in np.where(flagged)[0]:
+        u, st, rc = oracle.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        assert rc == 0 and st["n_active"] > 40
+        assert np.abs(out["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max()), i
