@@ -55,6 +55,9 @@ struct MpcLaunch {
     int *rescue_list;
     int rescue_parity;
     int rescue_mode;
+    // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
+    const int *lpt_cost_in;
+    int *lpt_order_out;
 };
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.

@@ -218,6 +218,33 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
     }
 }
 
+// Longest-processing-time-first dispatch order for the next launch.  A robot's solve time varies 10x with its active-set
+// iteration count, and with two resident workgroups per CU a long solve that starts late sets the kernel time.  Block
+// dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
+// the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
+// leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
+__device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restrict__ cost, int *__restrict__ order, int *hist /* 256 ints of LDS */)
+{
+    const int chunk = (n + 7) >> 3;
+    const int lo = x * chunk;
+    const int hi = (lo + chunk < n) ? lo + chunk : n;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < 256; ++b) { const int c = hist[b]; hist[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 256) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
+}
+__global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
+{
+    __shared__ int hist[256];
+    lpt_order_chunk(blockIdx.x, n, cost, order, hist);
+}
+
 template <int MAXB, bool MULTI>
 __global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
 void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
@@ -231,6 +258,11 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int n = P.n;
     int rid;
     if (P.rescue_mode) {
+        if (P.lpt_order_out && blockIdx.x < 8) {       // the histogram borrows the head of the dynamic LDS before the solve carves it
+            extern __shared__ double smem_head[];
+            lpt_order_chunk(blockIdx.x, n, P.lpt_cost_in, P.lpt_order_out, (int *)smem_head);
+            __syncthreads();
+        }
         // rescue pass: workgroup b re-solves the b-th robot the main pass could not hold
         int cnt = P.rescue_count[P.rescue_parity];
         cnt = cnt < n ? cnt : n;
@@ -1095,29 +1127,6 @@ QR_MPC_INST(4, true)
 QR_MPC_INST(4, false)
 QR_MPC_INST(9, true)
 QR_MPC_INST(9, false)
-
-// Longest-processing-time-first dispatch order for the next launch.  A robot's solve time varies 10x with its active-set
-// iteration count, and with two resident workgroups per CU a long solve that starts late sets the kernel time.  Block
-// dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
-// the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
-// leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
-__global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
-{
-    __shared__ int hist[256];
-    const int chunk = (n + 7) >> 3;
-    const int lo = blockIdx.x * chunk;
-    const int hi = (lo + chunk < n) ? lo + chunk : n;
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < 256; ++b) { const int c = hist[b]; hist[b] = acc; acc += c; }
-    }
-    __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
-}
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64, 1)
 void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
-                   float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT)
+                   float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT,
+                   const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */)
 {
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
@@ -352,7 +353,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 
     // ---------------- load ----------------
     if (lane < 37) st[lane] = (real)g_state[(size_t)lane * n + rid];
-    if (g_tau) for (int i = lane; i < 67; i += 64) cm[i] = (real)g_cmd[(size_t)i * n + rid];
+    if (g_tau) for (int i = lane; i < 67; i += 64) cm[i] = (real)((g_fr && i >= 51 && i < 63) ? g_fr[(size_t)(i - 51) * n + rid] : g_cmd[(size_t)i * n + rid]);
     for (int e = lane; e < 324; e += 64) A[e] = 0.0;
     for (int e = lane; e < 216; e += 64) JcA[e] = 0.0;
     wsync();
@@ -815,7 +816,38 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         int *posi = sI + 32;       // constraint -> position or -1
         if (lane < 32) posi[lane] = -1;
         wsync();
+        // The six floating-base equalities enter together instead of one active-set iteration each: with S_e = N_e M N_e' (6 x 6),
+        // u_e = -S_e^-1 c_e, z = M N_e' u_e, S^-1 = S_e^-1, working set = {0..5}.  Same point the six equality iterations reach.
         int next_eq = 0;
+        {
+            if (lane < 36) {
+                const int a = lane / 6, b2 = lane - 6 * a;
+                real acc = 0.0;
+                for (int j = 0; j < nz; ++j) acc += Nq[a * 18 + j] * Minv(j) * Nq[b2 * 18 + j];
+                Sq[a * 18 + b2] = acc;
+            }
+            wsync();
+            real tr = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tr += Sq[a * 18 + a];
+            const real minpiv = spd_inverse<1>(lane, Sq, 18, 6, qd_);
+            if (!(minpiv > 1e-14 * tr)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; }      // dependent equalities
+            if (lane < 6) {
+                real acc = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < 6; ++b2) acc -= Sq[lane * 18 + b2] * qc0[b2];
+                qu_[lane] = acc; act[lane] = lane; posi[lane] = lane;
+            }
+            wsync();
+            if (lane < nz) {
+                real acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc += Nq[a * 18 + lane] * qu_[a];
+                qx[lane] = Minv(lane) * acc;
+            }
+            q = 6; next_eq = np_;
+            wsync();
+        }
         while (!fail) {
             int p;
             if (next_eq < np_) p = next_eq;

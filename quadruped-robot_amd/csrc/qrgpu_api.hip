@@ -31,7 +31,8 @@ __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in
 __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
-                              float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT);
+                              float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
+                              const float *g_fr);
 }
 using namespace qrgpu;
 
@@ -346,6 +347,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.rescue_count = rescue ? c->d_rescue : nullptr;
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
+    P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave> (QRGPU_H16_MULTI=1), 2 = <9, single-wave>
     const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
     static int configured_lds[3] = {0, 0, 0};
@@ -373,6 +375,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // re-solve the robots whose working set outgrew the four-wave path (normally none: the workgroups exit at once)
         MpcLaunch R = P;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
+        R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
         const int rgrid = n < (small ? 64 : c->num_cu) ? n : (small ? 64 : c->num_cu);
         static int configured_rescue[2] = {0, 0};
@@ -390,7 +393,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         c->rescue_parity ^= 1;
     }
-    if (lpt) {
+    if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
+    else if (lpt) {
         hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
         HIPCHK(c, hipGetLastError());
         c->lpt_n = n;
@@ -399,7 +403,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 }
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
-                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or)
+                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -410,7 +414,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     {
         TimerScope ts(c, 1);
         hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
-                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc);
+                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -507,12 +511,12 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     if (!c || !d_fb_state || !d_wbc_cmd || !d_tau || !d_prev_ori) return QRGPU_ERR_BAD_ARG;
     if (n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    // wbc_cmd copy whose Fr_des rows (51..62) the MPC kernel overwrites with its forces (wbcData.Fr_des = f, :408)
-    HIPCHK(c, hipMemcpyAsync(c->d_cmd_tick, d_wbc_cmd, sizeof(float) * 67 * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, d_force, d_tau, d_status,
-                        nullptr, nullptr, c->d_cmd_tick);
+    // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written
+    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, d_force ? d_force : c->d_cmd_tick, d_tau, d_status,
+                        nullptr, nullptr, nullptr);
     if (rc) return rc;
-    return launch_wbc(c, n, d_type_id, d_fb_state, c->d_cmd_tick, d_prev_ori, d_tau, nullptr, d_status, nullptr, 1, d_status ? 1 : 0);
+    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, nullptr, d_status, nullptr, 1, d_status ? 1 : 0,
+                      d_force ? d_force : c->d_cmd_tick);
 }
 
 int qrgpu_mpc_solve1(qrgpu_ctx *c, int type_id, const float p[3], const float v[3], const float quat[4], const float w[3],
