@@ -555,9 +555,60 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 
     QW_TS(3);
     // ---------------- K13 GetModelRes: A^-1 ----------------
-    for (int e = lane; e < 324; e += 64) Ai[e] = A[e];
-    wsync();
-    spd_inverse<6>(lane, Ai, 18, 18, tv);                // 324 elements, 6 per lane
+    // The joints of different legs do not couple (H(leg a, leg b) = 0), so A = [Abb Abl; Abl' diag(L0..L3)] is inverted through the
+    // 6 x 6 Schur complement of the floating base instead of 18 pivots: Li = L^-1 (cofactors), T = Abl Li, Sb = Abb - T Abl',
+    // A^-1 = [Sb^-1, -Sb^-1 T; -T' Sb^-1, Li + T' Sb^-1 T].
+    {
+        real *Tm = scr, *Um = scr + 72;
+        if (lane < 36) {
+            const int l = lane / 9, e = lane - 9 * l, i = e / 3, j = e - 3 * i;
+            const real *B = A + (6 + 3 * l) * 18 + 6 + 3 * l;
+            const real b00 = B[0], b01 = B[1], b02 = B[2], b11 = B[19], b12 = B[20], b22 = B[38];
+            const real c00 = b11 * b22 - b12 * b12, c01 = b02 * b12 - b01 * b22, c02 = b01 * b12 - b02 * b11;
+            const real c11 = b00 * b22 - b02 * b02, c12 = b01 * b02 - b00 * b12, c22 = b00 * b11 - b01 * b01;
+            const real idet = 1.0 / (b00 * c00 + b01 * c01 + b02 * c02);
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const real c = (lo == 0) ? (hi == 0 ? c00 : (hi == 1 ? c01 : c02)) : (lo == 1 ? (hi == 1 ? c11 : c12) : c22);
+            Um[lane] = c * idet;                                    // Li, leg-major 3 x 3 blocks (parked in Um until T is formed)
+        }
+        wsync();
+        for (int e = lane; e < 72; e += 64) {
+            const int a = e / 12, c = e - 12 * a, l = c / 3, cc = c - 3 * l;
+            const real *Ar = A + a * 18 + 6 + 3 * l, *Li = Um + 9 * l;
+            Tm[e] = Ar[0] * Li[cc] + Ar[1] * Li[3 + cc] + Ar[2] * Li[6 + cc];
+        }
+        wsync();
+        for (int e = lane; e < 144; e += 64) {                      // leg-leg part starts as blockdiag(Li); everything else of Ai is written below
+            const int c = e / 12, d = e - 12 * c;
+            Ai[(6 + c) * 18 + 6 + d] = (c / 3 == d / 3) ? Um[9 * (c / 3) + 3 * (c % 3) + d % 3] : 0.0;
+        }
+        if (lane < 36) {
+            const int a = lane / 6, b2 = lane - 6 * a;
+            real acc = A[a * 18 + b2];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) acc -= Tm[a * 12 + c] * A[b2 * 18 + 6 + c];
+            Ai[a * 18 + b2] = acc;
+        }
+        wsync();
+        spd_inverse<1>(lane, Ai, 18, 6, tv);
+        for (int e = lane; e < 72; e += 64) {
+            const int a = e / 12, c = e - 12 * a;
+            real acc = 0.0;
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) acc += Ai[a * 18 + b2] * Tm[b2 * 12 + c];
+            Um[e] = acc;                                            // U = Sb^-1 T
+            Ai[a * 18 + 6 + c] = -acc; Ai[(6 + c) * 18 + a] = -acc;
+        }
+        wsync();
+        for (int e = lane; e < 144; e += 64) {
+            const int c = e / 12, d = e - 12 * c;
+            real acc = Ai[(6 + c) * 18 + 6 + d];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc += Tm[a * 12 + c] * Um[a * 12 + d];
+            Ai[(6 + c) * 18 + 6 + d] = acc;
+        }
+        wsync();
+    }
 
     QW_TS(4);
     // ---------------- K11 tasks and contacts ----------------
