@@ -905,7 +905,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             else {
                 real bs = -1e-10; int bc = 0x7fffffff;
                 if (lane >= 6 && lane < np_ + mi && posi[lane] < 0) {
-                    const real s = qc0[lane] + dot18(Nq + lane * 18, 1, qx, 1, nz);
+                    const int cj = 6 + 3 * ((lane - 6) / 6);                    // the three force unknowns of this row's contact
+                    const real s = qc0[lane] + (Nq[lane * 18 + cj] * qx[cj] + Nq[lane * 18 + cj + 1] * qx[cj + 1] + Nq[lane * 18 + cj + 2] * qx[cj + 2]);
                     if (s < bs) { bs = s; bc = lane; }
                 }
                 {   // lowest-id lane holding the minimum (lane == constraint id here)
@@ -919,10 +920,13 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             real up = 0.0;
             for (;;) {
                 if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
-                if (lane < nz) qw[lane] = Minv(lane) * Nq[p * 18 + lane];
-                wsync();
-                const real delta = wsum((lane < nz) ? Nq[p * 18 + lane] * qw[lane] : 0.0);
-                if (lane < q) qd_[lane] = dot18(Nq + act[lane] * 18, 1, qw, 1, nz);
+                // an inequality row touches the three force unknowns of one contact: its products are three terms, not a reduction
+                const int pj = 6 + 3 * ((p - 6) / 6);
+                const real pn0 = Nq[p * 18 + pj], pn1 = Nq[p * 18 + pj + 1], pn2 = Nq[p * 18 + pj + 2];
+                const real delta = (pn0 * pn0 + pn1 * pn1 + pn2 * pn2) * iw_fr;
+                // w = M n_p is iw_fr * n_p on those three unknowns and zero elsewhere
+                const real w0 = iw_fr * pn0, w1 = iw_fr * pn1, w2 = iw_fr * pn2;
+                if (lane < q) { const real *na = Nq + act[lane] * 18 + pj; qd_[lane] = na[0] * w0 + na[1] * w1 + na[2] * w2; }
                 wsync();
                 real dr = 0.0;
                 if (lane < q) { const real acc = dot18(Sq + lane * 18, 1, qd_, 1, q); qr_[lane] = acc; dr = acc * qd_[lane]; }
@@ -936,7 +940,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                     lpos = (mn < __builtin_inf()) ? first_lane(t1 == mn && lpos != 0x7fffffff) : 0x7fffffff;
                     t1 = mn;
                 }
-                const real sp = qc0[p] + wsum((lane < nz) ? Nq[p * 18 + lane] * qx[lane] : 0.0);
+                const real sp = qc0[p] + (pn0 * qx[pj] + pn1 * qx[pj + 1] + pn2 * qx[pj + 2]);
                 const bool have_z = zc > 1e-13 * delta;
                 const bool is_eq = p < np_;
                 const real izc = fast_rcp(zc);
@@ -957,7 +961,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 #pragma unroll
                             for (int j = 0; j < 18; ++j) acc += nv[j] * rv2[j];
                         }
-                        qz[lane] = qw[lane] - Minv(lane) * acc;
+                        const real wl_ = (lane == pj) ? w0 : (lane == pj + 1) ? w1 : (lane == pj + 2) ? w2 : 0.0;
+                        qz[lane] = wl_ - Minv(lane) * acc;
                         qx[lane] += t * qz[lane];
                     }
                 }
@@ -966,7 +971,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                 wsync();
                 if (have_z && (is_eq || t == t2)) {
                     const real isg = izc;
-                    for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; }
+                    { const int rq_ = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq_), j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; } }
                     if (lane < q) { Sq[q * 18 + lane] = -qr_[lane] * isg; Sq[lane * 18 + q] = -qr_[lane] * isg; }
                     if (lane == 0) { Sq[q * 18 + q] = isg; act[q] = p; posi[p] = q; qu_[q] = up; }
                     ++q;
@@ -979,7 +984,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                     if (lane < q) qd_[lane] = Sq[lane * 18 + l];
                     wsync();
                     const real isl = 1.0 / qd_[l];
-                    for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; }
+                    { const int rq_ = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq_), j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; } }
                     wsync();
                     if (l != last) {
                         if (lane < last) qr_[lane] = (lane == l) ? Sq[last * 18 + last] : Sq[last * 18 + lane];
