@@ -16,7 +16,7 @@ out = G.run_tick(ctx, pkg, b); out = G.run_tick(ctx, pkg, b)
 buf = np.zeros((n, 16), np.int64)
 lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, -n)
 d = np.diff(buf[:, :10], axis=1).astype(np.float64)
-names = ["load", "per-leg dyn", "base block", "dbg", "A^-1", "tasks", "K12", "WBIC recursion", "QP", "store"]
+names = ["load", "per-leg dyn", "base block (+dbg)", "A^-1", "tasks+contacts", "K12", "WBIC recursion", "QP", "store"]
 for k, nm in enumerate(names[:9]):
     print("  %-16s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, k].mean(), np.median(d[:, k]), d[:, k].max()))
 print("total mean %.0f max %.0f" % ((buf[:, 9] - buf[:, 0]).mean(), (buf[:, 9] - buf[:, 0]).max()))

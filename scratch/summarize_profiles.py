@@ -16,7 +16,7 @@ for nm in ("fetch", "write", "sq"):
     d = d[d["Kernel_Name"].str.contains("qrgpu::")]
     g = d.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].mean()
     for (k, c), v in g.items():
-        if "qr_mpc_kernel" in k: key = "qr_mpc_kernel"
+        if "qr_mpc_kernel<4, true>" in k or "qr_mpc_kernelILi4ELb1" in k: key = "qr_mpc_kernel"          # the main pass, not the rescue launch
         elif "qr_wbc_kernel" in k: key = "qr_wbc_kernel"
         else: continue
         rows.setdefault(key, {})[c] = float(v)
@@ -26,8 +26,12 @@ lines = ["# rocprofv3 summary (%s): `python3 bench.py` = 1024 A1 robots, h=10, f
          "| kernel | calls | avg ns | min ns | max ns |", "|---|---:|---:|---:|---:|"]
 for _, r in stats.iterrows():
     if "qrgpu::" in r["Name"]:
-        base = [k for k in ("qr_mpc_kernel", "qr_wbc_kernel", "qr_frontend_kernel", "qr_lpt_order_kernel", "qr_selftest_kernel") if k in r["Name"]]
-        lines.append("| %s | %d | %.0f | %d | %d |" % (base[0] if base else r["Name"][:40], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
+        nm = r["Name"]
+        base = [k for k in ("qr_mpc_kernel<4, true>", "qr_mpc_kernel<4, false>", "qr_mpc_kernel<9, true>", "qr_mpc_kernel<9, false>", "qr_mpc_kernel", "qr_wbc_kernel",
+                            "qr_frontend_kernel", "qr_vmc_kernel", "qr_lpt_order_kernel", "qr_selftest_kernel") if k in nm]
+        label = base[0] if base else nm[:40]
+        if label == "qr_mpc_kernel<4, false>": label += " (rescue launch, carries the longest-first sort)"
+        lines.append("| %s | %d | %.0f | %d | %d |" % (label, r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
 lines += ["", "PMC (separate passes, mean per launch).  FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md §HBM the read side",
           "is doubled (gfx950 tallies 128-B requests at 64 B; exact only for wide coalesced streams, an upper bound here):", "",
           "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes/launch (2*F+W) | algorithmic bytes/launch | ratio |", "|---|---:|---:|---:|---:|---:|"]
