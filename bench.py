@@ -106,7 +106,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = _load_pkg()
-    pkg._build.build()
+    if local_rank == 0:
+        pkg._build.build()          # one build per node; the other ranks wait (the build is also file-locked)
+    if world > 1:
+        dist.barrier()
     n, h = args.robots, args.horizon
     ctx = pkg.Context(device_id=local_rank, max_batch=n, horizon_max=16)   # raises without gfx950 / built library
     ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h)

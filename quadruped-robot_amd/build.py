@@ -23,9 +23,22 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles without a GPU.  Returns the path of the shared library."""
+    """hipcc cross-compiles without a GPU.  Returns the path of the shared library.  Serialised across processes with a file lock
+    (several ranks of one node may import the package at the same moment)."""
     if not force and not _stale():
         return SO
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():          # another process built it while we waited
+                return SO
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     flags = FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else [])
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
