@@ -422,11 +422,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
     int qW = 0;
     double *Wc = nullptr;
+    const int nsp = ns | 1;             // row stride of the cache: an odd number of doubles, so that one column block read by 64 rows
+                                        // (the d above) spreads over all LDS banks
     if constexpr (MULTI) {
         const int qs = qcap < 64 ? qcap : 64;
         const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs);
         Wc = Sinv + tri(qs);
-        if (rem > 0 && ns > 0) qW = (int)(rem / ns);
+        if (rem > 0 && ns > 0) qW = (int)(rem / (ns | 1));
         if (qW > 64) qW = 64;
     }
     int st = 0;
@@ -663,10 +665,15 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 // d = N' w : position i needs w of leg-step ck(i)
                 double dq = 0.0;
                 {
-                    double a0, a1, a2;
-                    cons_vec(ct, im, a0, a1, a2);
-                    const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
-                    if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
+                    if (fastz) {
+                        // d_i = c_i' M(k_i, kp) c_p = c_p' (W_A row i)(kp): three LDS doubles per position, independent of the load of w
+                        if (lane < q) { const double *wr = Wc + lane * nsp + 3 * kp; dq = c0 * wr[0] + c1 * wr[1] + c2 * wr[2]; }
+                    } else {
+                        double a0, a1, a2;
+                        cons_vec(ct, im, a0, a1, a2);
+                        const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
+                        if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
+                    }
                 }
                 QM_STAMP(1);
                 // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
@@ -742,14 +749,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         for (; i + 4 < q; i += 8) {
                             const double ra = readlane_d(rq, i), rb = readlane_d(rq, i + 4);
                             if (own) {
-                                const double *wa = wk + i * ns, *wb = wk + (i + 4) * ns;
+                                const double *wa = wk + i * nsp, *wb = wk + (i + 4) * nsp;
                                 const double a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
                                 p0 += a0 * ra + b0 * rb; p1 += a1 * ra + b1 * rb; p2 += a2 * ra + b2 * rb;
                             }
                         }
                         if (i < q) {
                             const double ra = readlane_d(rq, i);
-                            if (own) { const double *wa = wk + i * ns; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
+                            if (own) { const double *wa = wk + i * nsp; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
                         }
                     } else {
                         // y_k = sum over the active rows of my leg-step of c_row * r(position)
@@ -803,7 +810,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 if (full) {
                     // full step: the row joined the working set at position q (S^-1 already updated above)
                     if (fastz) {
-                        if (q < qW) { if (wv == 0 && own) { double *wq = Wc + q * ns + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }   // visible after the next barrier
+                        // every wave stores the (identical) row: a wave then reads back its own store in the next iteration's d
+                        // without waiting for a barrier
+                        if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
                         else fastz = false;
                     }
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
@@ -832,7 +841,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (wv == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
                         __syncthreads();
                         if (wv == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
-                        if (fastz && wv == 0 && own) { const double *wl_ = Wc + last * ns + 3 * kme; double *wd_ = Wc + l * ns + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
+                        if (fastz && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
                         const double ulast = readlane_d(uq, last);
                         if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
                     }

@@ -164,3 +164,27 @@ def test_rescue_pass_large_working_sets(gpu_ctx, pkg, oracle):
         u, st, rc = oracle.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
         assert rc == 0 and st["n_active"] > 40
         assert np.abs(out["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max()), i
+
+
+def test_dispatch_order_does_not_change_results(gpu_ctx, pkg):
+    """Longest-first dispatch is scheduling only: slot order, first history-less launch and history-ordered launches agree bit for bit."""
+    h, n = 10, 512
+    G.setup_a1(gpu_ctx, pkg, h)
+    b = pkg.make_batch(n, h, "a1", seed=0x51)
+    gpu_ctx.set_lpt_schedule(False)
+    try:
+        ref = G.run_mpc(gpu_ctx, pkg, b)
+    finally:
+        gpu_ctx.set_lpt_schedule(True)
+    first = G.run_mpc(gpu_ctx, pkg, b)          # no history yet for this n
+    second = G.run_mpc(gpu_ctx, pkg, b)         # ordered by the costs of `first`
+    b2 = pkg.make_batch(n, h, "a1", seed=0x52)   # different robots, stale history
+    third = G.run_mpc(gpu_ctx, pkg, b2)
+    gpu_ctx.set_lpt_schedule(False)
+    try:
+        ref2 = G.run_mpc(gpu_ctx, pkg, b2)
+    finally:
+        gpu_ctx.set_lpt_schedule(True)
+    for o in (first, second):
+        assert np.array_equal(o["force"], ref["force"]) and np.array_equal(o["tau"], ref["tau"]) and np.array_equal(o["status"], ref["status"])
+    assert np.array_equal(third["force"], ref2["force"]) and np.array_equal(third["status"], ref2["status"])
