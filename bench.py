@@ -73,6 +73,70 @@ def cpu_baseline(pkg, b, horizon):
                 single_thread_value=128 / t1)
 
 
+def side_mode(args, pkg, ctx, torch, dev, stream):
+    """The SURVEY 8f rows on one GPU: `vmc` = force-balance stance QP (ComputeContactForce), `frontend` = MPC front-end
+    (SetupCommand/Run/UpdateMPC).  A step = one batched call over --robots robots; kernel time by events on the launch stream."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build()
+    n, h = args.robots, args.horizon
+    T = lambda a: torch.from_numpy(pkg.to_soa(a)).to(dev)
+    W = pkg.workload
+    if args.mode == "vmc":
+        cfg, geom = W.vmc_cfg("a1"), pkg.model_desc("a1")[:3]
+        ctx.vmc_setup_packed(0, cfg, geom)
+        vin, q = W.make_vmc_batch(n, seed=0xB2)
+        d_in, d_q = T(vin), T(q)
+        d_f, d_t = torch.empty((12, n), dtype=torch.float32, device=dev), torch.empty((12, n), dtype=torch.float32, device=dev)
+        d_s = torch.zeros((n,), dtype=torch.int32, device=dev)
+        step = lambda: ctx.vmc_force_batch(n, d_in, d_q, d_f, d_t, d_s)
+        cpu = lambda i: O.vmc_solve(cfg, geom, vin[i], q[i])
+        alg_bytes = (37 + 12 + 12 + 12 + 1) * 4
+        metric, unit, kernel = "force-balance QP solves/s (batched robots)", "solves/s", "qr_vmc_kernel"
+        # assembly 12x12x6 + 6x12, inverse 12^3, ~20 working-set changes of ~4*12^2 (dense count, as SURVEY 8d does for the MPC QP)
+        alg_flop = 2 * 12 * 12 * 6 + 2 * 6 * 12 + 12 ** 3 + 20 * 4 * 12 ** 2
+    else:
+        vin, st = W.make_frontend_batch(n, seed=0xFE)
+        d_in, d_st = T(vin), T(st)
+        d_traj = torch.zeros((12 * h, n), dtype=torch.float32, device=dev); d_gait = torch.zeros((4 * h, n), dtype=torch.float32, device=dev)
+        d_cmd = torch.zeros((67, n), dtype=torch.float32, device=dev); d_u = torch.zeros((n,), dtype=torch.int32, device=dev)
+        step = lambda: ctx.mpc_frontend_batch(n, d_in, d_st, d_traj, d_gait, d_cmd, d_u)
+        cpu = lambda i: O.mpc_frontend(h, 2, vin[i], st[i])
+        alg_bytes = (64 + 8 + 8 + 16 * h + 19 + 1) * 4
+        metric, unit, kernel = "MPC front-end robot-ticks/s (batched robots)", "robot-ticks/s", "qr_frontend_kernel"
+        alg_flop = 0
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    # CPU restatement, one thread, bounded sample
+    m = min(n, 2000)
+    c0 = time.perf_counter()
+    for i in range(m):
+        cpu(i)
+    cpu_rate = m / (time.perf_counter() - c0)
+    gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9
+    out = {"metric": metric, "value": n * args.steps / elapsed, "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 assembly / f64 QP" if args.mode == "vmc" else "f32 (f64 where the reference promotes)", "data": "synthetic",
+           "config": {"workload": "%d A1 robots, %s" % (n, "ComputeContactForce + J^T f per robot" if args.mode == "vmc" else "horizon %d front-end per robot" % h),
+                      "robots_per_gpu": n},
+           "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_robot": alg_bytes, "algorithmic_flop_per_robot": alg_flop,
+                        "note": "launch- and latency-bound at this batch size, not bandwidth-bound"},
+           "cpu_baseline": {"value": cpu_rate, "unit": unit, "cores": 1, "kind": "port",
+                            "sample": "%d robots through the oracle's C++ restatement via ctypes, one thread" % m}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,7 +145,8 @@ def main():
     ap.add_argument("--robots", type=int, default=1024, help="robots per GPU")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--excite", type=float, default=1.0)
-    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc"])
+    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend"],
+                    help="tick = the headline; vmc / frontend = the SURVEY 8f rows (force-balance QP, MPC front-end), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compare-dispatch", action="store_true",
                     help="also time the loop with slot-order dispatch (no longest-first history); off by default so that a profile of the "
@@ -116,6 +181,12 @@ def main():
     ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+
+    if args.mode in ("vmc", "frontend"):
+        if rank == 0:
+            print(json.dumps(side_mode(args, pkg, ctx, torch, dev, stream)))
+        ctx.close()
+        return
 
     # every rank owns its own contiguous shard of the global robot population (seed offset by rank)
     b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite,

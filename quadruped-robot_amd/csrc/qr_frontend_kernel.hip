@@ -1,5 +1,5 @@
 // ============================================================================
-// MPC front-end, one thread per robot: command filter, desired-pose integration,
+// MPC front-end, one thread per (robot, horizon step): command filter, desired-pose integration,
 // contact table and reference trajectory of
 //   MPCStanceLegController::SetupCommand / Run / UpdateMPC
 //   (quadruped/src/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-204, 207-334, 337-382)
@@ -19,13 +19,18 @@ namespace qrgpu {
 #pragma clang fp contract(off)
 __device__ __forceinline__ float fe_clip(float c, float lo, float hi) { return c < lo ? lo : (c > hi ? hi : c); }
 
-__global__ void __launch_bounds__(256) qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *__restrict__ fin,
-                                                          float *__restrict__ fst, float *__restrict__ g_traj, float *__restrict__ g_gait,
-                                                          float *__restrict__ g_cmd, int *__restrict__ g_updated)
+// blockDim = (64 robots, horizon): thread (x, k) recomputes the short scalar prefix of robot x and writes row k of its contact table
+// and reference trajectory, so that the h-long store loops of one robot run side by side; thread k = 0 also writes the
+// controller memory, the WBC rows and the re-plan flag.  The barrier separates every read of fe_state from its rewrite.
+__global__ void __launch_bounds__(1024) qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *__restrict__ fin,
+                                                           float *__restrict__ fst, float *__restrict__ g_traj, float *__restrict__ g_gait,
+                                                           float *__restrict__ g_cmd, int *__restrict__ g_updated)
 {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int krow = threadIdx.y;
+    const int i_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i_raw < n;
+    const int i = live ? i_raw : n - 1;                 // out-of-range threads shadow the last robot (no stores) so that all reach the barrier
     const size_t N = (size_t)n;
 #define FIN(f) fin[(size_t)(f) * N + i]
     const double kPI = 3.14159265358979323846, k2PI = 6.28318530718;        // M_PI, M_2PI (utils/qr_ctypes.h:51)
@@ -36,6 +41,7 @@ __global__ void __launch_bounds__(256) qr_frontend_kernel(int n, int horizon, in
     float xVelDes = fst[0 * N + i], yVelDes = fst[1 * N + i], yawTurnRate = fst[2 * N + i], yawDesTrue = fst[3 * N + i];
     float posx = fst[4 * N + i], posy = fst[5 * N + i], posz = fst[6 * N + i];
     const int iterationCounter = (int)fst[7 * N + i];
+    __syncthreads();
 
     // SetupCommand (:163-203)
     const float x_filter = 0.01f, y_filter = 0.005f, yaw_filter = 0.03f;
@@ -91,15 +97,17 @@ __global__ void __launch_bounds__(256) qr_frontend_kernel(int n, int horizon, in
     posy = (1 - t) * FIN(63) + t * cdy;
 
     const float dPhase = (float)(1.0 / (double)(numHorizonL * horizon));
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float ph = FIN(42 + j), du = FIN(46 + j);
-        const bool early = (int)FIN(58 + j) == 2;                           // LegState::EARLY_CONTACT
-        g_gait[(size_t)j * N + i] = (ct[j] != 0.f) ? 1.f : 0.f;            // row 0 = measured contacts (:301-303)
-        for (int k = 1; k < horizon; ++k) {
-            float ith = ph + k * dPhase;
-            while ((double)ith > 1.0) ith = (float)((double)ith - 1.0);
-            g_gait[(size_t)(4 * k + j) * N + i] = (ith < du || early) ? 1.f : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            float v;
+            if (krow == 0) v = (ct[j] != 0.f) ? 1.f : 0.f;                  // row 0 = measured contacts (:301-303)
+            else {
+                float ith = FIN(42 + j) + krow * dPhase;
+                while ((double)ith > 1.0) ith = (float)((double)ith - 1.0);
+                v = (ith < FIN(46 + j) || (int)FIN(58 + j) == 2) ? 1.f : 0.f;    // LegState::EARLY_CONTACT stays in the table
+            }
+            g_gait[(size_t)(4 * krow + j) * N + i] = v;
         }
     }
 
@@ -110,14 +118,15 @@ __global__ void __launch_bounds__(256) qr_frontend_kernel(int n, int horizon, in
     if (upd) {
         posx = fe_clip(posx, px - 0.1f, px + 0.1f);
         posy = fe_clip(posy, py - 0.1f, py + 0.1f);
-        float yaw = yawDesTrue, x = posx, y = posy;
-        for (int k = 0; k < horizon; ++k) {
-            if (k > 0) { yaw = yaw + dtMPC * yawTurnRate; x = x + dtMPC * vwx; y = y + dtMPC * vwy; }
-            float *tr = g_traj + (size_t)(12 * k) * N + i;
+        if (live) {
+            float yaw = yawDesTrue, x = posx, y = posy;
+            for (int k = 0; k < krow; ++k) { yaw = yaw + dtMPC * yawTurnRate; x = x + dtMPC * vwx; y = y + dtMPC * vwy; }   // the reference's running sums (:372-374)
+            float *tr = g_traj + (size_t)(12 * krow) * N + i;
             tr[0] = 0.f; tr[N] = rpy1; tr[2 * N] = yaw; tr[3 * N] = x; tr[4 * N] = y; tr[5 * N] = bodyHeight;
             tr[6 * N] = 0.f; tr[7 * N] = 0.f; tr[8 * N] = yawTurnRate; tr[9 * N] = vwx; tr[10 * N] = vwy; tr[11 * N] = 0.f;
         }
     }
+    if (!live || krow != 0) return;
     if (g_updated) g_updated[i] = upd ? 1 : 0;
 
     // wbcData (:307-332)

@@ -498,7 +498,7 @@ int qrgpu_mpc_frontend_batch(qrgpu_ctx *c, int n, int num_horizon_l, float dt_ct
     if (num_horizon_l <= 0 || !(dt_ctrl > 0.f) || !(dt_mpc > 0.f)) return QRGPU_ERR_BAD_ARG;
     if (!c->mpc_ready[0]) return QRGPU_ERR_NOT_SETUP;
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(qr_frontend_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->mpc.horizon, num_horizon_l, dt_ctrl, dt_mpc,
+    hipLaunchKernelGGL(qr_frontend_kernel, dim3((n + 63) / 64), dim3(64, c->mpc.horizon), 0, c->stream, n, c->mpc.horizon, num_horizon_l, dt_ctrl, dt_mpc,
                        d_fe_in, d_fe_state, d_traj, d_gait, d_wbc_cmd, d_mpc_updated);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
