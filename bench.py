@@ -95,6 +95,19 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
         metric, unit, kernel = "force-balance QP solves/s (batched robots)", "solves/s", "qr_vmc_kernel"
         # assembly 12x12x6 + 6x12, inverse 12^3, ~20 working-set changes of ~4*12^2 (dense count, as SURVEY 8d does for the MPC QP)
         alg_flop = 2 * 12 * 12 * 6 + 2 * 6 * 12 + 12 ** 3 + 20 * 4 * 12 ** 2
+    elif args.mode == "estimator":
+        cfg = W.estimator_cfg("a1")
+        xs, stamps = W.make_estimator_sequence(n, 4, seed=0xE5)
+        d_in = T(xs[0]); d_tick = torch.from_numpy(stamps[0].astype(np.int64)).to(dev).to(torch.int32)
+        S_ = ctx.estimator_state_doubles(int(cfg[6]))
+        d_state = torch.zeros((S_, n), dtype=torch.float64, device=dev); d_out = torch.zeros((36, n), dtype=torch.float32, device=dev)
+        step = lambda: ctx.estimator_update_batch(n, cfg, d_in, d_tick, d_state, d_out)
+        seq = np.repeat(xs[0][None, :1], 200, 0)[:, 0]
+        cpu_all = lambda: O.estimator_run(cfg, seq, (1000 + 2 * np.arange(200)).astype(np.uint32))
+        cpu = None
+        alg_bytes = (41 + 1 + 36) * 4 + 2 * (32 + 6) * 8
+        metric, unit, kernel = "velocity-estimator robot-ticks/s (batched robots)", "robot-ticks/s", "qr_estimator_kernel"
+        alg_flop = 0
     else:
         vin, st = W.make_frontend_batch(n, seed=0xFE)
         d_in, d_st = T(vin), T(st)
@@ -120,20 +133,26 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
     # CPU restatement, one thread, bounded sample
     m = min(n, 2000)
     c0 = time.perf_counter()
-    for i in range(m):
-        cpu(i)
+    if cpu is None:
+        for _ in range(10):
+            cpu_all()
+        m = 2000
+    else:
+        for i in range(m):
+            cpu(i)
     cpu_rate = m / (time.perf_counter() - c0)
     gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9
     out = {"metric": metric, "value": n * args.steps / elapsed, "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 assembly / f64 QP" if args.mode == "vmc" else "f32 (f64 where the reference promotes)", "data": "synthetic",
-           "config": {"workload": "%d A1 robots, %s" % (n, "ComputeContactForce + J^T f per robot" if args.mode == "vmc" else "horizon %d front-end per robot" % h),
+           "config": {"workload": "%d A1 robots, %s" % (n, {"vmc": "ComputeContactForce + J^T f per robot", "frontend": "horizon %d front-end per robot" % h,
+                                                             "estimator": "UpdateDataFlow kinematics + velocity estimator update per robot"}[args.mode]),
                       "robots_per_gpu": n},
            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_robot": alg_bytes, "algorithmic_flop_per_robot": alg_flop,
                         "note": "launch- and latency-bound at this batch size, not bandwidth-bound"},
            "cpu_baseline": {"value": cpu_rate, "unit": unit, "cores": 1, "kind": "port",
-                            "sample": "%d robots through the oracle's C++ restatement via ctypes, one thread" % m}}
+                            "sample": "%d robot-ticks through the oracle's C++ restatement via ctypes, one thread" % m}}
     return out
 
 
@@ -145,7 +164,7 @@ def main():
     ap.add_argument("--robots", type=int, default=1024, help="robots per GPU")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--excite", type=float, default=1.0)
-    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend"],
+    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend", "estimator"],
                     help="tick = the headline; vmc / frontend = the SURVEY 8f rows (force-balance QP, MPC front-end), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compare-dispatch", action="store_true",
@@ -182,7 +201,7 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    if args.mode in ("vmc", "frontend"):
+    if args.mode in ("vmc", "frontend", "estimator"):
         if rank == 0:
             print(json.dumps(side_mode(args, pkg, ctx, torch, dev, stream)))
         ctx.close()

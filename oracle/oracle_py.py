@@ -244,3 +244,30 @@ def vmc_solve(cfg20, geom3, in37, q12=None):
     rc = lib().qro_vmc_solve(_fp(np.ascontiguousarray(cfg20, _f)), _fp(np.ascontiguousarray(geom3, _f)), _fp(np.ascontiguousarray(in37, _f)),
                              _fp(qa) if qa is not None else None, _fp(force), _fp(tau) if qa is not None else None, _dp(x), _ip(st))
     return force, (tau if qa is not None else None), x, dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])), rc
+
+
+def ekf3_run(qvar, rvar, deltaV, z):
+    """Our restatement of TinyEKF<3,3> with the velocity estimator's model, stepped from a fresh filter.  -> x after each step, failures"""
+    dv = np.ascontiguousarray(deltaV, _d); zz = np.ascontiguousarray(z, _d)
+    out = np.zeros_like(dv)
+    lib().qro_ekf3_run.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    bad = lib().qro_ekf3_run(float(qvar), float(rvar), dv.shape[0], _dp(dv), _dp(zz), _dp(out))
+    return out, bad
+
+
+def ref_tinyekf_run(acc_var, sensor_var, deltaV, z):
+    """The reference's own TinyEKF<3,3> (compiled from /root/reference into oracle/_ref), driven as qrRobotVelocityEstimator does."""
+    r = ref()
+    dv = np.ascontiguousarray(deltaV, _d); zz = np.ascontiguousarray(z, _d)
+    out = np.zeros_like(dv)
+    r.ref_tinyekf_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    bad = r.ref_tinyekf_run(float(acc_var), float(sensor_var), dv.shape[0], _dp(dv), _dp(zz), _dp(out))
+    return out, bad
+
+
+def estimator_run(cfg19, in41, tick):
+    """A sequence of velocity-estimator updates of one robot from a fresh estimator.  in41 [T][41], tick [T] (ms) -> out [T][36]"""
+    a = np.ascontiguousarray(in41, _f); t = np.ascontiguousarray(tick, np.uint32)
+    out = np.zeros((a.shape[0], 36), _f)
+    lib().qro_estimator_run(_fp(np.ascontiguousarray(cfg19, _f)), a.shape[0], _fp(a), t.ctypes.data_as(C.c_void_p), _fp(out))
+    return out

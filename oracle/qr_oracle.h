@@ -212,6 +212,27 @@ void vmc_assemble(const VmcConfig &c, const VmcInput &in, float G[144], float a[
 int vmc_solve(const VmcConfig &c, const VmcInput &in, float force[12], double xout[12], QpStats *st);
 
 // ---------------------------------------------------------------------------
+// Base velocity estimator + leg kinematics (first part).  qr_oracle_estimator.cpp
+// ---------------------------------------------------------------------------
+struct EstimatorConfig {
+    float hip_l = 0.08505f, upper_l = 0.2f, lower_l = 0.2f;
+    float hip_offset[12] = {0.1805f, -0.047f, 0, 0.1805f, 0.047f, 0, -0.1805f, -0.047f, 0, -0.1805f, 0.047f, 0};
+    float time_step = 0.002f;                      // robot->timeStep
+    float accelerometer_variance = 0.1f, sensor_variance = 0.1f;
+    int window = 60;                               // movingWindowFilterSize
+};
+struct EstimatorState {
+    unsigned last_timestamp = 0;
+    double x[3] = {0, 0, 0}, P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float est_vel_base[3] = {0, 0, 0};
+    std::vector<double> vel_win[3]; double vel_sum[3] = {0, 0, 0}, vel_corr[3] = {0, 0, 0}; int vel_count = 0, vel_head = 0;
+    float acc_win[3][20]; float acc_sum[3] = {0, 0, 0}, acc_corr[3] = {0, 0, 0}; int acc_count = 0, acc_head = 0;
+    explicit EstimatorState(int W) { for (auto &w : vel_win) w.assign(W, 0.0); std::memset(acc_win, 0, sizeof(acc_win)); }
+};
+int ekf3_step(double x[3], double P[9], double qvar, double rvar, const double deltaV[3], const double z[3]);
+void estimator_update(const EstimatorConfig &cfg, const float in[41], unsigned tick, EstimatorState &s, float out[36]);
+
+// ---------------------------------------------------------------------------
 // MPC front-end.  qr_oracle_frontend.cpp
 // in[64] = des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd, basePosition[3], yawCurrent,
 //          quat_wxyz[4], footPosWorld[12] (leg major), footTargetWorld[12], contacts[4], phaseInFullCycle[4],

@@ -18,6 +18,9 @@
 
 #include <limits>
 
+#include <string.h>
+#include "TinyEKF.h"
+
 extern "C" {
 
 // H: n*n row-major, A: m*n row-major (as EigenToOASES writes them,
@@ -69,6 +72,21 @@ double ref_quadprog(int n, int p, int m, const double *G, const double *g0,
     double f = quadprogpp::solve_quadprog(qG, qg0, qCE, qce0, qCI, qci0, qx);
     for (int i = 0; i < n; ++i) x_out[i] = qx[i];
     return f;
+}
+
+// The reference's own TinyEKF<3,3> (QX/TinyEKF/src/TinyEKF.h + tiny_ekf.c), constructed and stepped exactly as
+// qrRobotVelocityEstimator does (QS/estimators/qr_robot_velocity_estimator.cpp:42, :104-109): nsteps calls of step(deltaV, z).
+// x_out: [nsteps][3] state after each step.
+int ref_tinyekf_run(float accelerometerVariance, float sensorVariance, int nsteps, const double *deltaV, const double *z, double *x_out)
+{
+    TinyEKF<3, 3> f(0.f, 0.f, accelerometerVariance, sensorVariance);
+    int bad = 0;
+    for (int k = 0; k < nsteps; ++k) {
+        double dv[3] = {deltaV[3 * k], deltaV[3 * k + 1], deltaV[3 * k + 2]}, zz[3] = {z[3 * k], z[3 * k + 1], z[3 * k + 2]};
+        if (!f.step(dv, zz)) ++bad;
+        for (int i = 0; i < 3; ++i) x_out[3 * k + i] = f.getX(i);
+    }
+    return bad;
 }
 
 }  // extern "C"

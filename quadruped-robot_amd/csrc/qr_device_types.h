@@ -73,6 +73,14 @@ struct VmcLaunch {
     int n;
 };
 
+// Velocity-estimator parameters (qrgpu_estimator_desc)
+struct EstimatorDesc {
+    float hip_l, upper_l, lower_l;
+    float hip_offset[12];
+    float time_step, accelerometer_variance, sensor_variance;
+    int window;
+};
+
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
 // The four-wave active set needs the exchange buffers xz[4][NV], xr[4][64]; the single-wave one (h > 11 by default, and the
 // rescue pass) the staging arrays wl, yl, rl and the sAct / sPos tables.

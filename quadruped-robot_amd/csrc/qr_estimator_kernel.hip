@@ -1,0 +1,273 @@
+// ============================================================================
+// Base velocity estimator + the leg kinematics it reads, one thread per robot (first part):
+//   qrRobot::UpdateDataFlow              quadruped/src/robots/qr_robot.cpp:62-72, 187-197   (foot Jacobians, positions, velocities)
+//   qrRobotVelocityEstimator::Update     quadruped/src/estimators/qr_robot_velocity_estimator.cpp:77-133
+//   qrMovingWindowFilter                 quadruped/include/quadruped/estimators/qr_moving_window_filter.hpp:150-186, 236-263
+//   TinyEKF<3,3>                         quadruped/extern/TinyEKF/src/TinyEKF.h:103-124, tiny_ekf.c:17-93, 292-332
+// A streaming kernel with per-robot memory: the Kalman state, the two Neumaier window sums and their ring buffers live in a
+// [field][robot] array of doubles of which one tick touches 32 header fields and 6 ring slots.  Every operation of the filters is
+// the reference's, in its order and type, contraction off: with equal foot kinematics the outputs are bit-identical to the CPU
+// restatement (whose Kalman step is bit-identical to the reference's compiled TinyEKF); sinf / cosf of the leg kinematics differ
+// from libm in the last bit, which is what the tolerance of tests/test_gpu_estimator.py covers.
+// ============================================================================
+#include <hip/hip_runtime.h>
+#include "qr_device_types.h"
+#include "qr_wave_helpers.h"
+
+namespace qrgpu {
+
+namespace {
+#pragma clang fp contract(off)
+__device__ __forceinline__ void mulmat3(const double *a, const double *b, double *c)
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) acc += a[3 * i + l] * b[3 * l + j];
+            c[3 * i + j] = acc;
+        }
+}
+__device__ __forceinline__ int cholsl3(const double *A, double *a, double *p)
+{
+#pragma clang fp contract(off)
+    const int n = 3;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = A[i];
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = i; j < n; j++) {
+            double sum = a[i * n + j];
+#pragma unroll
+            for (int k = i - 1; k >= 0; k--) sum -= a[i * n + k] * a[j * n + k];
+            if (i == j) { if (sum <= 0) return 1; p[i] = sqrt(sum); }
+            else a[j * n + i] = sum / p[i];
+        }
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        a[i * n + i] = 1 / p[i];
+#pragma unroll
+        for (int j = i + 1; j < n; j++) {
+            double sum = 0;
+#pragma unroll
+            for (int k = i; k < j; k++) sum -= a[j * n + k] * a[k * n + i];
+            a[j * n + i] = sum / p[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = i + 1; j < n; j++) a[i * n + j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        a[i * n + i] *= a[i * n + i];
+#pragma unroll
+        for (int k = i + 1; k < n; k++) a[i * n + i] += a[k * n + i] * a[k * n + i];
+#pragma unroll
+        for (int j = i + 1; j < n; j++)
+#pragma unroll
+            for (int k = j; k < n; k++) a[i * n + j] += a[k * n + i] * a[k * n + j];
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) a[i * n + j] = a[j * n + i];
+    return 0;
+}
+
+// Neumaier update of (sum, corr) by v
+template <typename T> __device__ __forceinline__ void neumaier(T &sum, T &corr, T v)
+{
+#pragma clang fp contract(off)
+    const T ns = sum + v;
+    const T as = sum < 0 ? -sum : sum, av = v < 0 ? -v : v;
+    if (as >= av) corr += (sum - ns) + v;
+    else corr += (v - ns) + sum;
+    sum = ns;
+}
+}  // namespace
+
+#define EST_LAST 0
+#define EST_X 1
+#define EST_P 4
+#define EST_VB 13
+#define EST_VSUM 16
+#define EST_VCORR 19
+#define EST_VCNT 22
+#define EST_VHEAD 23
+#define EST_ASUM 24
+#define EST_ACORR 27
+#define EST_ACNT 30
+#define EST_AHEAD 31
+#define EST_AWIN 32
+#define EST_VWIN 92
+
+__global__ void __launch_bounds__(64) qr_estimator_kernel(int n, EstimatorDesc D, const float *__restrict__ g_in, const unsigned *__restrict__ g_tick,
+                                                          double *__restrict__ st, float *__restrict__ g_out)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define IN(f) g_in[(size_t)(f) * N + i]
+#define ST(f) st[(size_t)(f) * N + i]
+    // ---- UpdateDataFlow: leg kinematics (FootPositionInHipFrame :127-146, AnalyticalLegJacobian :148-172)
+    float footP[12], footV[12];
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) {
+        const float t0 = IN(17 + 3 * leg), t1 = IN(18 + 3 * leg), t2 = IN(19 + 3 * leg);
+        const float d0 = IN(29 + 3 * leg), d1 = IN(30 + 3 * leg), d2 = IN(31 + 3 * leg);
+        const float sh = D.hip_l * ((leg & 1) ? 1.f : -1.f);
+        const float lu = D.upper_l, ll = D.lower_l;
+        const float legDist = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
+        const float eff = t1 + t2 / 2;
+        const float offX = -legDist * sinf(eff), offZ = -legDist * cosf(eff), offY = sh;
+        footP[3 * leg + 0] = offX + D.hip_offset[3 * leg + 0];
+        footP[3 * leg + 1] = cosf(t0) * offY - sinf(t0) * offZ + D.hip_offset[3 * leg + 1];
+        footP[3 * leg + 2] = sinf(t0) * offY + cosf(t0) * offZ + D.hip_offset[3 * leg + 2];
+        float J[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) leg_jacobian_column(j, t0, t1, t2, sh, lu, ll, J[0][j], J[1][j], J[2][j]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) footV[3 * leg + r] = J[r][0] * d0 + J[r][1] * d1 + J[r][2] * d2;
+    }
+    // ---- AccFilter: 3-vector window of 20 (:79-80)
+    float facc[3];
+    {
+        const int cnt = (int)ST(EST_ACNT), head = (int)ST(EST_AHEAD);
+        const int len = cnt >= 20 ? cnt - 1 : cnt;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float sum = (float)ST(EST_ASUM + a), corr = (float)ST(EST_ACORR + a);
+            if (cnt >= 20) neumaier<float>(sum, corr, -(float)ST(EST_AWIN + 20 * a + head));
+            const float v = IN(3 + a);
+            neumaier<float>(sum, corr, v);
+            ST(EST_AWIN + 20 * a + head) = (double)v;
+            ST(EST_ASUM + a) = (double)sum; ST(EST_ACORR + a) = (double)corr;
+            facc[a] = (sum + corr) / (float)(len + 1);
+        }
+        ST(EST_ACNT) = (double)(len + 1); ST(EST_AHEAD) = (double)((head + 1) % 20);
+    }
+    // ---- ComputeDeltaTime (:64-75)
+    const unsigned tick = g_tick[i], last = (unsigned)ST(EST_LAST);
+    float deltaTime;
+    if ((double)last < 1e-5) deltaTime = D.time_step;
+    else deltaTime = (float)((double)(tick - last) / 1000.);
+    ST(EST_LAST) = (double)tick;
+    // ---- attitude, calibrated acceleration, contact-leg observation (:85-103)
+    const float e0 = IN(6), e1 = IN(7), e2 = IN(8), e3 = IN(9);
+    float R[3][3];
+    R[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); R[0][1] = 2 * (e1 * e2 - e0 * e3); R[0][2] = 2 * (e1 * e3 + e0 * e2);
+    R[1][0] = 2 * (e1 * e2 + e0 * e3); R[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); R[1][2] = 2 * (e2 * e3 - e0 * e1);
+    R[2][0] = 2 * (e1 * e3 - e0 * e2); R[2][1] = 2 * (e2 * e3 + e0 * e1); R[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    const float s0 = IN(0), s1 = IN(1), s2 = IN(2);
+    float cal[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cal[r] = R[r][0] * s0 + R[r][1] * s1 + R[r][2] * s2;
+    cal[2] = (float)((double)cal[2] - 9.81);
+    const double deltaV[3] = {(double)(cal[0] * deltaTime), (double)(cal[1] * deltaTime), (double)(cal[2] * deltaTime)};
+    const float wx = IN(10), wy = IN(11), wz = IN(12);
+    float mean[3] = {0.f, 0.f, 0.f};
+    int num = 0;
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) {
+        if (IN(13 + leg) == 0.f) continue;
+        const float p0 = footP[3 * leg], p1 = footP[3 * leg + 1], p2 = footP[3 * leg + 2];
+        const float cx = 0 * p0 + (-wz) * p1 + wy * p2;
+        const float cy = wz * p0 + 0 * p1 + (-wx) * p2;
+        const float cz = (-wy) * p0 + wx * p1 + 0 * p2;
+        const float vB0 = footV[3 * leg] + cx, vB1 = footV[3 * leg + 1] + cy, vB2 = footV[3 * leg + 2] + cz;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) mean[r] += (-R[r][0]) * vB0 + (-R[r][1]) * vB1 + (-R[r][2]) * vB2;
+        ++num;
+    }
+    double z[3];
+    if (num > 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { mean[r] /= (float)num; z[r] = (double)mean[r]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) z[r] = (double)(float)ST(EST_VB + r);
+    }
+    // ---- TinyEKF<3,3>::step with fx = x + deltaV, F = H = I (:104-109)
+    double x[3], P[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) x[r] = ST(EST_X + r);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) P[r] = ST(EST_P + r);
+    {
+        const double qv = (double)D.accelerometer_variance, rv = (double)D.sensor_variance;
+        const double F[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double fx[3] = {x[0] + deltaV[0], x[1] + deltaV[1], x[2] + deltaV[2]};
+        double tmp0[9], Pp[9], tmp1[9], tmp2[9], tmp3[9], tmp4[9], tmp5[3], G[9];
+        mulmat3(F, P, tmp0);
+        mulmat3(tmp0, F, Pp);                        // Ft = F
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Pp[4 * r] += qv;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (r % 4 != 0) Pp[r] += 0.0;
+        mulmat3(Pp, F, tmp1);                        // Ht = H = I
+        mulmat3(F, Pp, tmp2);
+        mulmat3(tmp2, F, tmp3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tmp3[4 * r] += rv;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (r % 4 != 0) tmp3[r] += 0.0;
+        if (!cholsl3(tmp3, tmp4, tmp5)) {
+            mulmat3(tmp1, tmp4, G);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tmp5[r] = z[r] - fx[r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { double y = 0; for (int j = 0; j < 3; ++j) y += tmp5[j] * G[3 * r + j]; x[r] = fx[r] + y; }
+            mulmat3(G, F, tmp0);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) tmp0[r] = -tmp0[r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tmp0[4 * r] += 1;
+            mulmat3(tmp0, Pp, P);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ST(EST_X + r) = x[r];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) ST(EST_P + r) = P[r];
+    // ---- three scalar windows of W doubles on float(x) (:111-116)
+    float vw[3];
+    {
+        const int W = D.window;
+        const int cnt = (int)ST(EST_VCNT), head = (int)ST(EST_VHEAD);
+        const int len = cnt >= W ? cnt - 1 : cnt;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double sum = ST(EST_VSUM + a), corr = ST(EST_VCORR + a);
+            double *slot = st + (size_t)(EST_VWIN + W * a + head) * N + i;
+            if (cnt >= W) neumaier<double>(sum, corr, -*slot);
+            const double v = (double)(float)x[a];
+            neumaier<double>(sum, corr, v);
+            *slot = v;
+            ST(EST_VSUM + a) = sum; ST(EST_VCORR + a) = corr;
+            vw[a] = (float)((sum + corr) / (double)(len + 1));
+        }
+        ST(EST_VCNT) = (double)(len + 1); ST(EST_VHEAD) = (double)((head + 1) % W);
+    }
+    // ---- outputs (:117-132)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float vb = R[0][r] * vw[0] + R[1][r] * vw[1] + R[2][r] * vw[2];
+        ST(EST_VB + r) = (double)vb;
+        g_out[(size_t)r * N + i] = facc[r];
+        g_out[(size_t)(3 + r) * N + i] = vw[r];
+        g_out[(size_t)(6 + r) * N + i] = vb;
+        g_out[(size_t)(9 + r) * N + i] = R[r][0] * wx + R[r][1] * wy + R[r][2] * wz;
+    }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { g_out[(size_t)(12 + r) * N + i] = footP[r]; g_out[(size_t)(24 + r) * N + i] = footV[r]; }
+#undef IN
+#undef ST
+}
+
+}  // namespace qrgpu

@@ -27,6 +27,7 @@ QR_MPC_DECL(9, true)
 QR_MPC_DECL(9, false)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_estimator_kernel(int n, EstimatorDesc D, const float *g_in, const unsigned *g_tick, double *st, float *g_out);
 __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
 __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
                                    float *g_gait, float *g_cmd, int *g_updated);
@@ -449,6 +450,34 @@ int qrgpu_fb_debug_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float 
 {
     if (!d_out) return QRGPU_ERR_BAD_ARG;
     return launch_wbc(c, n, d_type_id, d_fb_state, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, 0, 0);
+}
+
+void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d)
+{
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    d->hip_l = 0.08505f; d->upper_l = 0.2f; d->lower_l = 0.2f;
+    const float ho[12] = {0.1805f, -0.047f, 0.f, 0.1805f, 0.047f, 0.f, -0.1805f, -0.047f, 0.f, -0.1805f, 0.047f, 0.f};
+    memcpy(d->hip_offset, ho, sizeof(ho));
+    d->time_step = 0.002f; d->accelerometer_variance = 0.1f; d->sensor_variance = 0.1f; d->window = 120;
+}
+
+int qrgpu_estimator_state_doubles(int window) { return window > 0 ? 92 + 3 * window : 0; }
+
+int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
+                                 double *d_est_state, float *d_est_out)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !d_est_in || !d_tick || !d_est_state || !d_est_out) return QRGPU_ERR_BAD_ARG;
+    if (desc->window <= 0 || desc->window > 4096) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    EstimatorDesc D;
+    D.hip_l = desc->hip_l; D.upper_l = desc->upper_l; D.lower_l = desc->lower_l;
+    memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset));
+    D.time_step = desc->time_step; D.accelerometer_variance = desc->accelerometer_variance; D.sensor_variance = desc->sensor_variance;
+    D.window = desc->window;
+    hipLaunchKernelGGL(qr_estimator_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_est_in, d_tick, d_est_state, d_est_out);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
 }
 
 void qrgpu_vmc_desc_default(qrgpu_vmc_desc *d)

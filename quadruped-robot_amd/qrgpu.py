@@ -46,6 +46,11 @@ class vmc_desc_struct(C.Structure):
                 ("hip_l", C.c_float), ("upper_l", C.c_float), ("lower_l", C.c_float)]
 
 
+class estimator_desc_struct(C.Structure):
+    _fields_ = [("hip_l", C.c_float), ("upper_l", C.c_float), ("lower_l", C.c_float), ("hip_offset", C.c_float * 12),
+                ("time_step", C.c_float), ("accelerometer_variance", C.c_float), ("sensor_variance", C.c_float), ("window", C.c_int)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libqrgpu.so")
 
@@ -54,7 +59,8 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
-           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass"]
+           "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
+           "qrgpu_estimator_update_batch"]
 
 
 def load_library():
@@ -84,6 +90,9 @@ def load_library():
     lib.qrgpu_vmc_desc_default.argtypes = [C.POINTER(vmc_desc_struct)]; lib.qrgpu_vmc_desc_default.restype = None
     lib.qrgpu_vmc_setup.argtypes = [vp, ip, C.POINTER(vmc_desc_struct)]
     lib.qrgpu_vmc_force_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_estimator_desc_default.argtypes = [C.POINTER(estimator_desc_struct)]; lib.qrgpu_estimator_desc_default.restype = None
+    lib.qrgpu_estimator_state_doubles.argtypes = [ip]
+    lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_vmc_force1.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(ip)]
     lib.qrgpu_mpc_frontend_batch.argtypes = [vp, ip, ip, C.c_float, C.c_float] + [vp] * 6
     lib.qrgpu_fb_debug_batch.argtypes = [vp, ip, vp, vp, vp]
@@ -242,6 +251,18 @@ class Context:
         self._chk(self._lib.qrgpu_vmc_force1(self._h, type_id, _fp(a), _fp(qa) if qa is not None else None, _fp(f),
                                              _fp(tau) if qa is not None else None, C.byref(st)))
         return f, (tau if qa is not None else None), st.value
+
+    def estimator_state_doubles(self, window):
+        return self._lib.qrgpu_estimator_state_doubles(int(window))
+
+    def estimator_update_batch(self, n, cfg19, est_in, tick, est_state, est_out):
+        """UpdateDataFlow kinematics + qrRobotVelocityEstimator::Update of n robots.  cfg19 = workload.estimator_cfg()."""
+        d = estimator_desc_struct()
+        cfg19 = np.asarray(cfg19, np.float32)
+        d.hip_l, d.upper_l, d.lower_l, d.time_step, d.accelerometer_variance, d.sensor_variance = (float(v) for v in cfg19[:6])
+        d.window = int(cfg19[6])
+        for i in range(12): d.hip_offset[i] = float(cfg19[7 + i])
+        self._chk(self._lib.qrgpu_estimator_update_batch(self._h, n, C.byref(d), _dp(est_in), _dp(tick), _dp(est_state), _dp(est_out)))
 
     def mpc_frontend_batch(self, n, fe_in, fe_state, traj, gait, wbc_cmd=None, mpc_updated=None, num_horizon_l=2, dt_ctrl=0.002, dt_mpc=0.06):
         """SetupCommand + Run + UpdateMPC (without the solve) of n robots: qr_mpc_stance_leg_controller.cpp:158-382."""

@@ -281,3 +281,39 @@ def make_vmc_batch(n, robot="a1", seed=0xB2, sloped=0.0, excite=1.0):
             vin[i, 31:34] = Rc.T @ np.array([0, 0, 9.8], f32)
             vin[i, 34:37] = (-s, 0, c)
     return vin, q
+
+
+def estimator_cfg(robot="a1", time_step=0.002, accelerometer_variance=0.1, sensor_variance=0.1, window=120):
+    """Packed velocity-estimator parameters: leg lengths, robot->timeStep, the three user_parameters.yaml values, hip offsets[12]."""
+    r = ROBOTS[robot]
+    return np.array([r["hip_l"], r["upper_l"], r["lower_l"], time_step, accelerometer_variance, sensor_variance, window,
+                     *np.asarray(r["hip_offset"], f32).reshape(-1)], dtype=f32)
+
+
+def make_estimator_sequence(n, ticks, seed=0xE5, dt_ms=2):
+    """Synthetic sensor streams for n robots over `ticks` control ticks: [ticks][n][41] floats + [ticks][n] uint32 millisecond stamps.
+    Layout per tick (include/qrgpu.h est_in): baseAccInBaseFrame[3], baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3], footContact[4],
+    q[12], dq[12].  A slow body motion with noise, trot contacts, a flight phase (no contact) for some robots."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros((ticks, n, 41), f32)
+    stamp = np.zeros((ticks, n), np.uint32)
+    t0 = rng.integers(1, 5000, n)
+    phase0 = rng.uniform(0, 1, n)
+    yaw0 = rng.uniform(-np.pi, np.pi, n)
+    qn = np.tile(np.array([0.0, 0.9, -1.8], f32), (n, 4))
+    for k in range(ticks):
+        t = k * dt_ms * 1e-3
+        rpy = np.stack([0.05 * np.sin(3 * t + phase0), 0.05 * np.cos(2 * t + phase0), yaw0 + 0.3 * t], 1)
+        x[k, :, 6:10] = _quat_from_rpy(rpy)
+        x[k, :, 10:13] = np.stack([0.15 * np.cos(3 * t + phase0), -0.1 * np.sin(2 * t + phase0), 0.3 + 0 * phase0], 1) + 0.02 * rng.standard_normal((n, 3))
+        acc = np.stack([0.5 * np.sin(5 * t + phase0), 0.3 * np.cos(4 * t + phase0), 9.81 + 0.4 * np.sin(7 * t + phase0)], 1)
+        x[k, :, 0:3] = acc + 0.1 * rng.standard_normal((n, 3))
+        x[k, :, 3:6] = acc - np.array([0, 0, 9.81]) + 0.1 * rng.standard_normal((n, 3))
+        ph = (phase0 + t / 0.5) % 1.0
+        c = np.stack([ph < 0.6, (ph + 0.5) % 1 < 0.6, (ph + 0.5) % 1 < 0.6, ph < 0.6], 1).astype(f32)
+        c[(np.arange(n) % 7 == 3) & (k % 40 > 30)] = 0                   # a flight phase: the filter falls back on its own estimate
+        x[k, :, 13:17] = c
+        x[k, :, 17:29] = qn + 0.2 * np.sin(6 * t + phase0)[:, None] * np.array([0.3, 1, -1] * 4, f32) + 0.01 * rng.standard_normal((n, 12))
+        x[k, :, 29:41] = 1.5 * np.cos(6 * t + phase0)[:, None] * np.array([0.3, 1, -1] * 4, f32) + 0.05 * rng.standard_normal((n, 12))
+        stamp[k] = t0 + k * dt_ms + (rng.uniform(0, 1, n) < 0.05)        # an occasional late sample
+    return x, stamp
