@@ -121,6 +121,19 @@ def vmc_golden():
     print("vmc_golden.npz: 48 cases, %d with QuadProg++ returning +inf" % int(np.sum(infs)))
 
 
+def ekf_golden():
+    """States of the reference's TinyEKF<3,3> (compiled from /root/reference) over three 200-step sequences."""
+    rng = np.random.default_rng(4004)
+    out = {}
+    for j, (av, sv) in enumerate(((0.1, 0.1), (0.01, 0.5), (1.0, 0.02))):
+        dv = 0.01 * rng.standard_normal((200, 3)); z = np.cumsum(dv, 0) + 0.05 * rng.standard_normal((200, 3))
+        x, bad = O.ref_tinyekf_run(av, sv, dv, z)
+        assert bad == 0
+        out["var%d" % j] = np.array([av, sv], np.float32); out["dv%d" % j] = dv; out["z%d" % j] = z; out["x%d" % j] = x
+    np.savez_compressed(os.path.join(OUT, "ekf_golden.npz"), **out)
+    print("ekf_golden.npz: 3 sequences x 200 steps")
+
+
 def save(name, rows):
     flat = {"count": np.array([len(rows)])}
     for i, r in enumerate(rows):
@@ -135,4 +148,5 @@ if __name__ == "__main__":
     save("mpc_golden.npz", mpc_cases())
     save("wbc_golden.npz", wbc_cases())
     vmc_golden()
+    ekf_golden()
     save("qp_golden.npz", qp_cases())
