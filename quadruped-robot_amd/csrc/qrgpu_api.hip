@@ -378,7 +378,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
-        const int rgrid = n < (small ? 64 : c->num_cu) ? n : (small ? 64 : c->num_cu);
+        // list capacity served per call: 64 robots (one per CU at h = 16), or a sixteenth of a large batch
+        int rgrid = small ? 64 : c->num_cu;
+        if (n / 16 > rgrid) rgrid = n / 16;
+        if (rgrid > n) rgrid = n;
         static int configured_rescue[2] = {0, 0};
         const void *rfn = small ? (const void *)qr_mpc_kernel<4, false> : (const void *)qr_mpc_kernel<9, false>;
         if (configured_rescue[small ? 0 : 1] < R.lds_bytes) {
