@@ -82,7 +82,8 @@ typedef enum {
  * hold the number of MPC active-set iterations (diagnostic).  Test `(status & 0xff) == 0`. */
 #define QRGPU_ST_OK            0
 #define QRGPU_ST_MPC_MAXITER   0x1    /* active-set iteration cap reached            */
-#define QRGPU_ST_MPC_INFEAS    0x2    /* QP reported infeasible (cannot happen: u=0 is feasible) */
+#define QRGPU_ST_MPC_INFEAS    0x2    /* no feasible step for a violated row, or the solve ended with a row it had set aside as
+                                         dependent violated, or an active row not tight, by more than 1e-4 N: the forces are not the optimum */
 #define QRGPU_ST_MPC_OVERFLOW  0x4    /* working set outgrew its LDS allotment       */
 #define QRGPU_ST_MPC_NOTSPD    0x8    /* Hessian pivot <= 0                          */
 #define QRGPU_ST_WBC_MAXITER   0x10

@@ -122,7 +122,7 @@ template <typename T> Mat<T> luInverse(const Mat<T> &A);
 struct QpStats { int iters = 0, adds = 0, drops = 0, n_active = 0; double obj = 0; };
 int qp_solve_gi(int n, const double *G, const double *g0, int p, const double *CE, const double *ce0,
                 int m, const double *CI, const double *ci0, double *x, double *lambda_ineq /*m or null*/,
-                QpStats *st, int max_iter = 0);
+                QpStats *st, int max_iter = 0, double abs_tol = 0.0);
 
 // ---------------------------------------------------------------------------
 // MPC (K1-K7).  QS/controllers/mpc/qr_mpc_interface.cpp, qr_mpc_stance_leg_controller.cpp

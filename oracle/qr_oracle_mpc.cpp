@@ -16,10 +16,18 @@
 // evaluates them with Eigen's fp32 Pade expm and repeated products
 // (qr_mpc_interface.cpp:257-293), whose rounding cannot be reproduced without
 // Eigen; mpc_assemble_literal() below restates that route to bound the gap.
+#include <cstdlib>
 #include "qr_oracle.h"
 #include <algorithm>
 
 namespace qro {
+
+// Stopping threshold on the constraint slack of the MPC QP (0 = QuadProg++'s psi rule); QRO_MPC_ABS_TOL overrides for experiments.
+static double mpc_abs_tol()
+{
+    static const double v = [] { const char *e = std::getenv("QRO_MPC_ABS_TOL"); return e ? std::atof(e) : 1e-9; }();
+    return v;
+}
 
 namespace {
 
@@ -362,7 +370,7 @@ int mpc_solve_qp(const MpcAssembly &a, const float *gait, int horizon, double *u
         set(2, 4, 1.0);                      //  fz >= 0
         set(2, 5, -1.0); ci0[c0 + 5] = (double)a.ub[5 * legstep + 4];   // fz <= gait*fMax
     }
-    int rc = qp_solve_gi(ns, G.data(), g0.data(), 0, nullptr, nullptr, m, CI.data(), ci0.data(), x.data(), nullptr, st);
+    int rc = qp_solve_gi(ns, G.data(), g0.data(), 0, nullptr, nullptr, m, CI.data(), ci0.data(), x.data(), nullptr, st, 0, mpc_abs_tol());
     for (int i = 0; i < ns; ++i) u_out[idx[i]] = x[i];
     return rc;
 }

@@ -114,7 +114,7 @@ struct GI {
 }  // namespace
 
 int qp_solve_gi(int n, const double *G, const double *g0, int p, const double *CE, const double *ce0,
-                int m, const double *CI, const double *ci0, double *x, double *lambda_ineq, QpStats *st, int max_iter)
+                int m, const double *CI, const double *ci0, double *x, double *lambda_ineq, QpStats *st, int max_iter, double abs_tol)
 {
     const double inf = std::numeric_limits<double>::infinity();
     const double eps = std::numeric_limits<double>::epsilon();
@@ -194,7 +194,10 @@ int qp_solve_gi(int n, const double *G, const double *g0, int p, const double *C
             psi += std::min(0.0, v);
             if (!active[i] && !excluded[i] && v < smin) { smin = v; ip = i; }
         }
-        if (ip < 0 || std::fabs(psi) <= m * eps * c1 * c2 * 100.0) break;
+        // QuadProg++'s stopping rule (sum of violations against an estimate of cond(G)); abs_tol > 0 replaces it by "no row
+        // violated by more than abs_tol" (the MPC QP, whose 1/(2 alpha) = 1.25e5 turns 1e-7 of slack into 1e-2 N of force)
+        if (abs_tol > 0.0) { if (ip < 0 || smin >= -abs_tol) break; }
+        else if (ip < 0 || std::fabs(psi) <= m * eps * c1 * c2 * 100.0) break;
 
         // Step 2: add ip, possibly dropping blocking constraints on the way.
         for (int k = 0; k < n; ++k) s.np[k] = CI[(size_t)k * m + ip];

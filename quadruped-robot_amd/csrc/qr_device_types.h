@@ -58,6 +58,7 @@ struct MpcLaunch {
     // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
     const int *lpt_cost_in;
     int *lpt_order_out;
+    int no_wcache;              // diagnostic (QRGPU_NO_WCACHE=1): always take the z = w - M (N_A r) form
 };
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.

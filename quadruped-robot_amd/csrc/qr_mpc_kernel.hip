@@ -422,14 +422,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
     int qW = 0;
     double *Wc = nullptr;
-    const int nsp = ns | 1;             // row stride of the cache: an odd number of doubles, so that one column block read by 64 rows
-                                        // (the d above) spreads over all LDS banks
+    const int nsp = ns | 1;             // row stride of the cache (odd number of doubles)
     if constexpr (MULTI) {
         const int qs = qcap < 64 ? qcap : 64;
         const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs);
         Wc = Sinv + tri(qs);
         if (rem > 0 && ns > 0) qW = (int)(rem / (ns | 1));
         if (qW > 64) qW = 64;
+        if (P.no_wcache == 1) qW = 0;
     }
     int st = 0;
     if (npairs > MAXB * QR_MPC_THREADS) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
@@ -642,7 +642,23 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
             }
             const double smin = wave_min_d(bs);
-            if (!(smin < -tol)) break;
+            if (!(smin < -tol)) {
+                // Rows left out as dependent are combinations of active rows and hold with them -- unless the exclusion was a
+                // numerical accident (seen at twice SURVEY 8d's ranges after ~1000 iterations): then this point is not the optimum.
+                // Likewise an active row must be tight: the updates keep x = x0 + M N u whatever r was, but a drifted S^-1 lets
+                // active rows slip, and those are not scanned.  Either residual beyond 1e-4 N (a tenth of the force tolerance at 100 N) flags the robot.
+                double be = 0.0;
+                if (own && (xmask | amask)) {
+                    const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        if (((xmask >> t) & 1u) && s[t] < be) be = s[t];
+                        if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
+                    }
+                }
+                if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
+                break;
+            }
             const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
             const int tp = __builtin_amdgcn_readlane(bt, kp);
             double c0, c1, c2;
@@ -665,15 +681,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 // d = N' w : position i needs w of leg-step ck(i)
                 double dq = 0.0;
                 {
-                    if (fastz) {
-                        // d_i = c_i' M(k_i, kp) c_p = c_p' (W_A row i)(kp): three LDS doubles per position, independent of the load of w
-                        if (lane < q) { const double *wr = Wc + lane * nsp + 3 * kp; dq = c0 * wr[0] + c1 * wr[1] + c2 * wr[2]; }
-                    } else {
-                        double a0, a1, a2;
-                        cons_vec(ct, im, a0, a1, a2);
-                        const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
-                        if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
-                    }
+                    // (taking d from the W_A cache instead -- c_p' (W_A row i)(kp) -- is the same number in exact arithmetic but rounds
+                    // differently from delta; for a row that is dependent on active rows of its own leg-step the cancellation in
+                    // z'c = delta - d'r is then no longer exact, and one robot in 36 864 ended 8e-4 N off: scratch/diag_outlier.py)
+                    double a0, a1, a2;
+                    cons_vec(ct, im, a0, a1, a2);
+                    const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
+                    if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
                 }
                 QM_STAMP(1);
                 // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
@@ -810,9 +824,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 if (full) {
                     // full step: the row joined the working set at position q (S^-1 already updated above)
                     if (fastz) {
-                        // every wave stores the (identical) row: a wave then reads back its own store in the next iteration's d
-                        // without waiting for a barrier
-                        if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
+                        if (q < qW) { if (wv == 0 && own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
                         else fastz = false;
                     }
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
@@ -841,7 +853,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (wv == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
                         __syncthreads();
                         if (wv == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
-                        if (fastz && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
+                        if (fastz && wv == 0 && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
                         const double ulast = readlane_d(uq, last);
                         if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
                     }
@@ -910,7 +922,19 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
         }
         const double smin = wave_min_d(bs);
-        if (!(smin < -tol)) break;
+        if (!(smin < -tol)) {
+            double be = 0.0;                           // as in the four-wave path: excluded rows hold, active rows are tight
+            if (own && (xmask | amask)) {
+                const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    if (((xmask >> t) & 1u) && s[t] < be) be = s[t];
+                    if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
+                }
+            }
+            if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
+            break;
+        }
         const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
         const int tp = __builtin_amdgcn_readlane(bt, kp);
         const int p = 6 * kp + tp;

@@ -349,6 +349,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
+    { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave> (QRGPU_H16_MULTI=1), 2 = <9, single-wave>
     const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
     static int configured_lds[3] = {0, 0, 0};
