@@ -56,6 +56,8 @@ struct qrgpu_ctx {
     int *d_st1 = nullptr;
     int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
+    int configured_lds[3] = {0, 0, 0};     // dynamic-LDS limit already set on this context's device, per kernel variant
+    int configured_rescue[2] = {0, 0};
     int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
     int rescue_parity = 0;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
@@ -352,11 +354,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave> (QRGPU_H16_MULTI=1), 2 = <9, single-wave>
     const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
-    static int configured_lds[3] = {0, 0, 0};
     const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true> : var == 1 ? (const void *)qr_mpc_kernel<9, true> : (const void *)qr_mpc_kernel<9, false>;
-    if (configured_lds[var] < P.lds_bytes) {
+    if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
-        configured_lds[var] = P.lds_bytes;
+        c->configured_lds[var] = P.lds_bytes;
     }
     {
         TimerScope ts(c, 0);
@@ -383,11 +384,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         int rgrid = small ? 64 : c->num_cu;
         if (n / 16 > rgrid) rgrid = n / 16;
         if (rgrid > n) rgrid = n;
-        static int configured_rescue[2] = {0, 0};
         const void *rfn = small ? (const void *)qr_mpc_kernel<4, false> : (const void *)qr_mpc_kernel<9, false>;
-        if (configured_rescue[small ? 0 : 1] < R.lds_bytes) {
+        if (c->configured_rescue[small ? 0 : 1] < R.lds_bytes) {
             HIPCHK(c, hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
-            configured_rescue[small ? 0 : 1] = R.lds_bytes;
+            c->configured_rescue[small ? 0 : 1] = R.lds_bytes;
         }
         if (small)
             hipLaunchKernelGGL((qr_mpc_kernel<4, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
