@@ -19,8 +19,9 @@
  *   qrgpu_vmc_setup / qrgpu_vmc_force_batch <- Quadruped::ComputeContactForce (control-frame overload) + qrRobot::MapContactForceToJointTorques
  *                             QS/controllers/balance_controller/qr_qp_torque_optimizer.cpp:190-301, QS/robots/qr_robot.cpp:241-251
  *                             (what TorqueStanceLegController::GetAction calls, qr_torque_stance_leg_controller.cpp:500-507)
- *   qrgpu_estimator_update_batch <- qrRobot::UpdateDataFlow (leg kinematics) + qrRobotVelocityEstimator::Update
- *                             QS/robots/qr_robot.cpp:62-72,187-197, QS/estimators/qr_robot_velocity_estimator.cpp:77-133
+ *   qrgpu_estimator_update_batch <- qrRobot::UpdateDataFlow (leg kinematics) + qrRobotVelocityEstimator::Update + qrRobotPoseEstimator::Update
+ *                             QS/robots/qr_robot.cpp:62-72,187-197, QS/estimators/qr_robot_velocity_estimator.cpp:77-133,
+ *                             QS/estimators/qr_robot_pose_estimator.cpp:68-165 (qrRobotEstimator::Update, qr_robot_estimator.cpp:79-83)
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
  *
@@ -46,10 +47,12 @@
  *   tau       [12][n] : joint torques
  *   vmc_in    [37][n] : force-balance QP inputs: footPositionsInBaseFrame[12] (3*leg+axis), desiredAcc[6], contacts[4],
  *                       Rcb[9] (row-major; identity on PLANE / PLUM_PILES terrain), g.head(3) ((0,0,9.8) on a plane), surfaceNormal[3]
- *   est_in    [41][n] : velocity-estimator inputs: baseAccInBaseFrame[3], baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3],
- *                       footContact[4], motor angles q[12], motor velocities dq[12]
- *   est_out   [36][n] : filtered baseLinearAcceleration[3], baseVInWorldFrame[3], baseVelocityInBaseFrame[3], baseWInWorldFrame[3],
- *                       footPositionsInBaseFrame[12], footVelocitiesInBaseFrame[12] (3*leg+axis)
+ *   est_in    [54][n] : estimator inputs: baseAccInBaseFrame[3], baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3], footContact[4],
+ *                       motor angles q[12], motor velocities dq[12], desiredLegState[4] (LegState values), groundOrientationMat[9]
+ *                       (GetAlignedDirections, row-major; identity on a plane)
+ *   est_out   [42][n] : filtered baseLinearAcceleration[3], baseVInWorldFrame[3], baseVelocityInBaseFrame[3], baseWInWorldFrame[3],
+ *                       footPositionsInBaseFrame[12], footVelocitiesInBaseFrame[12] (3*leg+axis), basePosition[3] (odometry x, y and
+ *                       the stance-foot height), heightInControlFrame (NaN = unchanged: no stance foot), absoluteHight, odometry yaw
  *   fe_in     [64][n] : front-end inputs per control tick: des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd
  *                       (stateDes 2,3,4,6,7,11 after UpdateDesCommand), basePosition[3], yaw, quat_wxyz[4], footPosWorld[12]
  *                       (leg-major), footTargetPositionsInWorldFrame[12], contacts[4], phaseInFullCycle[4], dutyFactor[4],
@@ -175,7 +178,8 @@ int qrgpu_vmc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_vmc_desc *desc);
 int qrgpu_vmc_force_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q /*[12][n], may be NULL*/,
                           float *d_force, float *d_tau /*may be NULL*/, int *d_status /*may be NULL*/);
 
-/* Base velocity estimator (TinyEKF<3,3> + moving-window filters) and the leg kinematics it reads, for n robots and one control tick.
+/* Base velocity estimator (TinyEKF<3,3> + moving-window filters), the leg kinematics it reads and the pose estimator that follows it
+ * (stance-foot height, planar odometry), for n robots and one control tick.
  * d_est_state is the estimators' memory: qrgpu_estimator_state_doubles(window) doubles per robot, [field][robot], zero = freshly
  * constructed / Reset() (qr_robot_velocity_estimator.cpp:29-60).  d_tick: robot->GetTick() in milliseconds.  All robots share `desc`. */
 typedef struct {
@@ -184,6 +188,7 @@ typedef struct {
     float time_step;                      /* robot->timeStep, used for the first sample */
     float accelerometer_variance, sensor_variance;   /* user_parameters.yaml: 0.1, 0.1 */
     int window;                           /* movingWindowFilterSize: 120 */
+    float body_height;                    /* robot->bodyHeight, the height reported while no foot is in stance */
 } qrgpu_estimator_desc;
 void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d);
 int qrgpu_estimator_state_doubles(int window);

@@ -265,9 +265,10 @@ def ref_tinyekf_run(acc_var, sensor_var, deltaV, z):
     return out, bad
 
 
-def estimator_run(cfg19, in41, tick):
-    """A sequence of velocity-estimator updates of one robot from a fresh estimator.  in41 [T][41], tick [T] (ms) -> out [T][36]"""
-    a = np.ascontiguousarray(in41, _f); t = np.ascontiguousarray(tick, np.uint32)
-    out = np.zeros((a.shape[0], 36), _f)
-    lib().qro_estimator_run(_fp(np.ascontiguousarray(cfg19, _f)), a.shape[0], _fp(a), t.ctypes.data_as(C.c_void_p), _fp(out))
+def estimator_run(cfg20, in54, tick):
+    """A sequence of velocity + pose estimator updates of one robot from fresh estimators.  in54 [T][54], tick [T] (ms) -> out [T][42]"""
+    a = np.ascontiguousarray(in54, _f); t = np.ascontiguousarray(tick, np.uint32)
+    assert a.shape[1] == 54
+    out = np.zeros((a.shape[0], 42), _f)
+    lib().qro_estimator_run(_fp(np.ascontiguousarray(cfg20, _f)), a.shape[0], _fp(a), t.ctypes.data_as(C.c_void_p), _fp(out))
     return out

@@ -220,17 +220,19 @@ struct EstimatorConfig {
     float time_step = 0.002f;                      // robot->timeStep
     float accelerometer_variance = 0.1f, sensor_variance = 0.1f;
     int window = 60;                               // movingWindowFilterSize
+    float body_height = 0.28f;                     // robot->bodyHeight (all feet in the air)
 };
 struct EstimatorState {
     unsigned last_timestamp = 0;
     double x[3] = {0, 0, 0}, P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float est_vel_base[3] = {0, 0, 0};
+    float pose_x = 0, pose_y = 0, pose_theta = 0, abs_height = 0;     // qrRobotPoseEstimator: estimatedPose[0,1,5], robot->absoluteHight
     std::vector<double> vel_win[3]; double vel_sum[3] = {0, 0, 0}, vel_corr[3] = {0, 0, 0}; int vel_count = 0, vel_head = 0;
     float acc_win[3][20]; float acc_sum[3] = {0, 0, 0}, acc_corr[3] = {0, 0, 0}; int acc_count = 0, acc_head = 0;
     explicit EstimatorState(int W) { for (auto &w : vel_win) w.assign(W, 0.0); std::memset(acc_win, 0, sizeof(acc_win)); }
 };
 int ekf3_step(double x[3], double P[9], double qvar, double rvar, const double deltaV[3], const double z[3]);
-void estimator_update(const EstimatorConfig &cfg, const float in[41], unsigned tick, EstimatorState &s, float out[36]);
+void estimator_update(const EstimatorConfig &cfg, const float in[54], unsigned tick, EstimatorState &s, float out[42]);
 
 // ---------------------------------------------------------------------------
 // MPC front-end.  qr_oracle_frontend.cpp

@@ -3,6 +3,8 @@
 // Base velocity estimator + the leg kinematics it reads (first part):
 //   qrRobot::UpdateDataFlow                  QS/robots/qr_robot.cpp:62-72  (foot Jacobians, foot positions / velocities in the base frame)
 //   qrRobotVelocityEstimator::Update         QS/estimators/qr_robot_velocity_estimator.cpp:77-133
+//   qrRobotPoseEstimator::Update             QS/estimators/qr_robot_pose_estimator.cpp:68-165 (height from the stance feet, planar odometry;
+//                                            called right after the velocity estimator, qr_robot_estimator.cpp:81-82)
 //   qrMovingWindowFilter (Neumaier sums)     QI/estimators/qr_moving_window_filter.hpp:150-186, 236-263
 //   TinyEKF<3,3>::model / ekf_step           QX/TinyEKF/src/TinyEKF.h:103-124, QX/TinyEKF/src/tiny_ekf.c:292-332 (+ cholsl :17-93)
 // The Kalman step is restated operation by operation (same loops, same accumulation order) and pinned against the reference's own
@@ -97,11 +99,11 @@ static T window_average(T *win, int W, int &count, int &head, T &sum, T &corr, T
     return (sum + corr) / (T)(len + 1);
 }
 
-// in[45]: sensorAcc[3] (baseAccInBaseFrame), baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3], footContact[4], q[12], dq[12],
-//         then tick (ms, as float64 to stay exact) is passed separately.
-// state: EstimatorState (below).  out[36]: filteredAcc[3], baseVInWorldFrame[3], baseVelocityInBaseFrame[3], baseWInWorldFrame[3],
-//         footPositionsInBaseFrame[12], footVelocitiesInBaseFrame[12].
-void estimator_update(const EstimatorConfig &cfg, const float in[41], unsigned tick, EstimatorState &s, float out[36])
+// in[54]: sensorAcc[3] (baseAccInBaseFrame), baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3], footContact[4], q[12], dq[12],
+//         desiredLegState[4], groundOrientationMat[9] (GetAlignedDirections, row-major; identity on a plane); tick (ms) separately.
+// out[42]: filteredAcc[3], baseVInWorldFrame[3], baseVelocityInBaseFrame[3], baseWInWorldFrame[3], footPositionsInBaseFrame[12],
+//         footVelocitiesInBaseFrame[12], basePosition[3], heightInControlFrame, absoluteHight, estimatedPose yaw.
+void estimator_update(const EstimatorConfig &cfg, const float in[54], unsigned tick, EstimatorState &s, float out[42])
 {
     const float *sensorAcc = in, *linAcc = in + 3, *quat = in + 6, *rpyRate = in + 10, *contact = in + 13, *q = in + 17, *dq = in + 29;
     // UpdateDataFlow: foot Jacobians, velocities, positions in the base frame (:62-72, :187-197)
@@ -170,6 +172,38 @@ void estimator_update(const EstimatorConfig &cfg, const float in[41], unsigned t
         out[9 + i] = R[i][0] * rpyRate[0] + R[i][1] * rpyRate[1] + R[i][2] * rpyRate[2];
     }
     for (int i = 0; i < 12; ++i) { out[12 + i] = footP[i]; out[24 + i] = footV[i]; }
+
+    // ---- qrRobotPoseEstimator::Update (its own lastTimestamp sees the same ticks: same deltaTime)
+    const float *desLeg = in + 41, *gm = in + 45;
+    int nct = 0;
+    for (int leg = 0; leg < 4; ++leg) nct += ((int)desLeg[leg] == 1 /*STANCE*/) ? 1 : 0;
+    float height, hctrl = 0.f;
+    if (nct == 0) { height = cfg.body_height; hctrl = std::nanf(""); }      // heightInControlFrame is left as it was (:103-105)
+    else {
+        float hs = 0.f, hc = 0.f;
+        for (int leg = 0; leg < 4; ++leg) {
+            const float *p = footP + 3 * leg;
+            float w[3];
+            for (int i = 0; i < 3; ++i) w[i] = R[i][0] * p[0] + R[i][1] * p[1] + R[i][2] * p[2];              // rotMat * footPositions
+            const float cz = gm[2] * w[0] + gm[5] * w[1] + gm[8] * w[2];                                         // row 2 of groundOrientationMat^T
+            const float c = ((int)desLeg[leg] == 1) ? 1.f : 0.f;
+            hc += (-cz) * c;
+            hs += (-w[2]) * c;
+        }
+        hctrl = hc / nct;
+        height = hs / nct;
+    }
+    {   // ComputePose (:137-165): planar odometry with the base-frame velocity the velocity estimator has just left behind
+        const float vX = s.est_vel_base[0], vY = s.est_vel_base[1], vZ = s.est_vel_base[2], vTheta = rpyRate[2];
+        const float theta = s.pose_theta;
+        const float deltaX = (vX * std::cos((double)theta) - vY * std::sin((double)theta)) * deltaTime;
+        const float deltaY = (vX * std::sin((double)theta) + vY * std::cos((double)theta)) * deltaTime;
+        const float deltaTheta = vTheta * deltaTime;
+        s.pose_x += deltaX; s.pose_y += deltaY;
+        s.abs_height += vZ * deltaTime;
+        s.pose_theta = theta + deltaTheta;
+    }
+    out[36] = s.pose_x; out[37] = s.pose_y; out[38] = height; out[39] = hctrl; out[40] = s.abs_height; out[41] = s.pose_theta;
 }
 
 }  // namespace qro
@@ -185,15 +219,16 @@ int qro_ekf3_run(double qvar, double rvar, int nsteps, const double *deltaV, con
     }
     return bad;
 }
-// A sequence of nticks updates of ONE robot from a fresh estimator: in [nticks][41], tick [nticks], out [nticks][36].
-// cfg9: hip_l, upper_l, lower_l, time_step, accelerometerVariance, sensorVariance, window, then hip_offset[12].
+// A sequence of nticks updates of ONE robot from a fresh estimator: in [nticks][54], tick [nticks], out [nticks][42].
+// cfg20: hip_l, upper_l, lower_l, time_step, accelerometerVariance, sensorVariance, window, hip_offset[12], body_height.
 void qro_estimator_run(const float *cfg, int nticks, const float *in, const unsigned *tick, float *out)
 {
     qro::EstimatorConfig c;
     c.hip_l = cfg[0]; c.upper_l = cfg[1]; c.lower_l = cfg[2]; c.time_step = cfg[3]; c.accelerometer_variance = cfg[4]; c.sensor_variance = cfg[5];
     c.window = (int)cfg[6];
     for (int i = 0; i < 12; ++i) c.hip_offset[i] = cfg[7 + i];
+    c.body_height = cfg[19];
     qro::EstimatorState s(c.window);
-    for (int k = 0; k < nticks; ++k) qro::estimator_update(c, in + 41 * k, tick[k], s, out + 36 * k);
+    for (int k = 0; k < nticks; ++k) qro::estimator_update(c, in + 54 * k, tick[k], s, out + 42 * k);
 }
 }

@@ -80,6 +80,7 @@ struct EstimatorDesc {
     float hip_offset[12];
     float time_step, accelerometer_variance, sensor_variance;
     int window;
+    float body_height;
 };
 
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).

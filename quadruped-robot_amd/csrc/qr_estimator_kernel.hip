@@ -2,6 +2,7 @@
 // Base velocity estimator + the leg kinematics it reads, one thread per robot (first part):
 //   qrRobot::UpdateDataFlow              quadruped/src/robots/qr_robot.cpp:62-72, 187-197   (foot Jacobians, positions, velocities)
 //   qrRobotVelocityEstimator::Update     quadruped/src/estimators/qr_robot_velocity_estimator.cpp:77-133
+//   qrRobotPoseEstimator::Update         quadruped/src/estimators/qr_robot_pose_estimator.cpp:68-165   (stance-foot height, planar odometry)
 //   qrMovingWindowFilter                 quadruped/include/quadruped/estimators/qr_moving_window_filter.hpp:150-186, 236-263
 //   TinyEKF<3,3>                         quadruped/extern/TinyEKF/src/TinyEKF.h:103-124, tiny_ekf.c:17-93, 292-332
 // A streaming kernel with per-robot memory: the Kalman state, the two Neumaier window sums and their ring buffers live in a
@@ -103,8 +104,9 @@ template <typename T> __device__ __forceinline__ void neumaier(T &sum, T &corr, 
 #define EST_ACORR 27
 #define EST_ACNT 30
 #define EST_AHEAD 31
-#define EST_AWIN 32
-#define EST_VWIN 92
+#define EST_POSE 32          /* x, y, theta, absoluteHight */
+#define EST_AWIN 36
+#define EST_VWIN 96
 
 __global__ void __launch_bounds__(64) qr_estimator_kernel(int n, EstimatorDesc D, const float *__restrict__ g_in, const unsigned *__restrict__ g_tick,
                                                           double *__restrict__ st, float *__restrict__ g_out)
@@ -266,6 +268,38 @@ __global__ void __launch_bounds__(64) qr_estimator_kernel(int n, EstimatorDesc D
     }
 #pragma unroll
     for (int r = 0; r < 12; ++r) { g_out[(size_t)(12 + r) * N + i] = footP[r]; g_out[(size_t)(24 + r) * N + i] = footV[r]; }
+    // ---- qrRobotPoseEstimator::Update (:68-165): same ticks, hence the same deltaTime
+    {
+        int nct = 0;
+        float hs = 0.f, hc = 0.f;
+        const float g2 = IN(47), g5 = IN(50), g8 = IN(53);            // third column of groundOrientationMat = row 2 of its transpose
+#pragma unroll
+        for (int leg = 0; leg < 4; ++leg) {
+            const bool st_ = (int)IN(41 + leg) == 1;                    // LegState::STANCE
+            const float p0 = footP[3 * leg], p1 = footP[3 * leg + 1], p2 = footP[3 * leg + 2];
+            float w[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) w[r] = R[r][0] * p0 + R[r][1] * p1 + R[r][2] * p2;
+            const float cz = g2 * w[0] + g5 * w[1] + g8 * w[2];
+            const float c = st_ ? 1.f : 0.f;
+            hc += (-cz) * c;
+            hs += (-w[2]) * c;
+            nct += st_ ? 1 : 0;
+        }
+        const float height = nct ? hs / (float)nct : D.body_height;
+        const float hctrl = nct ? hc / (float)nct : __builtin_nanf("");
+        const float vX = (float)ST(EST_VB), vY = (float)ST(EST_VB + 1), vZ = (float)ST(EST_VB + 2);
+        const float theta = (float)ST(EST_POSE + 2);
+        const double ct = cos((double)theta), sn = sin((double)theta);
+        const float deltaX = (float)(((double)vX * ct - (double)vY * sn) * (double)deltaTime);
+        const float deltaY = (float)(((double)vX * sn + (double)vY * ct) * (double)deltaTime);
+        const float px = (float)ST(EST_POSE) + deltaX, py = (float)ST(EST_POSE + 1) + deltaY;
+        const float ah = (float)ST(EST_POSE + 3) + vZ * deltaTime;
+        const float th = theta + wz * deltaTime;
+        ST(EST_POSE) = (double)px; ST(EST_POSE + 1) = (double)py; ST(EST_POSE + 2) = (double)th; ST(EST_POSE + 3) = (double)ah;
+        g_out[(size_t)36 * N + i] = px; g_out[(size_t)37 * N + i] = py; g_out[(size_t)38 * N + i] = height;
+        g_out[(size_t)39 * N + i] = hctrl; g_out[(size_t)40 * N + i] = ah; g_out[(size_t)41 * N + i] = th;
+    }
 #undef IN
 #undef ST
 }

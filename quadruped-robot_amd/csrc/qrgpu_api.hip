@@ -463,10 +463,10 @@ void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d)
     d->hip_l = 0.08505f; d->upper_l = 0.2f; d->lower_l = 0.2f;
     const float ho[12] = {0.1805f, -0.047f, 0.f, 0.1805f, 0.047f, 0.f, -0.1805f, -0.047f, 0.f, -0.1805f, 0.047f, 0.f};
     memcpy(d->hip_offset, ho, sizeof(ho));
-    d->time_step = 0.002f; d->accelerometer_variance = 0.1f; d->sensor_variance = 0.1f; d->window = 120;
+    d->time_step = 0.002f; d->accelerometer_variance = 0.1f; d->sensor_variance = 0.1f; d->window = 120; d->body_height = 0.28f;
 }
 
-int qrgpu_estimator_state_doubles(int window) { return window > 0 ? 92 + 3 * window : 0; }
+int qrgpu_estimator_state_doubles(int window) { return window > 0 ? 96 + 3 * window : 0; }
 
 int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out)
@@ -478,7 +478,7 @@ int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc
     D.hip_l = desc->hip_l; D.upper_l = desc->upper_l; D.lower_l = desc->lower_l;
     memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset));
     D.time_step = desc->time_step; D.accelerometer_variance = desc->accelerometer_variance; D.sensor_variance = desc->sensor_variance;
-    D.window = desc->window;
+    D.window = desc->window; D.body_height = desc->body_height;
     hipLaunchKernelGGL(qr_estimator_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_est_in, d_tick, d_est_state, d_est_out);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;

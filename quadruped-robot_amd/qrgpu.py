@@ -48,7 +48,8 @@ class vmc_desc_struct(C.Structure):
 
 class estimator_desc_struct(C.Structure):
     _fields_ = [("hip_l", C.c_float), ("upper_l", C.c_float), ("lower_l", C.c_float), ("hip_offset", C.c_float * 12),
-                ("time_step", C.c_float), ("accelerometer_variance", C.c_float), ("sensor_variance", C.c_float), ("window", C.c_int)]
+                ("time_step", C.c_float), ("accelerometer_variance", C.c_float), ("sensor_variance", C.c_float), ("window", C.c_int),
+                ("body_height", C.c_float)]
 
 
 def lib_path():
@@ -255,13 +256,13 @@ class Context:
     def estimator_state_doubles(self, window):
         return self._lib.qrgpu_estimator_state_doubles(int(window))
 
-    def estimator_update_batch(self, n, cfg19, est_in, tick, est_state, est_out):
-        """UpdateDataFlow kinematics + qrRobotVelocityEstimator::Update of n robots.  cfg19 = workload.estimator_cfg()."""
+    def estimator_update_batch(self, n, cfg20, est_in, tick, est_state, est_out):
+        """UpdateDataFlow kinematics + qrRobotVelocityEstimator::Update of n robots.  cfg20 = workload.estimator_cfg()."""
         d = estimator_desc_struct()
-        cfg19 = np.asarray(cfg19, np.float32)
-        d.hip_l, d.upper_l, d.lower_l, d.time_step, d.accelerometer_variance, d.sensor_variance = (float(v) for v in cfg19[:6])
-        d.window = int(cfg19[6])
-        for i in range(12): d.hip_offset[i] = float(cfg19[7 + i])
+        cfg20 = np.asarray(cfg20, np.float32)
+        d.hip_l, d.upper_l, d.lower_l, d.time_step, d.accelerometer_variance, d.sensor_variance = (float(v) for v in cfg20[:6])
+        d.window = int(cfg20[6]); d.body_height = float(cfg20[19])
+        for i in range(12): d.hip_offset[i] = float(cfg20[7 + i])
         self._chk(self._lib.qrgpu_estimator_update_batch(self._h, n, C.byref(d), _dp(est_in), _dp(tick), _dp(est_state), _dp(est_out)))
 
     def mpc_frontend_batch(self, n, fe_in, fe_state, traj, gait, wbc_cmd=None, mpc_updated=None, num_horizon_l=2, dt_ctrl=0.002, dt_mpc=0.06):

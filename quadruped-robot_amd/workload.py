@@ -283,19 +283,23 @@ def make_vmc_batch(n, robot="a1", seed=0xB2, sloped=0.0, excite=1.0):
     return vin, q
 
 
-def estimator_cfg(robot="a1", time_step=0.002, accelerometer_variance=0.1, sensor_variance=0.1, window=120):
-    """Packed velocity-estimator parameters: leg lengths, robot->timeStep, the three user_parameters.yaml values, hip offsets[12]."""
+def estimator_cfg(robot="a1", time_step=0.002, accelerometer_variance=0.1, sensor_variance=0.1, window=120, body_height=0.28):
+    """Packed estimator parameters: leg lengths, robot->timeStep, the three user_parameters.yaml values, hip offsets[12], robot->bodyHeight."""
     r = ROBOTS[robot]
     return np.array([r["hip_l"], r["upper_l"], r["lower_l"], time_step, accelerometer_variance, sensor_variance, window,
-                     *np.asarray(r["hip_offset"], f32).reshape(-1)], dtype=f32)
+                     *np.asarray(r["hip_offset"], f32).reshape(-1), body_height], dtype=f32)
 
 
 def make_estimator_sequence(n, ticks, seed=0xE5, dt_ms=2):
-    """Synthetic sensor streams for n robots over `ticks` control ticks: [ticks][n][41] floats + [ticks][n] uint32 millisecond stamps.
+    """Synthetic sensor streams for n robots over `ticks` control ticks: [ticks][n][54] floats + [ticks][n] uint32 millisecond stamps.
     Layout per tick (include/qrgpu.h est_in): baseAccInBaseFrame[3], baseLinearAcceleration[3], quat_wxyz[4], rpyRate[3], footContact[4],
-    q[12], dq[12].  A slow body motion with noise, trot contacts, a flight phase (no contact) for some robots."""
+    q[12], dq[12], desiredLegState[4], groundOrientationMat[9].  A slow body motion with noise, trot contacts, a flight phase (no
+    contact) for some robots, a pitched ground frame for every fifth robot."""
     rng = np.random.default_rng(seed)
-    x = np.zeros((ticks, n, 41), f32)
+    x = np.zeros((ticks, n, 54), f32)
+    gpitch = np.where(np.arange(n) % 5 == 2, 0.2, 0.0)
+    gmat = np.zeros((n, 9), f32)
+    gmat[:, 0] = np.cos(gpitch); gmat[:, 2] = np.sin(gpitch); gmat[:, 4] = 1; gmat[:, 6] = -np.sin(gpitch); gmat[:, 8] = np.cos(gpitch)
     stamp = np.zeros((ticks, n), np.uint32)
     t0 = rng.integers(1, 5000, n)
     phase0 = rng.uniform(0, 1, n)
@@ -313,6 +317,8 @@ def make_estimator_sequence(n, ticks, seed=0xE5, dt_ms=2):
         c = np.stack([ph < 0.6, (ph + 0.5) % 1 < 0.6, (ph + 0.5) % 1 < 0.6, ph < 0.6], 1).astype(f32)
         c[(np.arange(n) % 7 == 3) & (k % 40 > 30)] = 0                   # a flight phase: the filter falls back on its own estimate
         x[k, :, 13:17] = c
+        x[k, :, 41:45] = c                                               # desiredLegState: STANCE = 1, SWING = 0
+        x[k, :, 45:54] = gmat
         x[k, :, 17:29] = qn + 0.2 * np.sin(6 * t + phase0)[:, None] * np.array([0.3, 1, -1] * 4, f32) + 0.01 * rng.standard_normal((n, 12))
         x[k, :, 29:41] = 1.5 * np.cos(6 * t + phase0)[:, None] * np.array([0.3, 1, -1] * 4, f32) + 0.05 * rng.standard_normal((n, 12))
         stamp[k] = t0 + k * dt_ms + (rng.uniform(0, 1, n) < 0.05)        # an occasional late sample

@@ -16,9 +16,9 @@ def test_estimator_sequence_parity(gpu_ctx, pkg, oracle, window, ticks):
     cfg = W.estimator_cfg("a1", window=window)
     x, stamp = W.make_estimator_sequence(n, ticks, seed=window)
     S = gpu_ctx.estimator_state_doubles(window)
-    assert S == 92 + 3 * window
+    assert S == 96 + 3 * window
     d_state = gpu_ctx.alloc((S, n), np.float64).upload(np.zeros((S, n)))
-    d_in = gpu_ctx.alloc((41, n)); d_tick = gpu_ctx.alloc((n,), np.uint32); d_out = gpu_ctx.alloc((36, n))
+    d_in = gpu_ctx.alloc((54, n)); d_tick = gpu_ctx.alloc((n,), np.uint32); d_out = gpu_ctx.alloc((42, n))
     outs = []
     for k in range(ticks):
         d_in.upload(pkg.to_soa(x[k])); d_tick.upload(stamp[k])
@@ -34,5 +34,7 @@ def test_estimator_sequence_parity(gpu_ctx, pkg, oracle, window, ticks):
             assert np.abs(o[r, 24:36] - e[24:36]).max() <= 2e-5 * max(1.0, np.abs(e[24:36]).max())   # J dq
             assert np.array_equal(o[r, 0:3], e[0:3]), (k, r)                                  # acceleration window: no kinematics involved
             assert np.abs(o[r, 3:12] - e[3:12]).max() <= 1e-5, (k, r, np.abs(o[r, 3:12] - e[3:12]).max())
+            # pose estimator: odometry, stance-foot height (NaN where no foot stands), absolute height, yaw
+            assert np.allclose(o[r, 36:42], e[36:42], rtol=0, atol=2e-5, equal_nan=True), (k, r, o[r, 36:42], e[36:42])
     for v in (d_state, d_in, d_tick, d_out):
         v.free()
