@@ -195,6 +195,13 @@ int qrgpu_estimator_state_doubles(int window);
 int qrgpu_estimator_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out);
 
+/* The tick's state arrays from the estimator's inputs and outputs: what SolveDenseMPC (qr_mpc_stance_leg_controller.cpp:385-399:
+ * pos, baseVInWorldFrame, quat, baseWInWorldFrame, foot2ComInWorldFrame = baseRMat (footPositionsInBaseFrame - comOffset), rpy) and
+ * qrWbcLocomotionController::UpdateModel (qr_wbc_locomotion_controller.cpp:136-156) read.  d_rpy [3][n] = GetBaseRollPitchYaw.
+ * Either output may be NULL. */
+int qrgpu_pack_state_batch(qrgpu_ctx *ctx, int n, const float com_offset[3], const float *d_est_in, const float *d_est_out, const float *d_rpy,
+                           float *d_mpc_state, float *d_fb_state);
+
 /* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */
 int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float v[3], const float quat_wxyz[4],
                      const float w[3], const float r_3x4_colmajor[12], const float rpy[3],

@@ -304,4 +304,54 @@ __global__ void __launch_bounds__(64) qr_estimator_kernel(int n, EstimatorDesc D
 #undef ST
 }
 
+// Glue between the estimators and the tick, one thread per robot: what MPCStanceLegController::SolveDenseMPC (:385-399) and
+// qrWbcLocomotionController::UpdateModel (:136-156) read from qrRobot / stateDataFlow, laid out as the tick's mpc_state[28] and
+// fb_state[37].  foot2ComInWorldFrame = baseRMat * (footPositionsInBaseFrame - comOffset); rpy is an input (GetBaseRollPitchYaw).
+__global__ void __launch_bounds__(64) qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *__restrict__ g_in, const float *__restrict__ g_est,
+                                                           const float *__restrict__ g_rpy, float *__restrict__ g_mpc, float *__restrict__ g_fb)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define IN(f) g_in[(size_t)(f) * N + i]
+#define ES(f) g_est[(size_t)(f) * N + i]
+    const float e0 = IN(6), e1 = IN(7), e2 = IN(8), e3 = IN(9);
+    float R[3][3];
+    R[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); R[0][1] = 2 * (e1 * e2 - e0 * e3); R[0][2] = 2 * (e1 * e3 + e0 * e2);
+    R[1][0] = 2 * (e1 * e2 + e0 * e3); R[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); R[1][2] = 2 * (e2 * e3 - e0 * e1);
+    R[2][0] = 2 * (e1 * e3 - e0 * e2); R[2][1] = 2 * (e2 * e3 + e0 * e1); R[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    if (g_mpc) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            g_mpc[(size_t)r * N + i] = ES(36 + r);                 // basePosition
+            g_mpc[(size_t)(3 + r) * N + i] = ES(3 + r);            // baseVInWorldFrame
+            g_mpc[(size_t)(10 + r) * N + i] = ES(9 + r);           // baseWInWorldFrame
+            g_mpc[(size_t)(25 + r) * N + i] = g_rpy[(size_t)r * N + i];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g_mpc[(size_t)(6 + r) * N + i] = IN(6 + r);
+#pragma unroll
+        for (int leg = 0; leg < 4; ++leg) {
+            const float p0 = ES(12 + 3 * leg) - c0, p1 = ES(13 + 3 * leg) - c1, p2 = ES(14 + 3 * leg) - c2;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) g_mpc[(size_t)(13 + 3 * leg + r) * N + i] = R[r][0] * p0 + R[r][1] * p1 + R[r][2] * p2;
+        }
+    }
+    if (g_fb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g_fb[(size_t)r * N + i] = IN(6 + r);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            g_fb[(size_t)(4 + r) * N + i] = ES(36 + r);
+            g_fb[(size_t)(7 + r) * N + i] = IN(10 + r);            // omegaBody = GetBaseRollPitchYawRate
+            g_fb[(size_t)(10 + r) * N + i] = ES(6 + r);            // GetBaseVelocityInBaseFrame
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) { g_fb[(size_t)(13 + r) * N + i] = IN(17 + r); g_fb[(size_t)(25 + r) * N + i] = IN(29 + r); }
+    }
+#undef IN
+#undef ES
+}
+
 }  // namespace qrgpu

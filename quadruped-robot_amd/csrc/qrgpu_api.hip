@@ -27,6 +27,7 @@ QR_MPC_DECL(9, true)
 QR_MPC_DECL(9, false)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
 __global__ void qr_estimator_kernel(int n, EstimatorDesc D, const float *g_in, const unsigned *g_tick, double *st, float *g_out);
 __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
 __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt, float dtMPC, const float *fin, float *fst, float *g_traj,
@@ -480,6 +481,18 @@ int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc
     D.time_step = desc->time_step; D.accelerometer_variance = desc->accelerometer_variance; D.sensor_variance = desc->sensor_variance;
     D.window = desc->window; D.body_height = desc->body_height;
     hipLaunchKernelGGL(qr_estimator_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_est_in, d_tick, d_est_state, d_est_out);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+int qrgpu_pack_state_batch(qrgpu_ctx *c, int n, const float com_offset[3], const float *d_est_in, const float *d_est_out, const float *d_rpy,
+                           float *d_mpc_state, float *d_fb_state)
+{
+    if (!c || n <= 0 || n > c->max_batch || !com_offset || !d_est_in || !d_est_out || (!d_mpc_state && !d_fb_state)) return QRGPU_ERR_BAD_ARG;
+    if (d_mpc_state && !d_rpy) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(qr_pack_state_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, com_offset[0], com_offset[1], com_offset[2], d_est_in, d_est_out,
+                       d_rpy, d_mpc_state, d_fb_state);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

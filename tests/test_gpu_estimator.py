@@ -38,3 +38,53 @@ def test_estimator_sequence_parity(gpu_ctx, pkg, oracle, window, ticks):
             assert np.allclose(o[r, 36:42], e[36:42], rtol=0, atol=2e-5, equal_nan=True), (k, r, o[r, 36:42], e[36:42])
     for v in (d_state, d_in, d_tick, d_out):
         v.free()
+
+
+def test_sensor_to_torque_pipeline_stays_on_device(gpu_ctx, pkg, oracle):
+    """Raw sensor rows -> estimator kernel -> state packing kernel -> MPC+WBC tick, no host copy in between: the torques equal the
+    oracle's tick on the state the oracle's estimator produces from the same sensor stream."""
+    W = pkg.workload
+    n, h, ticks = 96, 10, 40
+    cfg = W.estimator_cfg("a1", window=16)
+    x, stamp = W.make_estimator_sequence(n, ticks, seed=33)
+    x[:, :, 45:54] = np.eye(3, dtype=np.float32).reshape(-1)               # level ground
+    gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    b = pkg.make_batch(n, h, "a1", seed=34, excite=0.3)                     # trajectory, contact table and WBC commands of the tick
+    S = pkg.to_soa
+    d_state = gpu_ctx.alloc((gpu_ctx.estimator_state_doubles(16), n), np.float64).upload(np.zeros((gpu_ctx.estimator_state_doubles(16), n)))
+    d_in = gpu_ctx.alloc((54, n)); d_tick = gpu_ctx.alloc((n,), np.uint32); d_est = gpu_ctx.alloc((42, n))
+    for k in range(ticks):
+        d_in.upload(S(x[k])); d_tick.upload(stamp[k])
+        gpu_ctx.estimator_update_batch(n, cfg, d_in, d_tick, d_state, d_est)
+    rpy = b["mpc_state"][:, 25:28].copy()
+    d_rpy = gpu_ctx.alloc((3, n)).upload(S(rpy))
+    d_mpc = gpu_ctx.alloc((28, n)); d_fb = gpu_ctx.alloc((37, n))
+    com = np.asarray(W.ROBOTS["a1"]["com_offset"], np.float32)
+    gpu_ctx.pack_state_batch(n, com, d_in, d_est, d_rpy, d_mpc, d_fb)
+    d = dict(traj=gpu_ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=gpu_ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+             cmd=gpu_ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=gpu_ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
+             force=gpu_ctx.alloc((12, n)), tau=gpu_ctx.alloc((12, n)), status=gpu_ctx.alloc((n,), np.int32))
+    gpu_ctx.tick_batch(n, d_mpc, d["traj"], d["gait"], d_fb, d["cmd"], d["prev"], d["force"], d["tau"], d["status"])
+    gpu_ctx.sync()
+    tau = d["tau"].download().T; status = d["status"].download()
+    mpc_g = d_mpc.download().T; fb_g = d_fb.download().T
+    # the same chain on the CPU: oracle estimator -> packing restated here -> oracle tick
+    mpc_o = np.zeros((n, 28), np.float32); fb_o = np.zeros((n, 37), np.float32)
+    for r in range(n):
+        e = oracle.estimator_run(cfg, x[:, r], stamp[:, r])[-1]
+        q4 = x[-1, r, 6:10].astype(np.float32); w_, a, b_, c_ = q4
+        R = np.array([[1 - 2 * (b_ * b_ + c_ * c_), 2 * (a * b_ - w_ * c_), 2 * (a * c_ + w_ * b_)],
+                      [2 * (a * b_ + w_ * c_), 1 - 2 * (a * a + c_ * c_), 2 * (b_ * c_ - w_ * a)],
+                      [2 * (a * c_ - w_ * b_), 2 * (b_ * c_ + w_ * a), 1 - 2 * (a * a + b_ * b_)]], np.float32)
+        mpc_o[r, 0:3] = e[36:39]; mpc_o[r, 3:6] = e[3:6]; mpc_o[r, 6:10] = q4; mpc_o[r, 10:13] = e[9:12]; mpc_o[r, 25:28] = rpy[r]
+        for leg in range(4):
+            mpc_o[r, 13 + 3 * leg:16 + 3 * leg] = R @ (e[12 + 3 * leg:15 + 3 * leg] - com)
+        fb_o[r, 0:4] = q4; fb_o[r, 4:7] = e[36:39]; fb_o[r, 7:10] = x[-1, r, 10:13]; fb_o[r, 10:13] = e[6:9]
+        fb_o[r, 13:25] = x[-1, r, 17:29]; fb_o[r, 25:37] = x[-1, r, 29:41]
+    assert np.abs(mpc_g - mpc_o).max() <= 2e-5 and np.abs(fb_g - fb_o).max() <= 2e-5
+    # torques: GPU tick on the GPU-packed state against the oracle tick on that same state (the estimator difference is tested above)
+    f_o, tau_o, st_o, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), mpc_g, b["traj"], b["gait"], fb_g,
+                                               b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
+    ok = ((status & 0xff) == 0) & (st_o == 0)
+    assert ok.sum() >= n - 2
+    assert np.all(np.abs(tau[ok] - tau_o[ok]) <= 1e-4 * np.maximum(1.0, np.abs(tau_o[ok])))
