@@ -22,6 +22,7 @@
  *   qrgpu_estimator_update_batch <- qrRobot::UpdateDataFlow (leg kinematics) + qrRobotVelocityEstimator::Update + qrRobotPoseEstimator::Update
  *                             QS/robots/qr_robot.cpp:62-72,187-197, QS/estimators/qr_robot_velocity_estimator.cpp:77-133,
  *                             QS/estimators/qr_robot_pose_estimator.cpp:68-165 (qrRobotEstimator::Update, qr_robot_estimator.cpp:79-83)
+ *   qrgpu_swing_targets_batch <- qrRaibertSwingLegController::GetAction (ADVANCED_TROT)   QS/controllers/qr_swing_leg_controller.cpp:362-424
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
  *
@@ -194,6 +195,16 @@ void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d);
 int qrgpu_estimator_state_doubles(int window);
 int qrgpu_estimator_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out);
+
+/* Swing-leg targets of the MPC/WBC mode (qrRaibertSwingLegController::GetAction, ADVANCED_TROT case on horizontal terrain,
+ * QS/controllers/qr_swing_leg_controller.cpp:362-398,408-424): XY-linear / Z-parabola foot trajectory between the lift-off point and the
+ * planned foothold, its world-frame image for the WBC foot tasks, and the inverse-kinematics joint targets of the swing command.
+ * swing_in [58][n]: swing flag[4], footholdPlanner phase[4], swingDuration[4], phaseSwitchFootGlobalPos[12], desiredFootholds[12] (base
+ * frame), basePosition[3], quat_wxyz[4], baseVInWorldFrame[3], motor angles[12].  For the flagged legs only: rows 15-50 of d_wbc_cmd
+ * (pFoot_des, vFoot_des, aFoot_des), d_foot_target_world [12][n] (footTargetPositionsInWorldFrame, rows 26-37 of fe_in) and
+ * d_qdes [24][n] (joint angle and velocity targets).  Any output may be NULL.  desc: leg lengths and hip offsets. */
+int qrgpu_swing_targets_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_swing_in, float *d_wbc_cmd,
+                              float *d_foot_target_world, float *d_qdes);
 
 /* The tick's state arrays from the estimator's inputs and outputs: what SolveDenseMPC (qr_mpc_stance_leg_controller.cpp:385-399:
  * pos, baseVInWorldFrame, quat, baseWInWorldFrame, foot2ComInWorldFrame = baseRMat (footPositionsInBaseFrame - comOffset), rpy) and

@@ -272,3 +272,10 @@ def estimator_run(cfg20, in54, tick):
     out = np.zeros((a.shape[0], 42), _f)
     lib().qro_estimator_run(_fp(np.ascontiguousarray(cfg20, _f)), a.shape[0], _fp(a), t.ctypes.data_as(C.c_void_p), _fp(out))
     return out
+
+
+def swing_targets(geom3, hip_offset12, in58, out72_prev=None):
+    """Swing-leg targets (ADVANCED_TROT, horizontal terrain).  -> out[72]; rows of stance legs keep out72_prev (NaN if not given)."""
+    out = np.full(72, np.nan, _f) if out72_prev is None else np.ascontiguousarray(out72_prev, _f).copy()
+    lib().qro_swing_targets(_fp(np.ascontiguousarray(geom3, _f)), _fp(np.ascontiguousarray(hip_offset12, _f)), _fp(np.ascontiguousarray(in58, _f)), _fp(out))
+    return out

@@ -234,6 +234,9 @@ struct EstimatorState {
 int ekf3_step(double x[3], double P[9], double qvar, double rvar, const double deltaV[3], const double z[3]);
 void estimator_update(const EstimatorConfig &cfg, const float in[54], unsigned tick, EstimatorState &s, float out[42]);
 
+// Swing-leg targets, ADVANCED_TROT on horizontal terrain (second part).  qr_oracle_swing.cpp
+void swing_targets(const LegGeom &geo, const float hip_offset[12], const float in[58], float out[72]);
+
 // ---------------------------------------------------------------------------
 // MPC front-end.  qr_oracle_frontend.cpp
 // in[64] = des_height, des_roll, des_pitch, x_vel_cmd, y_vel_cmd, yaw_vel_cmd, basePosition[3], yawCurrent,

@@ -1,0 +1,93 @@
+// TEST INFRASTRUCTURE (see qr_oracle.h).
+//
+// Swing-leg targets of the MPC/WBC locomotion mode (second part): restates, for LocomotionMode::ADVANCED_TROT on
+// horizontal terrain (dR = robotBaseR = I, QS/controllers/qr_swing_leg_controller.cpp:271-276),
+//   qrRaibertSwingLegController::GetAction, ADVANCED_TROT case           QS/controllers/qr_swing_leg_controller.cpp:362-398, 408-424
+//   SwingFootTrajectory::ResetFootTrajectory / GenerateTrajectoryPoint    QI/controllers/qr_foot_trajectory_generator.h:368-372, QS/.../qr_foot_trajectory_generator.cpp:322-343
+//   qrFootParabolaPatternGenerator::GenerateTrajectory (XYLinear_ZParabola) QS/controllers/qr_foot_trajectory_generator.cpp:187-215
+//   qrQuadraticSpline::getPoint(t, mid, out)                              QS/utils/qr_geometry.cpp:157-190   (xd = xdd = 0 in the reference)
+//   robotics::math::invertRigidTransform                                  QI/utils/qr_se3.h:442-449
+//   qrRobot::ComputeMotorAnglesFromFootLocalPosition / FootPositionInHipFrameToJointAngle / ComputeMotorVelocityFromFootLocalVelocity
+//                                                                         QS/robots/qr_robot.cpp:106-124, 200-219
+// Eigen's Isometry / Quaternion arithmetic cannot be compiled here: "parity unpinned" at that boundary; pinned by properties
+// (trajectory end points, apex height, IK o FK = identity) in tests/test_oracle_swing.py.
+#include "qr_oracle.h"
+
+namespace qro {
+
+// in[58]: swing flag[4] (leg is in swingFootIds), footholdPlanner->phase[4], swingDuration[4], phaseSwitchFootGlobalPos[12] (3*leg+axis),
+//         desiredFootholds[12] (base frame), basePosition[3], quat_wxyz[4], baseVInWorldFrame[3], motor angles q[12].
+// out[72]: pFoot_des[12], vFoot_des[12], aFoot_des[12] (world), footTargetPositionsInWorldFrame[12], joint angle targets[12],
+//          joint velocity targets[12]; entries of stance legs are left untouched (the caller's previous values).
+void swing_targets(const LegGeom &geo, const float hip_offset[12], const float in[58], float out[72])
+{
+    const float *flag = in, *phase_in = in + 4, *swingDur = in + 8, *pswitch = in + 12, *foothold = in + 24, *bp = in + 36, *quat = in + 39, *bv = in + 43, *q = in + 46;
+    Q4<float> qq = {{quat[0], quat[1], quat[2], quat[3]}};
+    M3<float> Rt = quaternionToRotationMatrix(qq);           // world -> body; its transpose rotates body -> world
+    auto to_world = [&](const float p[3], float o[3]) {      // invertRigidTransform(basePosition, quat, p): t + R p
+        for (int i = 0; i < 3; ++i) o[i] = (Rt[0][i] * p[0] + Rt[1][i] * p[1] + Rt[2][i] * p[2]) + bp[i];
+    };
+    for (int leg = 0; leg < 4; ++leg) {
+        if (flag[leg] == 0.f) continue;
+        const float *tgt = foothold + 3 * leg, *st = pswitch + 3 * leg;
+        const float phase = phase_in[leg];
+        const float H = 0.1f;
+        to_world(tgt, out + 36 + 3 * leg);                    // desiredStateCommand->footTargetPositionsInWorldFrame (:366-367)
+        // XYLinear_ZParabola with duration 1, start = phaseSwitchFootGlobalPos, end = robotBaseR * target = target
+        float pw[3] = {0, 0, 0}, vw[3] = {0, 0, 0}, aw[3] = {0, 0, 0};
+        if (!(phase < 0.f - 1e-3) && !(phase >= 0.f + 1.f + 1e-3)) {
+            pw[0] = (1 - phase) * st[0] + phase * tgt[0];
+            pw[1] = (1 - phase) * st[1] + phase * tgt[1];
+            const float mid = std::max(tgt[2], st[2]) + H;
+            float dt = phase - 0.f;
+            if (dt > 1.f) dt = 1.f;
+            if (!(dt < 0.)) {
+                const float mid_phase = 0.5;
+                const float d1 = mid - st[2], d2 = tgt[2] - st[2];
+                const float d3 = std::pow((double)mid_phase, 2) - mid_phase;
+                const float ca = (d1 - d2 * mid_phase) / d3;
+                const float cb = (d2 * std::pow((double)mid_phase, 2) - d1) / d3;
+                const float cc = st[2];
+                pw[2] = ca * std::pow((double)phase, 2) + cb * phase + cc;
+            }
+        }
+        float pb[3] = {pw[0], pw[1], pw[2]}, vb[3] = {0, 0, 0};      // robotBaseR^T * (...) with robotBaseR = I
+        if (phase < 1.0) for (int i = 0; i < 3; ++i) vb[i] = vw[i] / swingDur[leg];
+        to_world(pb, out + 3 * leg);                                      // pFoot_des (:393)
+        for (int i = 0; i < 3; ++i) { out[12 + 3 * leg + i] = bv[i] + vb[i]; out[24 + 3 * leg + i] = aw[i]; }      // (:394-395)
+        // joint targets: IK of the base-frame point, J^-1 of the base-frame velocity (:408-411)
+        const float sgn = ((leg + 1) % 2 == 0) ? 1.f : -1.f;             // pow(-1, leg + 1)
+        const float sh = geo.hip_l * sgn;
+        const float x = pb[0] - hip_offset[3 * leg], y = pb[1] - hip_offset[3 * leg + 1], z = pb[2] - hip_offset[3 * leg + 2];
+        const float lu = geo.upper_l, ll = geo.lower_l;
+        float tK = -std::acos(((x * x + y * y + z * z) - (sh * sh + lu * lu + ll * ll)) / (2 * ll * lu));
+        const float l = std::sqrt(lu * lu + ll * ll + 2 * lu * ll * std::cos(tK));
+        float tH = std::asin(-x / l) - tK / 2;
+        const float c1 = sh * y - l * std::cos(tH + tK / 2) * z;
+        const float s1 = l * std::cos(tH + tK / 2) * y + sh * z;
+        float tA = std::atan2(s1, c1);
+        float ang[3] = {tA, tH, tK};
+        float J[9];
+        analytical_leg_jacobian(geo, ang, leg, J);
+        // dq = J^-1 v by cofactors
+        const float det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+        const float id = 1.f / det;
+        const float Ji[9] = {(J[4] * J[8] - J[5] * J[7]) * id, (J[2] * J[7] - J[1] * J[8]) * id, (J[1] * J[5] - J[2] * J[4]) * id,
+                             (J[5] * J[6] - J[3] * J[8]) * id, (J[0] * J[8] - J[2] * J[6]) * id, (J[2] * J[3] - J[0] * J[5]) * id,
+                             (J[3] * J[7] - J[4] * J[6]) * id, (J[1] * J[6] - J[0] * J[7]) * id, (J[0] * J[4] - J[1] * J[3]) * id};
+        for (int i = 0; i < 3; ++i) {
+            float a = ang[i];
+            if (std::isnan(a)) a = q[3 * leg + i];                        // (:415-418) unreachable target: keep the current angle
+            out[48 + 3 * leg + i] = a;
+            out[60 + 3 * leg + i] = Ji[3 * i] * vb[0] + Ji[3 * i + 1] * vb[1] + Ji[3 * i + 2] * vb[2];
+        }
+    }
+}
+
+}  // namespace qro
+
+extern "C" void qro_swing_targets(const float *geom3, const float *hip_offset12, const float *in58, float *out72)
+{
+    qro::LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2];
+    qro::swing_targets(g, hip_offset12, in58, out72);
+}

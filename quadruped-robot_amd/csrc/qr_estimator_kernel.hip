@@ -354,4 +354,90 @@ __global__ void __launch_bounds__(64) qr_pack_state_kernel(int n, float c0, floa
 #undef ES
 }
 
+// Swing-leg targets of the MPC/WBC mode (ADVANCED_TROT, horizontal terrain), one thread per robot:
+//   qrRaibertSwingLegController::GetAction      quadruped/src/controllers/qr_swing_leg_controller.cpp:362-398, 408-424
+//   qrFootParabolaPatternGenerator / qrQuadraticSpline   quadruped/src/controllers/qr_foot_trajectory_generator.cpp:187-215, quadruped/src/utils/qr_geometry.cpp:157-190
+//   leg inverse kinematics                      quadruped/src/robots/qr_robot.cpp:106-124, 200-219
+// Writes, for the legs flagged as swinging only: rows 15-50 of wbc_cmd (pFoot_des, vFoot_des, aFoot_des), the foot target in the
+// world frame (an input of the MPC front-end) and the joint angle / velocity targets of the swing-leg position command.
+__global__ void __launch_bounds__(64) qr_swing_kernel(int n, EstimatorDesc D, const float *__restrict__ g_in, float *__restrict__ g_cmd, float *__restrict__ g_tgt_world,
+                                                      float *__restrict__ g_qdes)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define IN(f) g_in[(size_t)(f) * N + i]
+    const float e0 = IN(39), e1 = IN(40), e2 = IN(41), e3 = IN(42);
+    float R[3][3];                                                        // body -> world
+    R[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); R[0][1] = 2 * (e1 * e2 - e0 * e3); R[0][2] = 2 * (e1 * e3 + e0 * e2);
+    R[1][0] = 2 * (e1 * e2 + e0 * e3); R[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); R[1][2] = 2 * (e2 * e3 - e0 * e1);
+    R[2][0] = 2 * (e1 * e3 - e0 * e2); R[2][1] = 2 * (e2 * e3 + e0 * e1); R[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    const float bp[3] = {IN(36), IN(37), IN(38)}, bv[3] = {IN(43), IN(44), IN(45)};
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) {
+        if (IN(leg) == 0.f) continue;
+        const float phase = IN(4 + leg), swingDur = IN(8 + leg);
+        const float st[3] = {IN(12 + 3 * leg), IN(13 + 3 * leg), IN(14 + 3 * leg)}, tg[3] = {IN(24 + 3 * leg), IN(25 + 3 * leg), IN(26 + 3 * leg)};
+        if (g_tgt_world) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) g_tgt_world[(size_t)(3 * leg + r) * N + i] = (R[r][0] * tg[0] + R[r][1] * tg[1] + R[r][2] * tg[2]) + bp[r];
+        }
+        float pw[3] = {0.f, 0.f, 0.f};
+        if (!((double)phase < 0.0 - 1e-3) && !((double)phase >= 0.0 + 1.0 + 1e-3)) {
+            pw[0] = (1 - phase) * st[0] + phase * tg[0];
+            pw[1] = (1 - phase) * st[1] + phase * tg[1];
+            const float mid = (tg[2] > st[2] ? tg[2] : st[2]) + 0.1f;
+            if (!(phase < 0.f)) {
+                const float d1 = mid - st[2], d2 = tg[2] - st[2];
+                const float d3 = (float)(0.25 - 0.5);
+                const float ca = (d1 - d2 * 0.5f) / d3;
+                const float cb = (float)(((double)d2 * 0.25 - (double)d1) / (double)d3);
+                pw[2] = (float)((double)ca * ((double)phase * (double)phase) + (double)(cb * phase) + (double)st[2]);
+            }
+        }
+        float vb[3] = {0.f, 0.f, 0.f};
+        if ((double)phase < 1.0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) vb[r] = 0.f / swingDur;
+        }
+        if (g_cmd) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                g_cmd[(size_t)(15 + 3 * leg + r) * N + i] = (R[r][0] * pw[0] + R[r][1] * pw[1] + R[r][2] * pw[2]) + bp[r];
+                g_cmd[(size_t)(27 + 3 * leg + r) * N + i] = bv[r] + vb[r];
+                g_cmd[(size_t)(39 + 3 * leg + r) * N + i] = 0.f;
+            }
+        }
+        if (g_qdes) {
+            const float sh = D.hip_l * ((leg & 1) ? 1.f : -1.f);
+            const float x = pw[0] - D.hip_offset[3 * leg], y = pw[1] - D.hip_offset[3 * leg + 1], z = pw[2] - D.hip_offset[3 * leg + 2];
+            const float lu = D.upper_l, ll = D.lower_l;
+            const float tK = -acosf(((x * x + y * y + z * z) - (sh * sh + lu * lu + ll * ll)) / (2 * ll * lu));
+            const float l = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(tK));
+            const float tH = asinf(-x / l) - tK / 2;
+            const float c1 = sh * y - l * cosf(tH + tK / 2) * z;
+            const float s1 = l * cosf(tH + tK / 2) * y + sh * z;
+            const float tA = atan2f(s1, c1);
+            const float ang[3] = {tA, tH, tK};
+            float J[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) leg_jacobian_column(j, tA, tH, tK, sh, lu, ll, J[0][j], J[1][j], J[2][j]);
+            const float det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            const float id = 1.f / det;
+            const float Ji[3][3] = {{(J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id},
+                                    {(J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id},
+                                    {(J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id}};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float a = ang[r];
+                if (a != a) a = IN(46 + 3 * leg + r);                     // unreachable target: keep the current angle (:415-418)
+                g_qdes[(size_t)(3 * leg + r) * N + i] = a;
+                g_qdes[(size_t)(12 + 3 * leg + r) * N + i] = Ji[r][0] * vb[0] + Ji[r][1] * vb[1] + Ji[r][2] * vb[2];
+            }
+        }
+    }
+#undef IN
+}
+
 }  // namespace qrgpu

@@ -27,6 +27,7 @@ QR_MPC_DECL(9, true)
 QR_MPC_DECL(9, false)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_swing_kernel(int n, EstimatorDesc D, const float *g_in, float *g_cmd, float *g_tgt_world, float *g_qdes);
 __global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
 __global__ void qr_estimator_kernel(int n, EstimatorDesc D, const float *g_in, const unsigned *g_tick, double *st, float *g_out);
 __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
@@ -481,6 +482,20 @@ int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc
     D.time_step = desc->time_step; D.accelerometer_variance = desc->accelerometer_variance; D.sensor_variance = desc->sensor_variance;
     D.window = desc->window; D.body_height = desc->body_height;
     hipLaunchKernelGGL(qr_estimator_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_est_in, d_tick, d_est_state, d_est_out);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+int qrgpu_swing_targets_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc *desc, const float *d_swing_in, float *d_wbc_cmd, float *d_foot_target_world,
+                              float *d_qdes)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !d_swing_in || (!d_wbc_cmd && !d_foot_target_world && !d_qdes)) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    EstimatorDesc D;
+    memset(&D, 0, sizeof(D));
+    D.hip_l = desc->hip_l; D.upper_l = desc->upper_l; D.lower_l = desc->lower_l;
+    memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset));
+    hipLaunchKernelGGL(qr_swing_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_swing_in, d_wbc_cmd, d_foot_target_world, d_qdes);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

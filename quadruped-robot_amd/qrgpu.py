@@ -61,7 +61,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
-           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch"]
+           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch"]
 
 
 def load_library():
@@ -94,6 +94,7 @@ def load_library():
     lib.qrgpu_estimator_desc_default.argtypes = [C.POINTER(estimator_desc_struct)]; lib.qrgpu_estimator_desc_default.restype = None
     lib.qrgpu_estimator_state_doubles.argtypes = [ip]
     lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
+    lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_pack_state_batch.argtypes = [vp, ip, fp, vp, vp, vp, vp, vp]
     lib.qrgpu_vmc_force1.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(ip)]
     lib.qrgpu_mpc_frontend_batch.argtypes = [vp, ip, ip, C.c_float, C.c_float] + [vp] * 6
@@ -265,6 +266,14 @@ class Context:
         d.window = int(cfg20[6]); d.body_height = float(cfg20[19])
         for i in range(12): d.hip_offset[i] = float(cfg20[7 + i])
         self._chk(self._lib.qrgpu_estimator_update_batch(self._h, n, C.byref(d), _dp(est_in), _dp(tick), _dp(est_state), _dp(est_out)))
+
+    def swing_targets_batch(self, n, cfg20, swing_in, wbc_cmd=None, foot_target_world=None, qdes=None):
+        """Swing-leg targets (qr_swing_leg_controller.cpp:362-424, ADVANCED_TROT).  cfg20 = workload.estimator_cfg() (geometry part)."""
+        d = estimator_desc_struct()
+        cfg20 = np.asarray(cfg20, np.float32)
+        d.hip_l, d.upper_l, d.lower_l = (float(v) for v in cfg20[:3])
+        for i in range(12): d.hip_offset[i] = float(cfg20[7 + i])
+        self._chk(self._lib.qrgpu_swing_targets_batch(self._h, n, C.byref(d), _dp(swing_in), _dp(wbc_cmd), _dp(foot_target_world), _dp(qdes)))
 
     def pack_state_batch(self, n, com_offset, est_in, est_out, rpy, mpc_state=None, fb_state=None):
         """mpc_state[28] / fb_state[37] from the estimator's inputs and outputs (SolveDenseMPC :385-399, UpdateModel :136-156)."""

@@ -323,3 +323,33 @@ def make_estimator_sequence(n, ticks, seed=0xE5, dt_ms=2):
         x[k, :, 29:41] = 1.5 * np.cos(6 * t + phase0)[:, None] * np.array([0.3, 1, -1] * 4, f32) + 0.05 * rng.standard_normal((n, 12))
         stamp[k] = t0 + k * dt_ms + (rng.uniform(0, 1, n) < 0.05)        # an occasional late sample
     return x, stamp
+
+
+def make_swing_batch(n, robot="a1", seed=0x5E):
+    """Synthetic inputs of the swing-leg target kernel, AoS [n][58] (layout: include/qrgpu.h swing_in): trot pairs swinging at random
+    phases (a few at exactly 0 and 1 and slightly beyond), lift-off points under the hips, footholds a step ahead."""
+    rng = np.random.default_rng(seed)
+    r = ROBOTS[robot]
+    x = np.zeros((n, 58), f32)
+    pair = rng.integers(0, 4, n)
+    flags = np.zeros((n, 4), f32)
+    flags[pair == 0] = (1, 0, 0, 1); flags[pair == 1] = (0, 1, 1, 0); flags[pair == 2] = (0, 0, 0, 0); flags[pair == 3] = (1, 0, 0, 0)
+    x[:, 0:4] = flags
+    ph = rng.uniform(0, 1, (n, 4)).astype(f32)
+    ph[: n // 16] = 0.0; ph[n // 16: n // 8] = 1.0; ph[n // 8: n // 8 + 4] = 1.0005
+    x[:, 4:8] = ph
+    x[:, 8:12] = rng.uniform(0.15, 0.3, (n, 4))
+    hip = np.asarray(r["hip_offset"], f32)
+    side = np.array([-1, 1, -1, 1], f32) * r["hip_l"]
+    for leg in range(4):
+        base = hip[leg] + np.array([0, side[leg], -0.28], f32)
+        x[:, 12 + 3 * leg:15 + 3 * leg] = base + 0.03 * rng.standard_normal((n, 3))
+        x[:, 24 + 3 * leg:27 + 3 * leg] = base + np.array([0.08, 0, 0], f32) + 0.03 * rng.standard_normal((n, 3))
+    x[:, 36:39] = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), 0.28 + 0.02 * rng.standard_normal(n)], 1)
+    rpy = np.stack([0.05 * rng.standard_normal(n), 0.05 * rng.standard_normal(n), rng.uniform(-np.pi, np.pi, n)], 1)
+    x[:, 39:43] = _quat_from_rpy(rpy)
+    x[:, 43:46] = rng.uniform(-0.5, 0.5, (n, 3))
+    x[:, 46:58] = np.tile(np.array([0.0, 0.9, -1.8], f32), (n, 4))
+    x[-1, 24:27] = (2.0, 0.0, -0.3)                      # an unreachable foothold: NaN angles fall back to the current ones
+    x[-1, 0] = 1; x[-1, 4] = 0.9
+    return x
