@@ -635,11 +635,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #endif
         while (!done) {
             // step 1: most violated inactive row (ties -> lowest id)
+            // (lanes without a leg-step run the same arithmetic on their zeros and are masked by one select: no divergent region)
             double bs = INF; int bt = 0;
-            if (own) {
+            {
                 const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+                const unsigned blocked = own ? (amask | xmask) : 0x3fu;
 #pragma unroll
-                for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
+                for (int t = 0; t < 6; ++t) { const bool take = !((blocked >> t) & 1u) && s[t] < bs; bs = take ? s[t] : bs; bt = take ? t : bt; }
             }
             const double smin = wave_min_d(bs);
             if (!(smin < -tol)) {
@@ -670,9 +672,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 q = __builtin_amdgcn_readfirstlane(q);
                 if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
                 // w_k = M_{k,kp} c_p
-                double w0 = 0.0, w1 = 0.0, w2_ = 0.0;
-                if (own) {
-                    Blk B; load_block(Mb, kme, kp, B);
+                double w0, w1, w2_;
+                {
+                    Blk B; load_block(Mb, kme, kp, B);                // kme is a valid leg-step in every lane
                     w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
                     w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
                     w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
@@ -687,7 +689,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     double a0, a1, a2;
                     cons_vec(ct, im, a0, a1, a2);
                     const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
-                    if (lane < q) dq = a0 * g0 + a1 * g1 + a2 * g2;
+                    dq = (lane < q) ? a0 * g0 + a1 * g1 + a2 * g2 : 0.0;
                 }
                 QM_STAMP(1);
                 // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
@@ -709,16 +711,16 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         for (int u = 0; u < 4; ++u) pr += sv[u] * dj[u];
                     }
                     for (; j < q; j += 4) pr += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(dq, j);
-                    if (lane < q) xr[wv * 64 + lane] = pr;
+                    xr[wv * 64 + lane] = pr;                      // every lane has its slot
                     __syncthreads();                              // B2
-                    if (lane < q) rq = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]);
+                    { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                 }
                 QM_STAMP(2);
                 const double dr = wave_sum_d(rq * dq);
                 const double zc = delta - dr;                    // z'c_p
                 // dual step length: min u_j / r_j over r_j > 0
                 double tt = INF;
-                if (lane < q && rq > 0.0) tt = uq * fast_rcp(rq);
+                { const double tq_ = uq * fast_rcp(rq); tt = (lane < q && rq > 0.0) ? tq_ : INF; }
                 const double t1 = wave_min_d(tt);
                 const int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
                 const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
@@ -762,7 +764,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         int i = wv;
                         for (; i + 4 < q; i += 8) {
                             const double ra = readlane_d(rq, i), rb = readlane_d(rq, i + 4);
-                            if (own) {
+                            {
                                 const double *wa = wk + i * nsp, *wb = wk + (i + 4) * nsp;
                                 const double a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
                                 p0 += a0 * ra + b0 * rb; p1 += a1 * ra + b1 * rb; p2 += a2 * ra + b2 * rb;
@@ -770,7 +772,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         }
                         if (i < q) {
                             const double ra = readlane_d(rq, i);
-                            if (own) { const double *wa = wk + i * nsp; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
+                            { const double *wa = wk + i * nsp; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
                         }
                     } else {
                         // y_k = sum over the active rows of my leg-step of c_row * r(position)
@@ -811,11 +813,11 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     }
                     if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
                     __syncthreads();                              // B3
-                    if (own) {
+                    {
                         double z0 = w0, z1 = w1, z2 = w2_;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) { z0 -= xz[v * NV + 3 * kme]; z1 -= xz[v * NV + 3 * kme + 1]; z2 -= xz[v * NV + 3 * kme + 2]; }
-                        x0 += t * z0; x1 += t * z1; x2 += t * z2;
+                        x0 += t * z0; x1 += t * z1; x2 += t * z2;      // (lanes without a leg-step shadow lane 0; their x is never read)
                     }
                 }
                 uq -= t * rq;
