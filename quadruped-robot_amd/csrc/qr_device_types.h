@@ -58,6 +58,9 @@ struct MpcLaunch {
     // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
     const int *lpt_cost_in;
     int *lpt_order_out;
+    // h = 16: an all-stance inverse Hessian (150 KB) leaves LDS for 26 rows of S^-1; robots that need more keep S^-1 in this global
+    // scratch instead ([robot][tri(QR_QH)] doubles, L2-resident), MAXB = 9 variants only
+    double *sinv_spill;
     int no_wcache;              // diagnostic (QRGPU_NO_WCACHE=1): always take the z = w - M (N_A r) form
 };
 

@@ -417,6 +417,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         qcap = qc < QR_QH ? qc : QR_QH;
         if (qcap > ns) qcap = ns;
     }
+    bool spilled = false;
+    if constexpr (MAXB > 4) {
+        // (the pointer is then generic and the S^-1 accesses of these variants compile to flat_* instructions: a few per cent at
+        // h = 16, nothing at h <= 11 whose variants never take this branch)
+        const int want = ns < QR_QH ? ns : QR_QH;
+        if (P.sinv_spill && qcap < want && qcap < 64) { Sinv = P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH); qcap = want; spilled = true; }
+    }
     // Four-wave path: what is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the
     // iteration that added it), so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to
     // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
@@ -424,9 +431,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     double *Wc = nullptr;
     const int nsp = ns | 1;             // row stride of the cache (odd number of doubles)
     if constexpr (MULTI) {
-        const int qs = qcap < 64 ? qcap : 64;
+        const int qs = spilled ? 0 : (qcap < 64 ? qcap : 64);
         const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs);
-        Wc = Sinv + tri(qs);
+        Wc = Mb + npairs * 9 + tri(qs);
         if (rem > 0 && ns > 0) qW = (int)(rem / (ns | 1));
         if (qW > 64) qW = 64;
         if (P.no_wcache == 1) qW = 0;

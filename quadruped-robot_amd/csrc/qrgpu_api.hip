@@ -60,6 +60,7 @@ struct qrgpu_ctx {
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
     int configured_lds[3] = {0, 0, 0};     // dynamic-LDS limit already set on this context's device, per kernel variant
     int configured_rescue[2] = {0, 0};
+    double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
     int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
     int rescue_parity = 0;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
@@ -266,6 +267,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_order) hipFree(c->d_order);
     if (c->d_cost) hipFree(c->d_cost);
     if (c->d_rescue) hipFree(c->d_rescue);
+    if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
 }
 
@@ -346,6 +348,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.cost = lpt ? c->d_cost : nullptr;
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
+    P.sinv_spill = nullptr;
+    if (!small) {
+        if (!c->d_sinv_spill) HIPCHK(c, hipMalloc(&c->d_sinv_spill, sizeof(double) * (size_t)c->max_batch * (size_t)(QR_QH * (QR_QH + 1) / 2)));
+        P.sinv_spill = c->d_sinv_spill;
+    }
     // rescue pass for the four-wave variants (not for inspection launches or single-robot calls through the staging buffers)
     const bool rescue = c->rescue && !dH && !(mpc_h16_single() && !small);
     P.rescue_mode = 0;
