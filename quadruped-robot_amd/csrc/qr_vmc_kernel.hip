@@ -204,9 +204,25 @@ __global__ void __launch_bounds__(64) qr_vmc_kernel(VmcLaunch P, const int *__re
                 dd[lane] = (double)cn[3 * c] * wd[3 * l] + (double)cn[3 * c + 1] * wd[3 * l + 1] + (double)cn[3 * c + 2] * wd[3 * l + 2];
             }
             vsync();
-            if (lane < q) { double acc = 0.0; for (int j = 0; j < q; ++j) acc += Sq[13 * lane + j] * dd[j]; rr[lane] = acc; }
+            if (lane < q) {
+                double sv[12], dv[12];                       // every load is issued before the first use (q <= 12)
+#pragma unroll
+                for (int j = 0; j < 12; ++j) { const bool ok = j < q; sv[j] = ok ? Sq[13 * lane + j] : 0.0; dv[j] = ok ? dd[j] : 0.0; }
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 12; j += 3) { a0 += sv[j] * dv[j]; a1 += sv[j + 1] * dv[j + 1]; a2 += sv[j + 2] * dv[j + 2]; }
+                rr[lane] = (a0 + a1) + a2;
+            }
             vsync();
-            if (lane < 12) { double acc = 0.0; for (int i = 0; i < q; ++i) acc += mna[12 * i + lane] * rr[i]; zd[lane] = wd[lane] - acc; }
+            if (lane < 12) {
+                double mv[12], rv[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { const bool ok = i < q; mv[i] = ok ? mna[12 * i + lane] : 0.0; rv[i] = ok ? rr[i] : 0.0; }
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 12; i += 3) { a0 += mv[i] * rv[i]; a1 += mv[i + 1] * rv[i + 1]; a2 += mv[i + 2] * rv[i + 2]; }
+                zd[lane] = wd[lane] - ((a0 + a1) + a2);
+            }
             vsync();
             const double znp = zd[3 * lp] * p0 + zd[3 * lp + 1] * p1 + zd[3 * lp + 2] * p2;
             double tt = INF;
@@ -228,7 +244,7 @@ __global__ void __launch_bounds__(64) qr_vmc_kernel(VmcLaunch P, const int *__re
             if (!dual_only && t == t2) {
                 // full step: row ip joins the working set at position q (bordered update of S^-1 with 1 / z'n_p)
                 const double isg = 1.0 / znp;
-                for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; Sq[13 * i + j] += rr[i] * rr[j] * isg; }
+                { const int rq_ = (65536 + q - 1) / q; for (int e = lane; e < q * q; e += 64) { const int i = (e * rq_) >> 16, j = e - i * q; Sq[13 * i + j] += rr[i] * rr[j] * isg; } }
                 if (lane < q) { Sq[13 * q + lane] = -rr[lane] * isg; Sq[13 * lane + q] = -rr[lane] * isg; }
                 if (lane == 0) { Sq[13 * q + q] = isg; act[q] = ip; uu[q] = unew; }
                 if (lane < 12) mna[12 * q + lane] = wd[lane];                            // M n_p, kept for z
@@ -244,7 +260,7 @@ __global__ void __launch_bounds__(64) qr_vmc_kernel(VmcLaunch P, const int *__re
                 if (lane < q) dd[lane] = Sq[13 * lane + l];
                 vsync();
                 const double isl = 1.0 / dd[l];
-                for (int e = lane; e < q * q; e += 64) { const int i = e / q, j = e - i * q; if (i != l && j != l) Sq[13 * i + j] -= dd[i] * dd[j] * isl; }
+                { const int rq_ = (65536 + q - 1) / q; for (int e = lane; e < q * q; e += 64) { const int i = (e * rq_) >> 16, j = e - i * q; if (i != l && j != l) Sq[13 * i + j] -= dd[i] * dd[j] * isl; } }
                 vsync();
                 if (l != last) {
                     if (lane < last) rr[lane] = (lane == l) ? Sq[13 * last + last] : Sq[13 * last + lane];
