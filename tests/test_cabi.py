@@ -50,3 +50,46 @@ def test_model_desc_defaults(pkg):
     d = pkg.model_desc_struct()
     lib.qrgpu_model_desc_default(C.byref(d))
     assert abs(d.hip_l - 0.08505) < 1e-7 and d.kp_foot == 500.0 and abs(d.mu - 0.4) < 1e-7 and abs(d.weight_fb - 0.1) < 1e-7
+
+
+def test_all_kernels_present(pkg):
+    """Every kernel of the path and of the SURVEY 8f rows is in the gfx950 code object."""
+    data = open(pkg._build.build(), "rb").read()
+    for k in (b"qr_mpc_kernel", b"qr_wbc_kernel", b"qr_vmc_kernel", b"qr_frontend_kernel", b"qr_estimator_kernel", b"qr_pack_state_kernel",
+              b"qr_swing_kernel", b"qr_lpt_order_kernel"):
+        assert k in data, k
+
+
+def test_desc_defaults(pkg):
+    lib = pkg.load_library()
+    v = pkg.qrgpu.vmc_desc_struct(); lib.qrgpu_vmc_desc_default(C.byref(v))
+    assert v.mass == 13.0 and abs(v.reg_weight - 1e-4) < 1e-10 and v.fmax_ratio == 10.0 and list(v.acc_weight) == [1, 1, 1, 10, 10, 1]
+    e = pkg.qrgpu.estimator_desc_struct(); lib.qrgpu_estimator_desc_default(C.byref(e))
+    assert e.window == 120 and abs(e.time_step - 0.002) < 1e-9 and abs(e.hip_offset[0] - 0.1805) < 1e-7
+    assert lib.qrgpu_estimator_state_doubles(120) == 96 + 360 and lib.qrgpu_estimator_state_doubles(0) == 0
+
+
+@pytest.mark.gpu
+def test_error_returns(gpu_ctx, pkg):
+    """The reference has no error channel on this path; the C ABI returns a code from every call (error behaviour)."""
+    import numpy as np
+    ctx = pkg.Context(device_id=0, max_batch=8, horizon_max=16)
+    try:
+        a = ctx.alloc((28, 8)); t = ctx.alloc((120, 8)); g = ctx.alloc((40, 8)); f = ctx.alloc((12, 8))
+        with pytest.raises(pkg.QrgpuError, match="NOT_SETUP"):
+            ctx.mpc_solve_batch(8, a, t, g, None, f, None, None)
+        ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), 10)
+        with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
+            ctx.mpc_solve_batch(9, a, t, g, None, f, None, None)              # n > max_batch
+        with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
+            ctx.mpc_solve_batch(8, a, t, g, None, None, None, None)           # no output array
+        with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
+            ctx.mpc_solve_batch(8, a, t, g, None, f, f, None)                 # torques requested without joint angles
+        with pytest.raises(pkg.QrgpuError, match="NOT_SETUP"):
+            ctx.vmc_force_batch(8, a, None, f)
+        with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
+            ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), 17)                    # horizon beyond K_MAX_GAIT_SEGMENTS
+        for v in (a, t, g, f):
+            v.free()
+    finally:
+        ctx.close()
