@@ -22,6 +22,7 @@
  *   qrgpu_estimator_update_batch <- qrRobot::UpdateDataFlow (leg kinematics) + qrRobotVelocityEstimator::Update + qrRobotPoseEstimator::Update
  *                             QS/robots/qr_robot.cpp:62-72,187-197, QS/estimators/qr_robot_velocity_estimator.cpp:77-133,
  *                             QS/estimators/qr_robot_pose_estimator.cpp:68-165 (qrRobotEstimator::Update, qr_robot_estimator.cpp:79-83)
+ *   qrgpu_gait_update_batch <- qrOpenLoopGaitGenerator::Update / Schedule   QS/gait/qr_openloop_gait_generator.cpp:126-249
  *   qrgpu_swing_targets_batch <- qrRaibertSwingLegController::GetAction (ADVANCED_TROT)   QS/controllers/qr_swing_leg_controller.cpp:362-424
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
@@ -195,6 +196,23 @@ void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d);
 int qrgpu_estimator_state_doubles(int window);
 int qrgpu_estimator_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out);
+
+/* Open-loop gait generator (qrOpenLoopGaitGenerator::Update + Schedule, QS/gait/qr_openloop_gait_generator.cpp:126-249) of n robots for
+ * one control tick.  d_contact [4][n]: robot->GetFootContact().  d_gait_state [QRGPU_GAIT_STATE_FLOATS][n] is the generators' memory;
+ * reset != 0 applies Reset(0) before the update.  d_gait_out [24][n] (may be NULL): phaseInFullCycle[4], normalizedPhase[4],
+ * desiredLegState[4], legState[4], curLegState[4], swingTimeRemaining[4].  d_fe_in (may be NULL): the front-end's input array, whose rows
+ * 42-61 (phaseInFullCycle, dutyFactor, normalizedPhase, desiredLegState, legState) are written.  Legs with duty factor 0
+ * (USERDEFINED_SWING) are not supported. */
+#define QRGPU_GAIT_STATE_FLOATS 52
+typedef struct {
+    float stance_duration[4], duty_factor[4], initial_leg_phase[4];   /* openloop_gait_generator.yaml: 0.5, 0.6, (0.5, 0, 0, 0.5) for advanced_trot */
+    int initial_leg_state[4];                                          /* LegState: SWING 0, STANCE 1 */
+    float contact_detection_phase_threshold, wait_time;                /* 0.5, gait_params.wait_time */
+    int advanced_trot;                                                 /* gait == "advanced_trot": the lost-contact hold of Schedule() */
+} qrgpu_gait_desc;
+void qrgpu_gait_desc_default(qrgpu_gait_desc *d);
+int qrgpu_gait_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_gait_desc *desc, float current_time, int robot_stop, int reset, const float *d_contact,
+                            float *d_gait_state, float *d_gait_out, float *d_fe_in);
 
 /* Swing-leg targets of the MPC/WBC mode (qrRaibertSwingLegController::GetAction, ADVANCED_TROT case on horizontal terrain,
  * QS/controllers/qr_swing_leg_controller.cpp:362-398,408-424): XY-linear / Z-parabola foot trajectory between the lift-off point and the

@@ -279,3 +279,13 @@ def swing_targets(geom3, hip_offset12, in58, out72_prev=None):
     out = np.full(72, np.nan, _f) if out72_prev is None else np.ascontiguousarray(out72_prev, _f).copy()
     lib().qro_swing_targets(_fp(np.ascontiguousarray(geom3, _f)), _fp(np.ascontiguousarray(hip_offset12, _f)), _fp(np.ascontiguousarray(in58, _f)), _fp(out))
     return out
+
+
+def gait_run(cfg19, time, contact, stop=None):
+    """Open-loop gait generator of one robot from Reset(0): time [T], contact [T][4] -> out [T][24]
+    (phaseInFullCycle, normalizedPhase, desiredLegState, legState, curLegState, swingTimeRemaining)."""
+    t = np.ascontiguousarray(time, _f); c = np.ascontiguousarray(contact, _f)
+    out = np.zeros((t.shape[0], 24), _f)
+    st = np.ascontiguousarray(stop, np.int32) if stop is not None else None
+    lib().qro_gait_run(_fp(np.ascontiguousarray(cfg19, _f)), t.shape[0], _fp(t), _fp(c), _ip(st) if st is not None else None, _fp(out))
+    return out

@@ -234,6 +234,22 @@ struct EstimatorState {
 int ekf3_step(double x[3], double P[9], double qvar, double rvar, const double deltaV[3], const double z[3]);
 void estimator_update(const EstimatorConfig &cfg, const float in[54], unsigned tick, EstimatorState &s, float out[42]);
 
+// Open-loop gait generator (qr_oracle_gait.cpp).  LegState: SWING 0, STANCE 1, EARLY_CONTACT 2.
+struct GaitConfig {                                   // config/a1_sim/openloop_gait_generator.yaml, gait "advanced_trot"
+    float stance_duration[4] = {0.5f, 0.5f, 0.5f, 0.5f}, duty_factor[4] = {0.6f, 0.6f, 0.6f, 0.6f}, initial_leg_phase[4] = {0.5f, 0.f, 0.f, 0.5f};
+    int initial_leg_state[4] = {1, 1, 1, 1};
+    float contact_detection_phase_threshold = 0.5f, wait_time = 1.0f;
+    bool advanced_trot = true;
+};
+struct GaitState {
+    float reset_time = 0, last_time = 0, cum_dt = 0, gait_cycle = 0;
+    int cur[4] = {0, 0, 0, 0}, last[4] = {0, 0, 0, 0}, desired[4] = {0, 0, 0, 0}, leg[4] = {0, 0, 0, 0}, allow[4] = {1, 1, 1, 1};
+    int first_swing[4] = {0, 0, 0, 0}, first_stance[4] = {0, 0, 0, 0};
+    float phase[4] = {0, 0, 0, 0}, nphase[4] = {0, 0, 0, 0}, contact_start_phase[4] = {0, 0, 0, 0}, swing_remaining[4] = {0, 0, 0, 0};
+};
+void gait_reset(const GaitConfig &c, GaitState &s);
+void gait_update(const GaitConfig &c, float currentTime, const float contact[4], bool stop, GaitState &s, float out[24]);
+
 // Swing-leg targets, ADVANCED_TROT on horizontal terrain (second part).  qr_oracle_swing.cpp
 void swing_targets(const LegGeom &geo, const float hip_offset[12], const float in[58], float out[72]);
 

@@ -86,6 +86,14 @@ struct EstimatorDesc {
     float body_height;
 };
 
+// Open-loop gait generator parameters (qrgpu_gait_desc)
+struct GaitDesc {
+    float stance_duration[4], duty_factor[4], initial_leg_phase[4];
+    int initial_leg_state[4];
+    float contact_detection_phase_threshold, wait_time;
+    int advanced_trot;
+};
+
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
 // The four-wave active set needs the exchange buffers xz[4][NV], xr[4][64]; the single-wave one (h > 11 by default, and the
 // rescue pass) the staging arrays wl, yl, rl and the sAct / sPos tables.

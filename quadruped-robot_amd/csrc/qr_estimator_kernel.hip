@@ -440,4 +440,90 @@ __global__ void __launch_bounds__(64) qr_swing_kernel(int n, EstimatorDesc D, co
 #undef IN
 }
 
+// Open-loop gait generator, one thread per robot: qrOpenLoopGaitGenerator::Update + Schedule
+// (quadruped/src/gait/qr_openloop_gait_generator.cpp:126-207, 210-249; legs with a non-zero duty factor).  State [52][n] floats:
+// resetTime, lastTime, cumDt, gaitCycle, then per leg cur, last, desired, legState, allow, firstSwing, firstStance, phaseInFullCycle,
+// normalizedPhase, contactStartPhase, swingTimeRemaining, (spare); `fresh` != 0 applies Reset(0) first.  Plain float arithmetic and
+// fmodf (exact): bit-identical to the CPU restatement.
+__global__ void __launch_bounds__(64) qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *__restrict__ g_contact,
+                                                     float *__restrict__ st, float *__restrict__ g_out, float *__restrict__ g_fe)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define ST(f) st[(size_t)(f) * N + i]
+    float reset_time, last_time, cum_dt, gait_cycle;
+    int cur[4], last[4], desired[4], leg[4], allow[4], fsw[4], fst[4];
+    float phase[4], nphase[4], csp[4], srem[4];
+    if (fresh) {
+        reset_time = last_time = cum_dt = gait_cycle = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { cur[l] = last[l] = desired[l] = leg[l] = D.initial_leg_state[l]; allow[l] = 1; fsw[l] = fst[l] = 0; phase[l] = nphase[l] = csp[l] = srem[l] = 0.f; }
+    } else {
+        reset_time = ST(0); last_time = ST(1); cum_dt = ST(2); gait_cycle = ST(3);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            cur[l] = (int)ST(4 + l); last[l] = (int)ST(8 + l); desired[l] = (int)ST(12 + l); leg[l] = (int)ST(16 + l); allow[l] = (int)ST(20 + l);
+            fsw[l] = (int)ST(24 + l); fst[l] = (int)ST(28 + l); phase[l] = ST(32 + l); nphase[l] = ST(36 + l); csp[l] = ST(40 + l); srem[l] = ST(44 + l);
+        }
+    }
+    float full[4], swingDur[4], ct[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { full[l] = D.stance_duration[l] / D.duty_factor[l]; swingDur[l] = full[l] - D.stance_duration[l]; ct[l] = g_contact[(size_t)l * N + i]; }
+    float tsr = currentTime;
+    if (reset_time + full[0] < tsr) { reset_time = tsr; gait_cycle += 1.f; }
+    tsr -= reset_time;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) allow[l] = 1;
+    if (D.advanced_trot) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) if (cur[l] == 0 && desired[l] == 1 && ct[l] == 0.f) allow[l] = 0;
+        if (allow[0] + allow[1] + allow[2] + allow[3] < 4) {
+            const float dt_ = currentTime - last_time;
+            cum_dt += dt_;
+            if (cum_dt > D.wait_time) {
+#pragma unroll
+                for (int l = 0; l < 4; ++l) allow[l] = 1;
+            } else reset_time += dt_;
+        } else cum_dt = 0.f;
+    }
+    const bool all_allowed = allow[0] + allow[1] + allow[2] + allow[3] == 4;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (!all_allowed) continue;
+        if (!stop || (stop && last[l] == 0)) { last[l] = cur[l]; cur[l] = desired[l]; }
+        const float augmented = D.initial_leg_phase[l] * full[l] + tsr;
+        phase[l] = fmodf(augmented, full[l]) / full[l];
+        const float ratio = D.duty_factor[l];
+        if (phase[l] < ratio) { desired[l] = 1; nphase[l] = phase[l] / ratio; }
+        else {
+            desired[l] = 0;
+            nphase[l] = (phase[l] - ratio) / (1 - ratio);
+            if (cur[l] == 1) { fsw[l] = 1; csp[l] = 0.f; fst[l] = 0; srem[l] = swingDur[l]; }
+            else { fsw[l] = 0; srem[l] = swingDur[l] * (1 - nphase[l]); }
+        }
+        if (leg[l] == 2 && desired[l] == 0) continue;
+        leg[l] = desired[l];
+        if (nphase[l] < D.contact_detection_phase_threshold) continue;
+        if (leg[l] == 0 && ct[l] != 0.f) { leg[l] = 2; csp[l] = phase[l] - 1.0f; }
+        if (cur[l] == 0 && (leg[l] == 2 || leg[l] == 1)) { fst[l] = 1; fsw[l] = 0; }
+    }
+    ST(0) = reset_time; ST(1) = currentTime; ST(2) = cum_dt; ST(3) = gait_cycle;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        ST(4 + l) = (float)cur[l]; ST(8 + l) = (float)last[l]; ST(12 + l) = (float)desired[l]; ST(16 + l) = (float)leg[l]; ST(20 + l) = (float)allow[l];
+        ST(24 + l) = (float)fsw[l]; ST(28 + l) = (float)fst[l]; ST(32 + l) = phase[l]; ST(36 + l) = nphase[l]; ST(40 + l) = csp[l]; ST(44 + l) = srem[l];
+        if (g_out) {
+            g_out[(size_t)l * N + i] = phase[l]; g_out[(size_t)(4 + l) * N + i] = nphase[l]; g_out[(size_t)(8 + l) * N + i] = (float)desired[l];
+            g_out[(size_t)(12 + l) * N + i] = (float)leg[l]; g_out[(size_t)(16 + l) * N + i] = (float)cur[l]; g_out[(size_t)(20 + l) * N + i] = srem[l];
+        }
+        if (g_fe) {          // rows 42-61 of the MPC front-end's input
+            g_fe[(size_t)(42 + l) * N + i] = phase[l]; g_fe[(size_t)(46 + l) * N + i] = D.duty_factor[l]; g_fe[(size_t)(50 + l) * N + i] = nphase[l];
+            g_fe[(size_t)(54 + l) * N + i] = (float)desired[l]; g_fe[(size_t)(58 + l) * N + i] = (float)leg[l];
+        }
+    }
+#undef ST
+}
+
 }  // namespace qrgpu

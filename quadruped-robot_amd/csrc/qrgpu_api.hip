@@ -27,6 +27,7 @@ QR_MPC_DECL(9, true)
 QR_MPC_DECL(9, false)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_kernel(int n, EstimatorDesc D, const float *g_in, float *g_cmd, float *g_tgt_world, float *g_qdes);
 __global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
 __global__ void qr_estimator_kernel(int n, EstimatorDesc D, const float *g_in, const unsigned *g_tick, double *st, float *g_out);
@@ -489,6 +490,30 @@ int qrgpu_estimator_update_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc
     D.time_step = desc->time_step; D.accelerometer_variance = desc->accelerometer_variance; D.sensor_variance = desc->sensor_variance;
     D.window = desc->window; D.body_height = desc->body_height;
     hipLaunchKernelGGL(qr_estimator_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_est_in, d_tick, d_est_state, d_est_out);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+void qrgpu_gait_desc_default(qrgpu_gait_desc *d)
+{
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    for (int l = 0; l < 4; ++l) { d->stance_duration[l] = 0.5f; d->duty_factor[l] = 0.6f; d->initial_leg_state[l] = 1; }
+    d->initial_leg_phase[0] = 0.5f; d->initial_leg_phase[3] = 0.5f;
+    d->contact_detection_phase_threshold = 0.5f; d->wait_time = 1.0f; d->advanced_trot = 1;
+}
+
+int qrgpu_gait_update_batch(qrgpu_ctx *c, int n, const qrgpu_gait_desc *desc, float current_time, int robot_stop, int reset, const float *d_contact,
+                            float *d_gait_state, float *d_gait_out, float *d_fe_in)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !d_contact || !d_gait_state) return QRGPU_ERR_BAD_ARG;
+    for (int l = 0; l < 4; ++l) if (!(desc->duty_factor[l] > 0.001f) || !(desc->stance_duration[l] > 0.f)) return QRGPU_ERR_BAD_ARG;   // USERDEFINED_SWING legs are not built
+    HIPCHK(c, hipSetDevice(c->device));
+    GaitDesc D;
+    memcpy(D.stance_duration, desc->stance_duration, 16); memcpy(D.duty_factor, desc->duty_factor, 16); memcpy(D.initial_leg_phase, desc->initial_leg_phase, 16);
+    memcpy(D.initial_leg_state, desc->initial_leg_state, 16);
+    D.contact_detection_phase_threshold = desc->contact_detection_phase_threshold; D.wait_time = desc->wait_time; D.advanced_trot = desc->advanced_trot;
+    hipLaunchKernelGGL(qr_gait_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, current_time, robot_stop, reset, d_contact, d_gait_state, d_gait_out, d_fe_in);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

@@ -52,6 +52,12 @@ class estimator_desc_struct(C.Structure):
                 ("body_height", C.c_float)]
 
 
+class gait_desc_struct(C.Structure):
+    _fields_ = [("stance_duration", C.c_float * 4), ("duty_factor", C.c_float * 4), ("initial_leg_phase", C.c_float * 4),
+                ("initial_leg_state", C.c_int * 4), ("contact_detection_phase_threshold", C.c_float), ("wait_time", C.c_float),
+                ("advanced_trot", C.c_int)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libqrgpu.so")
 
@@ -61,7 +67,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
-           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch"]
+           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch"]
 
 
 def load_library():
@@ -94,6 +100,8 @@ def load_library():
     lib.qrgpu_estimator_desc_default.argtypes = [C.POINTER(estimator_desc_struct)]; lib.qrgpu_estimator_desc_default.restype = None
     lib.qrgpu_estimator_state_doubles.argtypes = [ip]
     lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
+    lib.qrgpu_gait_desc_default.argtypes = [C.POINTER(gait_desc_struct)]; lib.qrgpu_gait_desc_default.restype = None
+    lib.qrgpu_gait_update_batch.argtypes = [vp, ip, C.POINTER(gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp]
     lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_pack_state_batch.argtypes = [vp, ip, fp, vp, vp, vp, vp, vp]
     lib.qrgpu_vmc_force1.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(ip)]
@@ -266,6 +274,17 @@ class Context:
         d.window = int(cfg20[6]); d.body_height = float(cfg20[19])
         for i in range(12): d.hip_offset[i] = float(cfg20[7 + i])
         self._chk(self._lib.qrgpu_estimator_update_batch(self._h, n, C.byref(d), _dp(est_in), _dp(tick), _dp(est_state), _dp(est_out)))
+
+    def gait_update_batch(self, n, cfg19, current_time, contact, gait_state, gait_out=None, fe_in=None, stop=False, reset=False):
+        """qrOpenLoopGaitGenerator::Update of n robots (qr_openloop_gait_generator.cpp:126-249).  cfg19 = workload.gait_cfg()."""
+        d = gait_desc_struct()
+        cfg19 = np.asarray(cfg19, np.float32)
+        for l in range(4):
+            d.stance_duration[l] = float(cfg19[l]); d.duty_factor[l] = float(cfg19[4 + l]); d.initial_leg_phase[l] = float(cfg19[8 + l])
+            d.initial_leg_state[l] = int(cfg19[12 + l])
+        d.contact_detection_phase_threshold = float(cfg19[16]); d.wait_time = float(cfg19[17]); d.advanced_trot = int(cfg19[18])
+        self._chk(self._lib.qrgpu_gait_update_batch(self._h, n, C.byref(d), float(current_time), int(bool(stop)), int(bool(reset)), _dp(contact),
+                                                    _dp(gait_state), _dp(gait_out), _dp(fe_in)))
 
     def swing_targets_batch(self, n, cfg20, swing_in, wbc_cmd=None, foot_target_world=None, qdes=None):
         """Swing-leg targets (qr_swing_leg_controller.cpp:362-424, ADVANCED_TROT).  cfg20 = workload.estimator_cfg() (geometry part)."""

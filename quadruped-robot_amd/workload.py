@@ -353,3 +353,30 @@ def make_swing_batch(n, robot="a1", seed=0x5E):
     x[-1, 24:27] = (2.0, 0.0, -0.3)                      # an unreachable foothold: NaN angles fall back to the current ones
     x[-1, 0] = 1; x[-1, 4] = 0.9
     return x
+
+
+def gait_cfg(stance_duration=0.5, duty_factor=0.6, initial_leg_phase=(0.5, 0.0, 0.0, 0.5), initial_leg_state=(1, 1, 1, 1),
+             contact_detection_phase_threshold=0.5, wait_time=1.0, advanced_trot=True):
+    """Packed open-loop gait parameters (config/a1_sim/openloop_gait_generator.yaml, gait "advanced_trot")."""
+    return np.array([*([stance_duration] * 4), *([duty_factor] * 4), *initial_leg_phase, *initial_leg_state, contact_detection_phase_threshold,
+                     wait_time, 1.0 if advanced_trot else 0.0], dtype=f32)
+
+
+def make_gait_contacts(n, ticks, cfg19, seed=0x6A, dt=0.002):
+    """Foot contact streams [ticks][n][4] that mostly follow the nominal trot, with late touch-downs (lost contact at the end of a
+    swing: exercises the hold of Schedule()) and early touch-downs (EARLY_CONTACT) sprinkled in."""
+    rng = np.random.default_rng(seed)
+    full = cfg19[0] / cfg19[4]
+    out = np.zeros((ticks, n, 4), f32)
+    late = rng.uniform(0, 1, (n, 4)) < 0.15
+    early = rng.uniform(0, 1, (n, 4)) < 0.15
+    for k in range(ticks):
+        t = k * dt
+        for l in range(4):
+            ph = np.fmod(cfg19[8 + l] * full + t, full) / full
+            nominal = ph < cfg19[4]
+            c = nominal.copy() if isinstance(nominal, np.ndarray) else np.full(n, nominal)
+            c = np.where(late[:, l] & (ph < 0.08), False, c)                  # still in the air 8 % into the stance phase
+            c = np.where(early[:, l] & (ph > 0.9), True, c)                   # touches down before the swing ends
+            out[k, :, l] = c
+    return out
