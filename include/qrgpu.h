@@ -135,7 +135,8 @@ int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
 int  qrgpu_set_lpt_schedule(qrgpu_ctx *ctx, int on);
 /* Rescue pass of the batched MPC solve (default on): robots whose working set outgrows the four-wave kernel (more than 64 active
  * rows, or more than the LDS behind an all-stance inverse Hessian holds) are re-solved by a single-wave variant with the whole CU's
- * LDS (up to 96 active rows) in a second, normally empty launch; at most max(64, n/16) robots per call (h <= 11; one per CU or n/16 at h = 16).
+ * LDS (up to 96 active rows) in a second, normally empty launch; at most max(64, n/16) robots per call.  h <= 11 only: at h = 16 the
+ * four-wave solve hands over to the single-wave loop in place and no second launch is made.
  * A robot neither pass can hold keeps QRGPU_ST_MPC_OVERFLOW. */
 int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
 const char *qrgpu_last_error(const qrgpu_ctx *ctx);

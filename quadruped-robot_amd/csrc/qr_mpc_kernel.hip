@@ -427,6 +427,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // Four-wave path: what is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the
     // iteration that added it), so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to
     // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
+    // h = 16 only: a four-wave solve whose working set reaches its 64 lanes hands over, in place, to the single-wave loop further down
+    // (positions 64..95 in a second register / the big-q path): the state is a consistent dual-feasible point there (see the hand-over)
+    bool handoff = false;
+    double h_x0 = 0.0, h_x1 = 0.0, h_x2 = 0.0, h_u0 = 0.0;
+    unsigned h_amask = 0;
+    int h_q = 0, h_iter = 0;
+    const int qcap_full = qcap;
     int qW = 0;
     double *Wc = nullptr;
     const int nsp = ns | 1;             // row stride of the cache (odd number of doubles)
@@ -744,7 +751,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 QM_STAMP(3);
                 if (full) {
                     // bordered update of S^-1 (needs only r and 1/z'c): columns j = wv (mod 4); published by B3 below
-                    if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
+                    if (q >= qcap) {
+                        // Nothing of this inner iteration has been applied yet, and with q at its maximum no row was dropped in this
+                        // outer iteration either (up == 0): (x, u, working set, S^-1) is exactly the state the outer loop started from.
+                        if constexpr (MAXB > 4) { if (q == 64 && qcap_full > 64) { handoff = true; done = true; break; } }
+                        st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break;
+                    }
                     const double isg = izc;
                     const bool act0 = lane < q;
                     const double ri = rq * isg;
@@ -876,27 +888,38 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
         QR_TS(5);
         if (wv != 0) return;
-        // ---- phase 6 (wave 0): stage the first-step forces through LDS, then the shared output code below
-        wave_sync();
-        if (lane < 12) xz[lane] = 0.0;
-        wave_sync();
-        if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
-        wave_sync();
-        mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
-        if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
-        if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-        if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
-        QR_TS(6);
-        if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
-        return;
+        if (handoff) {
+            // wave 0 carries on alone: working-set tables of the single-wave loop from the per-lane registers
+            if (lane < q) sAct[lane] = 6 * ck + ct;
+            if (own) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) sPos[6 * lane + t] = ((amask >> t) & 1u) ? (short)((posk >> (8 * t)) & 0x3full) : (short)-1;
+            }
+            h_x0 = x0; h_x1 = x1; h_x2 = x2; h_u0 = (lane < q) ? uq : 0.0; h_amask = amask; h_q = q; h_iter = iter;
+            wave_sync();
+        } else {
+            // ---- phase 6 (wave 0): stage the first-step forces through LDS, then the shared output code below
+            wave_sync();
+            if (lane < 12) xz[lane] = 0.0;
+            wave_sync();
+            if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
+            wave_sync();
+            mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+            if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+            if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
+            QR_TS(6);
+            if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
+            return;
+        }
     }
     if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below
 
     // ---------------- phase 4: x = -M g  (lane k owns leg-step k) ----------------
     const bool own = lane < nls;
     const int kme = own ? lane : 0;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (own) {
+    double x0 = h_x0, x1 = h_x1, x2 = h_x2;
+    if (own && !handoff) {
         for (int kc = 0; kc < nls; ++kc) {
             Blk B; load_block(Mb, kme, kc, B);
             const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
@@ -905,7 +928,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             x2 -= B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
         }
     }
-    QR_TS(4);
+    if (!handoff) QR_TS(4);
+    if (handoff) qcap = qcap_full;                    // the four-wave loop had clamped it to its 64 lanes
 
     // ---------------- phase 5: dual active set (wave 0) ----------------
     const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
@@ -915,10 +939,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const double INF = __builtin_inf();
     long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = 0;
 #define QR_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
-    int q = 0, iter = 0;
-    unsigned amask = 0;                               // active rows of my leg-step (6 bits)
+    int q = h_q, iter = h_iter;
+    unsigned amask = h_amask;                         // active rows of my leg-step (6 bits)
     unsigned xmask = 0;                               // rows found numerically dependent on the working set (skipped until the set changes)
-    double u0 = 0.0, u1 = 0.0;                        // multipliers of working-set positions lane, lane+64
+    double u0 = h_u0, u1 = 0.0;                       // multipliers of working-set positions lane, lane+64
     const int maxit = 40 * nls + 100;
     bool done = (nls == 0);
     while (!done) {

@@ -88,12 +88,11 @@ struct qrgpu_ctx {
         }                                                                                    \
     } while (0)
 
-// h > 11: the single-wave active set (up to 96 active rows in one pass) is the default.  The four-wave variant + rescue pass is 33 %
-// faster when no working set exceeds 64 rows but pays a second, serial solve for every robot that does (5 % of the h = 16 bench
-// batch at SURVEY 8d's ranges: 2.2 ms against 1.5 ms per 1024 robots); QRGPU_H16_MULTI=1 selects it.
+// h > 11: the four-wave active set is the default; a working set that reaches its 64 lanes is handed over in place to the single-wave
+// loop (up to 96 rows), so no rescue launch is needed there.  QRGPU_H16_SINGLE=1 selects the single-wave variant for the whole solve.
 static bool mpc_h16_single()
 {
-    static const bool v = [] { const char *e = getenv("QRGPU_H16_MULTI"); return !(e && e[0] == '1'); }();
+    static const bool v = [] { const char *e = getenv("QRGPU_H16_SINGLE"); return e && e[0] == '1'; }();
     return v;
 }
 
@@ -355,14 +354,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         P.sinv_spill = c->d_sinv_spill;
     }
     // rescue pass for the four-wave variants (not for inspection launches or single-robot calls through the staging buffers)
-    const bool rescue = c->rescue && !dH && !(mpc_h16_single() && !small);
+    const bool rescue = c->rescue && !dH && small;          // h > 11 hands over in place instead
     P.rescue_mode = 0;
     P.rescue_count = rescue ? c->d_rescue : nullptr;
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
-    // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave> (QRGPU_H16_MULTI=1), 2 = <9, single-wave>
+    // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave with in-place hand-over>, 2 = <9, single-wave> (QRGPU_H16_SINGLE=1)
     const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
     const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true> : var == 1 ? (const void *)qr_mpc_kernel<9, true> : (const void *)qr_mpc_kernel<9, false>;
     if (c->configured_lds[var] < P.lds_bytes) {
