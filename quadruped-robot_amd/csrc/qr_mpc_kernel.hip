@@ -754,7 +754,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     if (q >= qcap) {
                         // Nothing of this inner iteration has been applied yet, and with q at its maximum no row was dropped in this
                         // outer iteration either (up == 0): (x, u, working set, S^-1) is exactly the state the outer loop started from.
-                        if constexpr (MAXB > 4) { if (q == 64 && qcap_full > 64) { handoff = true; done = true; break; } }
+                        if (q == 64 && qcap_full > 64) { handoff = true; done = true; break; }
                         st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break;
                     }
                     const double isg = izc;
