@@ -42,7 +42,7 @@ def _load_pkg():
     return mod
 
 
-def cpu_baseline(pkg, b, horizon):
+def cpu_baseline(pkg, b, horizon, mode=1):
     """The CPU restatement (oracle/, kind "port") timed on this box's host cores over a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -53,12 +53,12 @@ def cpu_baseline(pkg, b, horizon):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     cfg, md = pkg.mpc_cfg("a1"), pkg.model_desc("a1")
-    args = (1, cfg, horizon, md[:3], md, b["mpc_state"], b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"])
+    args = (mode, cfg, horizon, md[:3], md, b["mpc_state"], b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"])
     n = b["n"]
     # single thread on a 128-robot slice, all cores on the whole batch
     sl = {k: (v[:128] if isinstance(v, np.ndarray) else v) for k, v in b.items()}
     t0 = time.perf_counter()
-    O.tick_batch(1, cfg, horizon, md[:3], md, sl["mpc_state"], sl["traj"], sl["gait"], sl["fb_state"], sl["wbc_cmd"],
+    O.tick_batch(mode, cfg, horizon, md[:3], md, sl["mpc_state"], sl["traj"], sl["gait"], sl["fb_state"], sl["wbc_cmd"],
                  sl["prev_ori_vel"].copy(), nthreads=1)
     t1 = time.perf_counter() - t0
     passes, wall = 0, 0.0
@@ -333,7 +333,7 @@ def main():
         achieved = (dom_flop * n) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and n == 1024 and h == 10 and args.mode == "tick":     # the PMC passes profile the default command only
             try:
                 traffic = json.load(open(tp)).get(dom_name)
             except Exception:
@@ -356,7 +356,7 @@ def main():
                          "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, b, h)
+            out["cpu_baseline"] = cpu_baseline(pkg, b, h, mode=0 if args.mode == "mpc" else 1) if args.mode != "wbc" else None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
