@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(verbose):
-    flags = FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else [])
+    flags = FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else []) + os.environ.get("QRGPU_EXTRA_FLAGS", "").split()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []

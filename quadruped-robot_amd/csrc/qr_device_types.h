@@ -106,7 +106,7 @@ __host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h, bool multi)
     b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);                // sT sU sSt sTraj sGait sV
     b += 4 * (NL + QR_QH);                                             // sLs sAct
     b += 2 * (6 * NL + ((6 * NL) & 1));                                // sPos
-    b += 4 * 4;                                                        // sMisc
+    b += 4 * 16;                                                       // sMisc (+ the control block of the control/worker loop)
     return (b + 7) & ~(size_t)7;
 }
 

@@ -297,11 +297,15 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     int *sLs = (int *)(sV + 13 * h);   // [NL] free leg-step -> original leg-step
     int *sAct = sLs + NL;              // [QH] active constraint ids (6*k + t)
     short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> position in sAct, or -1
-    int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [4]
+    int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [16]: [0] free leg-steps, [8..13] control block
     // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
     double *Mb = smem + (int)(mpc_lds_fixed_bytes(h, MULTI) / 8);   // block-packed M; the sweep panels live here first
 
+#ifdef QR_TRACE
+#define QR_TS(i) do { } while (0)
+#else
 #define QR_TS(i) do { if (dbgT && tid == 0) dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
+#endif
     QR_TS(0);
     // ---------------- phase 0: inputs ----------------
     if (tid < 28) sSt[tid] = g_state[(size_t)tid * n + rid];
@@ -599,6 +603,311 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // constraint (ck, ct), multiplier u, and d, r during an iteration; lane k knows its leg-step's active rows (amask)
     // and their positions (posk).  Per-lane gathers use ds_bpermute (__shfl), uniform ones v_readlane.
     // =====================================================================================================
+    // =====================================================================================================
+    // Control / worker active set (QR_GI_CTRL, default).  Wave 0 alone takes the decisions -- row scan, w, delta, d, step lengths,
+    // bookkeeping in its registers -- and waves 1-3 are linear-algebra helpers, so that the S^-1 border of one iteration runs while
+    // wave 0 already scans for the next row, and the z partials run while wave 0 reduces the step lengths:
+    //     wave 0:   scan, w, delta, d  ->X1-> r partial ->B2-> r, dr, t1, t2, t ->B3-> z, x, u, bookkeeping -> scan ...
+    //     wave 1-3: [S^-1 border / downdate of the previous iteration] ->X1-> r partial ->B2-> r, z partial ->B3-> S^-1 border ...
+    // Three workgroup barriers per working-set change (X1 also publishes the S^-1 update); the control block in LDS carries
+    // {command, q, flags, dropped position, 1/z'c}, d travels through xz[0], the row positions of every leg-step through sPos.
+    // =====================================================================================================
+#ifndef QR_GI_CTRL
+#define QR_GI_CTRL 1
+#endif
+    if constexpr (MULTI && QR_GI_CTRL) {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool own = lane < nls;
+        const int kme = own ? lane : 0;
+        const double im = (double)(1.f / C.mu);
+        const double fmaxk = own ? fmk[kme] : 0.0;
+        const int tril = tri(lane);
+        const double tol = 1e-9;
+        const double INF = __builtin_inf();
+        if (qcap > 64) qcap = 64;
+        int *sCtl = sMisc + 8;                            // [0] command (0 go, 1 exit), [1] q, [2] flags, [3] dropped position, [4,5] 1/z'c
+        double *dd = xz;                                  // d of the iteration (wave 0 produces no z partial: its slot is free)
+        enum { F_FULL = 1, F_DROP = 2 };
+        // ---- phase 4: x = -M g, block columns kc = wv (mod 4) per wave
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        {
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+            if (own) {
+                for (int kc = wv; kc < nls; kc += 4) {
+                    Blk B; load_block(Mb, kme, kc, B);
+                    const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
+                    p0 += B.m[0] * g0 + B.m[1] * g1 + B.m[2] * g2;
+                    p1 += B.m[3] * g0 + B.m[4] * g1 + B.m[5] * g2;
+                    p2 += B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
+                }
+                xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2;
+            }
+            if (wv == 0) for (int e = lane; e < 6 * nls; e += 64) sPos[e] = (short)-1;
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { x0 -= xz[v * NV + 3 * kme]; x1 -= xz[v * NV + 3 * kme + 1]; x2 -= xz[v * NV + 3 * kme + 2]; }
+            }
+            __syncthreads();
+        }
+        QR_TS(4);
+#ifdef QR_CTRL_NOFASTZ
+        bool fastz = false;
+#else
+        bool fastz = qW > 0;
+#endif
+        // r partial over columns j = wv (mod 4); (i, j) at tri(i) + j for j <= i, else tri(j) + i
+        auto r_partial = [&](int q, double dq) {
+            const int i0 = (lane < q) ? lane : 0;
+            double pr = 0.0;
+            int j = wv;
+            for (; j + 12 < q; j += 16) {
+                double sv[4], dj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; sv[u] = Sinv[(jj <= i0) ? tril + jj : tri(jj) + i0]; dj[u] = readlane_d(dq, jj); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pr += sv[u] * dj[u];
+            }
+            for (; j < q; j += 4) pr += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(dq, j);
+            xr[wv * 64 + lane] = pr;
+        };
+        if (wv != 0) {
+            // ================================ workers ================================
+            const int g = wv - 1;                         // 0..2
+            for (;;) {
+                __syncthreads();                          // X1
+                if (__builtin_amdgcn_readfirstlane(sCtl[0]) != 0) return;
+                const int q = __builtin_amdgcn_readfirstlane(sCtl[1]);
+                const double dq = (lane < q) ? dd[lane] : 0.0;
+                r_partial(q, dq);
+                __syncthreads();                          // B2
+                double rq;
+                { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
+                // z partial: W_A r over the positions i = g (mod 3), or M (N_A r) over every third active leg-step
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+                if (fastz) {
+                    const double *wk = Wc + 3 * kme;
+                    int i = g;
+                    for (; i + 3 < q; i += 6) {
+                        const double ra = readlane_d(rq, i), rb = readlane_d(rq, i + 3);
+                        const double *wa = wk + i * nsp, *wb = wk + (i + 3) * nsp;
+                        const double a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
+                        p0 += a0 * ra + b0 * rb; p1 += a1 * ra + b1 * rb; p2 += a2 * ra + b2 * rb;
+                    }
+                    if (i < q) { const double ra = readlane_d(rq, i); const double *wa = wk + i * nsp; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
+                } else if (q > 0) {
+                    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+                    bool hasrow = false;
+#pragma unroll
+                    for (int tq = 0; tq < 6; ++tq) {
+                        const int ps = own ? (int)sPos[6 * kme + tq] : -1;
+                        const double rr = __shfl(rq, ps < 0 ? 0 : ps, 64);
+                        if (ps >= 0) { double a0, a1, a2; cons_vec(tq, im, a0, a1, a2); y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr; hasrow = true; }
+                    }
+                    const unsigned long long kall = __ballot(hasrow);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(kall >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kall, 0u));
+                    const int r3 = rank - 3 * ((rank * 21846) >> 16);        // rank mod 3 for rank < 64
+                    unsigned long long km = __ballot(hasrow && r3 == g);
+                    while (km) {
+                        const int kc = (int)__builtin_ctzll(km);
+                        km &= km - 1;
+                        Blk B; load_block(Mb, kme, kc, B);
+                        const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
+                        p0 += B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2;
+                        p1 += B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2;
+                        p2 += B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2;
+                    }
+                }
+                if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
+                __syncthreads();                          // B3
+                const int flags = __builtin_amdgcn_readfirstlane(sCtl[2]);
+                if (flags & F_FULL) {
+                    // bordered update of S^-1, columns j = g (mod 3); published by the next X1
+                    const double isg = __hiloint2double(__builtin_amdgcn_readfirstlane(sCtl[4]), __builtin_amdgcn_readfirstlane(sCtl[5]));
+                    const bool act0 = lane < q;
+                    const double ri = rq * isg;
+                    int j = g;
+                    for (; j + 9 < q; j += 12) {
+                        double sv[4], rj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int jj = j + 3 * u; rj[u] = readlane_d(rq, jj); sv[u] = (act0 && jj <= lane) ? Sinv[tril + jj] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int jj = j + 3 * u; if (act0 && jj <= lane) Sinv[tril + jj] = sv[u] + ri * rj[u]; }
+                    }
+                    for (; j < q; j += 3) { const double rj = readlane_d(rq, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
+                    if (g == 0) {
+                        if (act0) Sinv[tri(q) + lane] = -rq * isg;
+                        if (lane == 0) Sinv[tri(q) + q] = isg;
+                    }
+                    if (fastz && !(q < qW)) fastz = false;      // the same rule wave 0 applies when it stores the cache row
+                } else if (flags & F_DROP) {
+                    const int l = __builtin_amdgcn_readfirstlane(sCtl[3]), last = q - 1;
+                    double sl = 0.0;
+                    if (lane < q) sl = Sinv[pidx(lane, l)];
+                    const double isl = fast_rcp(readlane_d(sl, l));
+                    __syncthreads();                      // D1: everyone has column l before anyone changes S^-1
+                    for (int j = g; j < q; j += 3) {
+                        if (j == l) continue;
+                        const double sj = readlane_d(sl, j) * isl;
+                        if (lane < q && lane != l && j <= lane) Sinv[tril + j] -= sl * sj;
+                    }
+                    __syncthreads();                      // D2
+                    double m0 = 0.0;
+                    if (l != last && g == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
+                    __syncthreads();                      // D3
+                    if (l != last && g == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
+                }
+            }
+        }
+        // ================================ wave 0: control ================================
+        int q = 0, iter = 0;
+        unsigned amask = 0, xmask = 0;
+        unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
+        int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
+        double uq = 0.0;                                  // its multiplier
+        const int maxit = 40 * nls + 100;
+        bool done = (nls == 0);
+        while (!done) {
+            double bs = INF; int bt = 0;
+            {
+                const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+                const unsigned blocked = own ? (amask | xmask) : 0x3fu;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { const bool take = !((blocked >> t) & 1u) && s[t] < bs; bs = take ? s[t] : bs; bt = take ? t : bt; }
+            }
+            const double smin = wave_min_d(bs);
+            if (!(smin < -tol)) {
+                double be = 0.0;                          // excluded rows hold, active rows are tight (see the four-wave loop below)
+                if (own && (xmask | amask)) {
+                    const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        if (((xmask >> t) & 1u) && s[t] < be) be = s[t];
+                        if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
+                    }
+                }
+                if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
+                break;
+            }
+            const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
+            const int tp = __builtin_amdgcn_readlane(bt, kp);
+            double c0, c1, c2;
+            cons_vec(tp, im, c0, c1, c2);
+            const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
+            double up = 0.0;
+            for (;;) {
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
+                double w0, w1, w2_;
+                {
+                    Blk B; load_block(Mb, kme, kp, B);
+                    w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
+                    w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
+                    w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
+                }
+                const double delta = c0 * readlane_d(w0, kp) + c1 * readlane_d(w1, kp) + c2 * readlane_d(w2_, kp);
+                double dq;
+                {
+                    double a0, a1, a2;
+                    cons_vec(ct, im, a0, a1, a2);
+                    const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
+                    dq = (lane < q) ? a0 * g0 + a1 * g1 + a2 * g2 : 0.0;
+                }
+                if (lane < q) dd[lane] = dq;
+                if (lane == 0) { sCtl[0] = 0; sCtl[1] = q; }
+                __syncthreads();                          // X1
+                r_partial(q, dq);
+                __syncthreads();                          // B2
+                double rq;
+                { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
+                const double dr = wave_sum_d(rq * dq);
+                const double zc = delta - dr;
+                double tt;
+                { const double tq_ = uq * fast_rcp(rq); tt = (lane < q && rq > 0.0) ? tq_ : INF; }
+                const double t1 = wave_min_d(tt);
+                const int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
+                const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
+                const bool have_z = zc > 1e-13 * delta;
+                const double izc = fast_rcp(zc);
+                const double t2 = have_z ? -sp * izc : INF;
+                const double t = t1 < t2 ? t1 : t2;
+                const bool degenerate = !(t < INF);
+                const bool full = !degenerate && have_z && t == t2;
+                const bool over = full && q >= qcap;
+                const int flags = (degenerate || over) ? 0 : (full ? F_FULL : F_DROP);
+#ifdef QR_TRACE
+                if (dbgT && lane == 0 && iter <= 7) { dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
+#endif
+                if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
+                __syncthreads();                          // B3
+                if (degenerate) { if (lane == kp) xmask |= 1u << tp; break; }
+                if (over) {
+                    if (q == 64 && qcap_full > 64) handoff = true; else st |= QRGPU_ST_MPC_OVERFLOW_D;
+                    done = true; break;
+                }
+                if (have_z) {
+                    const double z0 = w0 - ((xz[NV + 3 * kme] + xz[2 * NV + 3 * kme]) + xz[3 * NV + 3 * kme]);
+                    const double z1 = w1 - ((xz[NV + 3 * kme + 1] + xz[2 * NV + 3 * kme + 1]) + xz[3 * NV + 3 * kme + 1]);
+                    const double z2 = w2_ - ((xz[NV + 3 * kme + 2] + xz[2 * NV + 3 * kme + 2]) + xz[3 * NV + 3 * kme + 2]);
+                    x0 += t * z0; x1 += t * z1; x2 += t * z2;
+                }
+                uq -= t * rq;
+                up += t;
+                if (full) {
+                    if (fastz) {
+                        if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
+                        else fastz = false;
+                    }
+                    if (lane == q) { uq = up; ck = kp; ct = tp; }
+                    if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); sPos[6 * kp + tp] = (short)q; }
+                    xmask = 0;
+                    ++q;
+                    break;
+                }
+                // partial or dual-only step: position lpos leaves (the workers downdate S^-1 between D1 and D3)
+                {
+                    const int l = lpos, last = q - 1;
+                    const int clk = __builtin_amdgcn_readlane(ck, l), clt = __builtin_amdgcn_readlane(ct, l);
+                    const int cmk = __builtin_amdgcn_readlane(ck, last), cmt = __builtin_amdgcn_readlane(ct, last);
+                    __syncthreads();                      // D1
+                    if (fastz && l != last && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
+                    __syncthreads();                      // D2
+                    if (l != last) {
+                        const double ulast = readlane_d(uq, last);
+                        if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
+                    }
+                    if (lane == clk) { amask &= ~(1u << clt); sPos[6 * clk + clt] = (short)-1; }
+                    if (l != last && lane == cmk) { posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt)); sPos[6 * cmk + cmt] = (short)l; }
+                    __syncthreads();                      // D3
+                    xmask = 0;
+                    --q;
+                }
+            }
+        }
+        if (lane == 0) sCtl[0] = 1;                       // workers leave at their next X1
+        __syncthreads();
+        QR_TS(5);
+        if (handoff) {
+            if (lane < q) sAct[lane] = 6 * ck + ct;       // sPos has been kept all along
+            h_x0 = x0; h_x1 = x1; h_x2 = x2; h_u0 = (lane < q) ? uq : 0.0; h_amask = amask; h_q = q; h_iter = iter;
+            wave_sync();
+        } else {
+            wave_sync();
+            if (lane < 12) xz[lane] = 0.0;
+            wave_sync();
+            if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
+            wave_sync();
+            mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+            if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+            if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
+            QR_TS(6);
+#ifndef QR_TRACE
+            if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
+#endif
+            return;
+        }
+    } else
     if constexpr (MULTI) {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the partitioned loops below run on the SALU
         const bool own = lane < nls;
@@ -749,6 +1058,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
                 const bool full = have_z && t == t2;
                 QM_STAMP(3);
+#ifdef QR_TRACE
+                if (dbgT && tid == 0 && iter <= 7) { dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
+#endif
                 if (full) {
                     // bordered update of S^-1 (needs only r and 1/z'c): columns j = wv (mod 4); published by B3 below
                     if (q >= qcap) {
@@ -909,7 +1221,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
             QR_TS(6);
+#ifndef QR_TRACE
             if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
+#endif
             return;
         }
     }
@@ -1183,7 +1497,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
     if (tid == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
     QR_TS(6);
+#ifndef QR_TRACE
     if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
+#endif
 }
 
 #define QR_MPC_INST(MAXB, MULTI)                                                                                                      \
