@@ -506,6 +506,179 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
     QR_TS(2);
 
+// Two implementations of the sweep.  The default keeps the 3x3 blocks in VALU registers.  QR_SWEEP_MFMA=1 runs the same sweep on the
+// fp64 matrix cores (one v_mfma_f64_16x16x4_f64 per 16x16 tile and pivot); parity-green, but measured SLOWER on MI355X (1024 A1
+// robots, h = 10: 128 k cycles per robot against 84 k): the f64 matrix instruction holds its wave for 64 cycles and runs at 1.7x the
+// v_fma_f64 rate at best (scratch/ubench/mfma64b.hip), while copying the pivot columns out of the accumulator layout, the barrier and
+// P^-1 cost ~3 k cycles per pivot whatever the matrix size -- the sweep is a chain of 4h dependent rank-3 steps, not a GEMM.
+#ifndef QR_SWEEP_MFMA
+#define QR_SWEEP_MFMA 0
+#endif
+#if QR_SWEEP_MFMA
+    // ---------------- phase 3: symmetric sweep on the fp64 matrix cores,  A <- -H^-1 ----------------
+    // Pivot leg-step k, its three columns p:  P = A_pp,  C = A[:, p] (n x 3, the lower triangle mirrored),  D = C P^-1;
+    //   A <- A - D C'   everywhere,   then   A[:, p] <- D,  A[p, :] <- D',  A_pp <- -P^-1.
+    // The whole step is ONE rank-3 update: with V = C except V[p, :] = P - I,
+    //   A - (V P^-1) V'  =  A - D C' off the pivot,  D in the pivot columns / rows,  2I - P^-1 in the pivot block
+    // (the 2I is taken off the three diagonal entries when they are copied out).
+    // A lives in the accumulators of v_mfma_f64_16x16x4_f64 as 16x16 tiles of the lower triangle (diagonal tiles whole): five leg-steps
+    // per tile row / column (15 of 16 indices; no leg-step straddles a tile), tile p = tri(R) + C in slot p / 4 of wave p mod 4.  Lane l
+    // of a tile holds column l&15, rows (l>>4) + 4r, r = 0..3.  The update of a tile is one instruction: A operand -(V P^-1) rows of
+    // tile row R, B operand V rows of tile column C, the fourth k zero.  Only V goes through LDS (rows of 4 doubles, double-buffered, one
+    // barrier per pivot); the exact pivot diagonal goes to a side array for P^-1 (P_ii - 1 would lose the low bits of a small pivot
+    // there; as an operand it does not matter).
+    {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        constexpr int NTW = (MAXB <= 4) ? 12 : 24;         // tiles per wave: tri(9) = 45 (44 leg-steps), tri(13) = 91 (64 leg-steps)
+        const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lc = lane & 15, lr = lane >> 4;
+        const int T = (nls + 4) / 5, ntile = tri(T);
+        const int nsl = (ntile - wvs + 3) >> 2;              // tiles of this wave
+        int tRC[NTW];                                        // R | C << 8 (scalar)
+        int offA[NTW], offB[NTW];                            // byte offsets of the lane's operands inside a panel
+        d4 acc[NTW];
+        __syncthreads();               // the Hessian blocks parked in the M slots are read by other threads now
+        const int lcb = lc / 3, lcj = lc - 3 * lcb;
+#pragma unroll
+        for (int sl = 0; sl < NTW; ++sl) {
+            const int pt = 4 * sl + wvs;
+            int R = 0, C = 0;
+            if (pt < ntile) { while (tri(R + 1) <= pt) ++R; C = pt - tri(R); }
+            tRC[sl] = R | (C << 8);
+            offA[sl] = (16 * R + lc) * 32; offB[sl] = ((16 * C + lc) * 4 + lr) * 8;
+            acc[sl] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (pt < ntile) {
+                const int b = 5 * C + lcb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ri = lr + 4 * r, a = 5 * R + ri / 3, i = ri - 3 * (ri / 3);
+                    if (ri < 15 && lc < 15 && a < nls && b < nls)
+                        acc[sl][r] = (a >= b) ? Mb[(tri(a) + b) * 9 + 3 * i + lcj] : Mb[(tri(b) + a) * 9 + 3 * lcj + i];
+                }
+            }
+        }
+        __syncthreads();               // every tile is in registers: the M region can now carry the panels
+        double *pan0 = Mb + ((int)(Mb - smem) & 1);          // 16-byte aligned rows of 4 doubles: V[row][0..2] and a zero (the fourth k)
+        const int pansz = 64 * T;
+        double *pd0 = pan0 + 2 * pansz;                      // [2][4] exact pivot diagonals
+        for (int e = tid; e < 32 * T; e += QR_MPC_THREADS) pan0[4 * e + 3] = 0.0;
+#ifdef QR_SWEEP_STAMPS
+        long long sw_t[6] = {0, 0, 0, 0, 0, 0}, sw_0 = clock64();
+#define SW_STAMP(i) do { const long long t_ = clock64(); sw_t[i] += t_ - sw_0; sw_0 = t_; } while (0)
+#else
+#define SW_STAMP(i) do { } while (0)
+#endif
+        unsigned colmask = 0, rowmask = 0;                   // slots holding a tile of the pivot's tile column / tile row
+        int J = -1;
+        for (int k = 0; k < nls; ++k) {
+            double *pan = pan0 + (k & 1) * pansz, *pd = pd0 + (k & 1) * 4;
+            SW_STAMP(3);
+            if (k == 5 * (J + 1)) {
+                ++J; colmask = 0; rowmask = 0;
+#pragma unroll
+                for (int sl = 0; sl < NTW; ++sl) {
+                    if (sl >= nsl) continue;
+                    if ((tRC[sl] >> 8) == J) colmask |= 1u << sl;
+                    if ((tRC[sl] & 255) == J) rowmask |= 1u << sl;
+                }
+            }
+            const int y = 3 * (k - 5 * J);                   // first pivot index inside its tile
+            SW_STAMP(4);
+            // ---- the pivot columns -> panel (from the lower triangle only, so that the panel is exactly symmetric data)
+            const int jj = lc - y;
+#pragma unroll
+            for (int sl = 0; sl < NTW; ++sl) {
+                if ((colmask >> sl) & 1u) {
+                    const int R = tRC[sl] & 255;
+                    if (jj >= 0 && jj < 3) {
+                        double *dst = pan + (16 * R + lr) * 4 + jj;
+                        if (R > J) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dst[16 * r] = acc[sl][r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (lr + 4 * r == lc) { pd[jj] = acc[sl][r]; dst[16 * r] = acc[sl][r] - 1.0; acc[sl][r] -= 2.0; }
+                                else if (lr + 4 * r > lc) dst[16 * r] = acc[sl][r];
+                            }
+                        }
+                    }
+                }
+                if ((rowmask >> sl) & 1u) {
+                    // row y + ii of this tile sits in register (y + ii - lr) / 4 of the lanes whose lr makes that an integer
+                    const int C = tRC[sl] >> 8, ii = (lr - y) & 3, x = y + ii - lr;
+                    const double v01 = (x >> 2) == 0 ? acc[sl][0] : acc[sl][1], v23 = (x >> 2) == 2 ? acc[sl][2] : acc[sl][3];
+                    const double v = (x >> 2) < 2 ? v01 : v23;
+                    if (ii < 3 && (C < J || lc < y + ii)) pan[(16 * C + lc) * 4 + ii] = v;
+                }
+            }
+            SW_STAMP(0);
+            __syncthreads();
+            SW_STAMP(1);
+            // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per lane
+            double Pi[9];
+            {
+                const double *Pk = pan + 4 * (16 * J + y);
+                const double p00 = pd[0], p01 = Pk[4], p02 = Pk[8], p11 = pd[1], p12 = Pk[9], p22 = pd[2];
+                const double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
+                const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
+                const double det = p00 * c00 + p01 * c01 + p02 * c02;
+                if (!(det > 0.0) || !(p00 > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
+                const double id = fast_rcp(det);
+                Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
+                Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
+                Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
+            }
+            // column lr of -P^-1 for the A operand (k index = lr; the fourth k is zero padding)
+            const double q0 = -(lr == 0 ? Pi[0] : (lr == 1 ? Pi[1] : (lr == 2 ? Pi[2] : 0.0)));
+            const double q1 = -(lr == 0 ? Pi[3] : (lr == 1 ? Pi[4] : (lr == 2 ? Pi[5] : 0.0)));
+            const double q2 = -(lr == 0 ? Pi[6] : (lr == 1 ? Pi[7] : (lr == 2 ? Pi[8] : 0.0)));
+#ifdef QR_SWEEP_STAMPS
+            asm volatile("" :: "v"(q0), "v"(q1), "v"(q2));
+#endif
+            SW_STAMP(2);
+            // three tiles at a time: the operand loads first, then the products and the matrix instructions
+            // (a group's slots past the wave's last tile work on tile (0, 0) data and are never stored)
+            const char *panb = (const char *)pan;
+#pragma unroll
+            for (int g = 0; g < NTW / 3; ++g) {
+                if (3 * g >= nsl) continue;
+                double c0[3], c1[3], c2[3], bo[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const double *cr = (const double *)(panb + offA[3 * g + u]);
+                    c0[u] = cr[0]; c1[u] = cr[1]; c2[u] = cr[2];
+                    bo[u] = *(const double *)(panb + offB[3 * g + u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const double aop = c0[u] * q0 + c1[u] * q1 + c2[u] * q2;
+                    acc[3 * g + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bo[u], acc[3 * g + u], 0, 0, 0);
+                }
+            }
+        }
+#ifdef QR_SWEEP_STAMPS
+        SW_STAMP(3);
+        if (dbgT && tid == 0) { dbgT[(size_t)rid * 16 + 8] = sw_t[0]; dbgT[(size_t)rid * 16 + 9] = sw_t[1]; dbgT[(size_t)rid * 16 + 10] = sw_t[2]; dbgT[(size_t)rid * 16 + 11] = sw_t[3]; dbgT[(size_t)rid * 16 + 12] = sw_t[4]; }
+#endif
+        __syncthreads();           // everybody is done with the panels before M overwrites them
+#pragma unroll
+        for (int sl = 0; sl < NTW; ++sl) {
+            if (sl >= nsl) continue;
+            const int R = tRC[sl] & 255, C = tRC[sl] >> 8, b = 5 * C + lcb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ri = lr + 4 * r, a = 5 * R + ri / 3, i = ri - 3 * (ri / 3);
+                if (ri < 15 && lc < 15 && a < nls && (R > C || lc <= ri)) {
+                    const double v = -acc[sl][r];                              // M = +H^-1
+                    Mb[(tri(a) + b) * 9 + 3 * i + lcj] = v;
+                    if (a == b && i != lcj) Mb[(tri(a) + a) * 9 + 3 * lcj + i] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#else
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
     // Pivot leg-step k:  P = A_kk,  C_i = A_ik (i > k) or A_ki' (i < k);
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
@@ -591,6 +764,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
         __syncthreads();
     }
+#endif
     QR_TS(3);
     // =====================================================================================================
     // Four-wave active set (h <= 11).  All four wavefronts run the SAME control flow on the SAME data, so every
@@ -761,6 +935,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
         // ================================ wave 0: control ================================
         int q = 0, iter = 0;
+#ifdef QR_GI_STAMPS      // sub-phase cycle accounting of wave 0 (build.py: QRGPU_GI_STAMPS=1)
+        long long cs_t[6] = {0, 0, 0, 0, 0, 0}, cs_0 = clock64();
+#define CS_STAMP(i) do { const long long t_ = clock64(); cs_t[i] += t_ - cs_0; cs_0 = t_; } while (0)
+#else
+#define CS_STAMP(i) do { } while (0)
+#endif
         unsigned amask = 0, xmask = 0;
         unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
         int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
@@ -795,6 +975,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             cons_vec(tp, im, c0, c1, c2);
             const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
             double up = 0.0;
+            CS_STAMP(0);
             for (;;) {
                 q = __builtin_amdgcn_readfirstlane(q);
                 if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
@@ -815,9 +996,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
                 if (lane < q) dd[lane] = dq;
                 if (lane == 0) { sCtl[0] = 0; sCtl[1] = q; }
+                CS_STAMP(1);
                 __syncthreads();                          // X1
+                CS_STAMP(2);
                 r_partial(q, dq);
                 __syncthreads();                          // B2
+                CS_STAMP(3);
                 double rq;
                 { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                 const double dr = wave_sum_d(rq * dq);
@@ -839,7 +1023,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 if (dbgT && lane == 0 && iter <= 7) { dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
 #endif
                 if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
+                CS_STAMP(4);
                 __syncthreads();                          // B3
+                CS_STAMP(5);
                 if (degenerate) { if (lane == kp) xmask |= 1u << tp; break; }
                 if (over) {
                     if (q == 64 && qcap_full > 64) handoff = true; else st |= QRGPU_ST_MPC_OVERFLOW_D;
@@ -904,6 +1090,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             QR_TS(6);
 #ifndef QR_TRACE
             if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
+#ifdef QR_GI_STAMPS
+            if (lane == 0 && dbgT) for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = cs_t[i];
+#endif
 #endif
             return;
         }
