@@ -6,7 +6,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one qrgpu_tick_batch over this rank's 1024 robots (inputs already resident in HBM) and, for
-N > 1, one RCCL all-gather of the per-robot torques (weak scaling: every rank owns 1024 robots).
+N > 1, one RCCL all-gather of the per-robot torques on a second stream, overlapped with the next tick (weak scaling: every rank
+owns 1024 robots; the timed region ends when the last gather has landed).
 torch is plumbing only (device buffers, the stream, torch.distributed); the tick itself is two
 hand-written HIP kernels behind the C ABI of include/qrgpu.h.  Rank 0 prints ONE JSON line.
 """
@@ -183,14 +184,22 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
         args.gpus = world
+    # QRGPU_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- a functional rehearsal of the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
+    rehearsal = os.environ.get("QRGPU_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     pkg = _load_pkg()
-    if local_rank == 0:
+    if rank == 0 or (local_rank == 0 and not rehearsal):
         pkg._build.build()          # one build per node; the other ranks wait (the build is also file-locked)
     if world > 1:
         dist.barrier()
@@ -219,16 +228,35 @@ def main():
     d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
     d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
     d_tau_all = torch.zeros((world * 12, n), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major [world][12][n]
+    # N > 1: the all-gather of tick i runs on its own stream while tick i+1 computes (the ticks never wait for a collective; they only
+    # wait, two ticks later, for the gather that is still reading the torque buffer they are about to overwrite)
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    d_tau2 = [d_tau, torch.zeros_like(d_tau)] if world > 1 else [d_tau]
+    gathered = [None, None]
+    nstep = [0]
 
     def step():
+        par = nstep[0] & 1 if world > 1 else 0
+        nstep[0] += 1
+        tau = d_tau2[par]
+        if gathered[par] is not None:
+            stream.wait_event(gathered[par])
         if args.mode == "tick":
-            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, d_tau, d_status)
+            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, tau, d_status)
         elif args.mode == "mpc":
-            ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_force, d_tau, d_status)
+            ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_force, tau, d_status)
         else:
-            ctx.wbc_run_batch(n, d_fb, d_cmd, d_prev, d_tau, d_qdes, d_status)
+            ctx.wbc_run_batch(n, d_fb, d_cmd, d_prev, tau, d_qdes, d_status)
         if world > 1:
-            dist.all_gather_into_tensor(d_tau_all, d_tau)      # RCCL over xGMI: the only exchange of the path
+            comm_stream.wait_stream(stream)                    # this tick's torques are complete
+            with torch.cuda.stream(comm_stream):
+                if rehearsal:
+                    dist.all_gather(list(d_tau_all.view(world, 12, n).unbind(0)), tau)
+                else:
+                    dist.all_gather_into_tensor(d_tau_all, tau)    # RCCL over xGMI: the only exchange of the path
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+            gathered[par] = ev
 
     def fence():
         if world > 1:
@@ -244,6 +272,11 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        # the last gather's block for this rank must be this rank's last torques (every rank checks its own block)
+        own = d_tau_all.view(world, 12, n)[rank]
+        if not torch.equal(own, d_tau2[(nstep[0] - 1) & 1]):
+            raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
     mpc_ms, mpc_cnt = ctx.get_timing(0)
     wbc_ms, wbc_cnt = ctx.get_timing(1)
     ctx.enable_timing(False)
@@ -345,7 +378,7 @@ def main():
             "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
-                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques" % world,
+                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques overlapped with the next tick" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us, "vmc_qp_kernel_us": vmc_us,
                        "dispatch": "longest-first from the previous step's per-robot solve time", "ticks_per_s_slot_order_dispatch": value_no_lpt},
