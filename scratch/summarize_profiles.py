@@ -5,14 +5,14 @@ import pandas as pd
 tag = sys.argv[1]; out_tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv"))[0]
+ks = max(glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv")), key=os.path.getmtime)       # a tag may have been visited twice
 shutil.copy(ks, "profiles/%s_rocprofv3_kernel_stats.csv" % out_tag)
 stats = pd.read_csv(ks)
 rows = {}
 for nm in ("fetch", "write", "sq"):
     f = glob.glob(os.path.join(src, "pmc_%s" % nm, "*", "*_counter_collection.csv"))
     if not f: continue
-    d = pd.read_csv(f[0])
+    d = pd.read_csv(max(f, key=os.path.getmtime))
     d = d[d["Kernel_Name"].str.contains("qrgpu::")]
     g = d.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].mean()
     for (k, c), v in g.items():
