@@ -8,6 +8,8 @@ The directory name is not a Python identifier; load it with
 from . import build as _build          # noqa: F401
 from . import workload                  # noqa: F401
 from . import shard                     # noqa: F401
+from . import ticklog                   # noqa: F401
+from . import replay                    # noqa: F401
 from .qrgpu import (Context, QrgpuError, MissingExtension, lib_path, load_library,   # noqa: F401
                     MPCInterface, WbcLocomotionController, model_desc_struct)
 from .workload import make_batch, mpc_cfg, model_desc, to_soa, ROBOTS    # noqa: F401
