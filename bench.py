@@ -65,9 +65,10 @@ def cpu_baseline(pkg, b, horizon, mode=1):
     passes, wall = 0, 0.0
     while wall < 4.0 and passes < 8:
         t0 = time.perf_counter()
-        O.tick_batch(*args, b["prev_ori_vel"].copy(), nthreads=cores)
+        f_cpu, tau_cpu, st_cpu, _, _ = O.tick_batch(*args, b["prev_ori_vel"].copy(), nthreads=cores)
         wall += time.perf_counter() - t0
         passes += 1
+    cpu_baseline.outputs = (f_cpu, tau_cpu, st_cpu)      # the checker's answer on this batch, for max_rel_*_err_vs_cpu
     return dict(value=passes * n / wall, unit="ticks/s", cores=cores, kind="port",
                 sample="%d passes over the same %d-robot batch on %d threads (oracle/ CPU restatement, own fp64 active-set QP)"
                        % (passes, n, cores),
@@ -390,6 +391,23 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, b, h, mode=0 if args.mode == "mpc" else 1) if args.mode != "wbc" else None
+            if out["cpu_baseline"] is not None:
+                # BASELINE's metric quotes the torque error beside the rate: one more (untimed) call from the batch's initial WBC memory,
+                # against what the CPU pass above returned for the same inputs; robots either side flags are counted, not compared
+                d_prev.copy_(T(b["prev_ori_vel"]))
+                d_f1, d_t1, d_s1 = torch.zeros_like(d_force), torch.zeros_like(d_tau), torch.zeros_like(d_status)
+                if args.mode == "tick":
+                    ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_f1, d_t1, d_s1)
+                else:
+                    ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_f1, d_t1, d_s1)
+                torch.cuda.synchronize()
+                f_cpu, tau_cpu, st_cpu = cpu_baseline.outputs
+                ok = ((d_s1.cpu().numpy() & 0xff) == 0) & (st_cpu == 0)
+                f_gpu, tau_gpu = d_f1.cpu().numpy().T, d_t1.cpu().numpy().T
+                out["config"]["max_rel_force_err_vs_cpu"] = float((np.abs(f_gpu - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
+                if args.mode == "tick":
+                    out["config"]["max_rel_torque_err_vs_cpu"] = float((np.abs(tau_gpu - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
+                out["config"]["robots_compared_with_cpu"] = int(ok.sum())
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
