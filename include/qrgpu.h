@@ -24,6 +24,8 @@
  *                             QS/estimators/qr_robot_pose_estimator.cpp:68-165 (qrRobotEstimator::Update, qr_robot_estimator.cpp:79-83)
  *   qrgpu_gait_update_batch <- qrOpenLoopGaitGenerator::Update / Schedule   QS/gait/qr_openloop_gait_generator.cpp:126-249
  *   qrgpu_swing_targets_batch <- qrRaibertSwingLegController::GetAction (ADVANCED_TROT)   QS/controllers/qr_swing_leg_controller.cpp:362-424
+ *   qrgpu_footholds_batch  <- qrRaibertSwingLegController::Update + qrFootholdPlanner::ComputeHeuristicFootHold
+ *                             QS/controllers/qr_swing_leg_controller.cpp:211-236, QS/planner/qr_foothold_planner.cpp:110-239
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
  *
@@ -224,6 +226,26 @@ int qrgpu_gait_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_gait_desc *desc, 
  * d_qdes [24][n] (joint angle and velocity targets).  Any output may be NULL.  desc: leg lengths and hip offsets. */
 int qrgpu_swing_targets_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_swing_in, float *d_wbc_cmd,
                               float *d_foot_target_world, float *d_qdes);
+
+/* Swing-leg selection and the Raibert-type foothold heuristic that feed qrgpu_swing_targets_batch: qrRaibertSwingLegController::Update
+ * (default branch, QS/controllers/qr_swing_leg_controller.cpp:211-236) + qrFootholdPlanner::ComputeHeuristicFootHold
+ * (QS/planner/qr_foothold_planner.cpp:110-239) on flat ground (groundRMat = I).
+ * fh_in [46][n]: legState[4] (LegState: SWING 0, STANCE 1, EARLY_CONTACT 2, LOSE_CONTACT 3), allowSwitchLegState[4], swingTimeRemaining[4],
+ * normalizedPhase[4], desiredSpeed[3] (stateDes 6..8), desiredTwistingSpeed (stateDes 11), stateDes(2), footPositionsInBaseFrame[12],
+ * quat_wxyz[4], rpy[3], baseVelocityInBaseFrame[3], baseRollPitchYawRate[3].  When d_gait_state / d_gait_out (the arrays of
+ * qrgpu_gait_update_batch) are given, rows 0-15 are taken from them instead.  Writes swing_in rows 0-3 (leg is in swingFootIds) for every
+ * leg and, for those legs, rows 4-7 (footholdPlanner->phase) and 24-35 (desiredFootholds, base frame); other rows are left alone.
+ * The reference's out-of-bounds write for backwards commands (:222-225, footTargetPosition(0,2) on a 3x1 vector) is not reproduced. */
+typedef struct {
+    float hip_offset[12];             /* robot->hipOffset, 3*leg+axis (robot_params.hip_offset)                      */
+    float default_hip_position[12];   /* robot->GetDefaultHipPosition() (robot_params.default_hip_positions)         */
+    float hip_l;                      /* robot->hipLength                                                             */
+    float swing_kp[3];                /* user_parameters.yaml swingKp.advanced_trot: 0.16 x3                          */
+    float foot_clearance;             /* user_parameters.yaml footClearance: 0.01                                     */
+} qrgpu_foothold_desc;
+void qrgpu_foothold_desc_default(qrgpu_foothold_desc *d);
+int qrgpu_footholds_batch(qrgpu_ctx *ctx, int n, const qrgpu_foothold_desc *desc, const float *d_fh_in, const float *d_gait_state,
+                          const float *d_gait_out, float *d_swing_in);
 
 /* The tick's state arrays from the estimator's inputs and outputs: what SolveDenseMPC (qr_mpc_stance_leg_controller.cpp:385-399:
  * pos, baseVInWorldFrame, quat, baseWInWorldFrame, foot2ComInWorldFrame = baseRMat (footPositionsInBaseFrame - comOffset), rpy) and

@@ -274,6 +274,13 @@ def estimator_run(cfg20, in54, tick):
     return out
 
 
+def footholds(desc29, in46, swing_in58=None):
+    """Swing-leg selection + foothold heuristic (qr_oracle_swing.cpp footholds).  -> swing_in[58] with rows 0-7, 24-35 updated"""
+    out = np.zeros(58, _f) if swing_in58 is None else np.ascontiguousarray(swing_in58, _f).copy()
+    lib().qro_footholds(_fp(np.ascontiguousarray(desc29, _f)), _fp(np.ascontiguousarray(in46, _f)), _fp(out))
+    return out
+
+
 def swing_targets(geom3, hip_offset12, in58, out72_prev=None):
     """Swing-leg targets (ADVANCED_TROT, horizontal terrain).  -> out[72]; rows of stance legs keep out72_prev (NaN if not given)."""
     out = np.full(72, np.nan, _f) if out72_prev is None else np.ascontiguousarray(out72_prev, _f).copy()

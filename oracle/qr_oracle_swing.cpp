@@ -91,3 +91,78 @@ extern "C" void qro_swing_targets(const float *geom3, const float *hip_offset12,
     qro::LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2];
     qro::swing_targets(g, hip_offset12, in58, out72);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Swing-leg selection + Raibert-type foothold heuristic of the MPC/WBC mode: restates
+//   qrRaibertSwingLegController::Update, default branch (which legs are in swingFootIds)     QS/controllers/qr_swing_leg_controller.cpp:211-236
+//   qrFootholdPlanner::ComputeHeuristicFootHold                                               QS/planner/qr_foothold_planner.cpp:110-239
+// on flat ground (groundRMat = I, so dR = baseRInControlFrame = baseRMat, QS/robots/qr_robot.cpp:70-71; the ground estimator is not built).
+// One thing is NOT mirrored: for a backwards command (stateDes(6) < -0.01) the reference executes `footTargetPosition(0,2) -= 0.02;
+// footTargetPosition(0,3) -= 0.02;` on a 3x1 vector (:222-225) -- an out-of-bounds access (an assertion in debug builds, a stray stack
+// write otherwise); it is treated as a no-op here.  Eigen's fixed-size products cannot be compiled here: "parity unpinned" at that
+// boundary, pinned by properties in tests/test_oracle_swing.py (like the swing targets above).
+// desc[29]: hip_offset[12] (robot->hipOffset, 3*leg+axis), default_hip_position[12], hip_l, swing_kp[3], foot_clearance
+// in[46]:   legState[4], allowSwitchLegState[4], swingTimeRemaining[4], normalizedPhase[4], desiredSpeed[3] (stateDes 6..8),
+//           desiredTwistingSpeed (stateDes 11), stateDes(2), footPositionsInBaseFrame[12], quat_wxyz[4], rpy[3],
+//           baseVelocityInBaseFrame[3], baseRollPitchYawRate[3]
+// swing_in[58] (layout above): rows 0-3 (leg is in swingFootIds) are always written; for those legs rows 4-7 (planner phase) and
+//           24-35 (desiredFootholds, base frame); the other legs keep their previous values, as the planner's members do.
+namespace qro {
+void footholds(const float desc[29], const float in[46], float swing_in[58])
+{
+    const float *abad = desc, *hipPos = desc + 12, hipLen = desc[24], *kp = desc + 25, clearance = desc[28];
+    const float *legState = in, *allow = in + 4, *srem = in + 8, *nphase = in + 12, *vdes = in + 16, wdes = in[19], hdes = in[20];
+    const float *footB = in + 21, *quat = in + 33, *rpy = in + 37, *vb = in + 40, *w = in + 43;
+    Q4<float> qq = {{quat[0], quat[1], quat[2], quat[3]}};
+    const M3<float> Rt = quaternionToRotationMatrix(qq);                      // world -> body; baseRMat = its transpose
+    auto R = [&](int i, int j) { return Rt[j][i]; };                          // robotBaseR = dR
+    const float side_sign[4] = {-1.f, 1.f, -1.f, 1.f};
+    const float dh[3] = {0.f, 0.f, hdes - clearance};
+    for (int leg = 0; leg < 4; ++leg) {
+        const int st = (int)legState[leg];
+        const bool skip = (st == 1 /*STANCE*/ && allow[leg] != 0.f) || st == 2 /*EARLY_CONTACT*/;
+        swing_in[leg] = skip ? 0.f : 1.f;
+        if (skip) continue;
+        const float *ho = abad + 3 * leg;
+        const float twist[3] = {-ho[1], ho[0], 0.f};
+        const float cr[3] = {w[1] * ho[2] - w[2] * ho[1], w[2] * ho[0] - w[0] * ho[2], w[0] * ho[1] - w[1] * ho[0]};
+        const float hv0[3] = {vb[0] + cr[0], vb[1] + cr[1], vb[2] + cr[2]};
+        float hv[3];
+        for (int i = 0; i < 3; ++i) hv[i] = (R(i, 0) * hv0[0] + R(i, 1) * hv0[1]) + R(i, 2) * hv0[2];
+        hv[2] = 0.f;
+        const float tv[3] = {vdes[0] + wdes * twist[0], vdes[1] + wdes * twist[1], vdes[2] + wdes * twist[2]};
+        float ftp[3];
+        float phase;
+        if (allow[leg] == 0.f) {
+            const float d[3] = {footB[3 * leg] - hipPos[3 * leg], footB[3 * leg + 1] - hipPos[3 * leg + 1], footB[3 * leg + 2] - hipPos[3 * leg + 2]};
+            float t[3];
+            for (int i = 0; i < 3; ++i) t[i] = (R(i, 0) * d[0] + R(i, 1) * d[1]) + R(i, 2) * d[2];
+            if (t[1] > 0.01 + 0.00 * (-side_sign[leg])) t[1] -= 0.005; else if (t[1] < -0.01 + 0.00 * side_sign[leg]) t[1] += 0.005;
+            t[2] -= 0.02;
+            for (int i = 0; i < 3; ++i) ftp[i] = ((R(0, i) * t[0] + R(1, i) * t[1]) + R(2, i) * t[2]) + hipPos[3 * leg + i];
+            phase = 1.0f;
+        } else {
+            const float s = srem[leg];
+            float u[3];
+            for (int i = 0; i < 3; ++i) u[i] = tv[i] * s - kp[i] * (tv[i] - hv[i]);
+            float dP[3];
+            for (int i = 0; i < 3; ++i) dP[i] = (R(0, i) * u[0] + R(1, i) * u[1]) + R(2, i) * u[2];
+            const float th = 0.2f;
+            dP[0] = dP[0] < -th ? -th : (dP[0] > th ? th : dP[0]);
+            dP[1] = dP[1] < -th ? -th : (dP[1] > th ? th : dP[1]);
+            dP[2] = 0;
+            const float iy = hipLen * side_sign[leg];
+            const float c = std::cos(rpy[0]), sn = std::sin(rpy[0]);                 // coordinateRotation(X, roll) * (0, iy, 0)
+            const float rr[3] = {(0.f * 1.f + 0.f * iy) + 0.f * 0.f, (0.f * 0.f + c * iy) + sn * 0.f, (0.f * 0.f + -sn * iy) + c * 0.f};
+            const float a[3] = {ho[0], ho[1], 0.f};
+            for (int i = 0; i < 3; ++i) ftp[i] = (dP[i] + a[i]) + rr[i];
+            for (int i = 0; i < 3; ++i) ftp[i] -= (R(0, i) * dh[0] + R(1, i) * dh[1]) + R(2, i) * dh[2];
+            phase = nphase[leg];
+        }
+        swing_in[4 + leg] = phase;
+        for (int i = 0; i < 3; ++i) swing_in[24 + 3 * leg + i] = ftp[i];
+    }
+}
+}  // namespace qro
+
+extern "C" void qro_footholds(const float *desc29, const float *in46, float *swing_in58) { qro::footholds(desc29, in46, swing_in58); }

@@ -86,6 +86,12 @@ struct EstimatorDesc {
     float body_height;
 };
 
+// Foothold heuristic parameters (qrgpu_foothold_desc)
+struct FootholdDesc {
+    float hip_offset[12], default_hip_position[12];
+    float hip_l, swing_kp[3], foot_clearance;
+};
+
 // Open-loop gait generator parameters (qrgpu_gait_desc)
 struct GaitDesc {
     float stance_duration[4], duty_factor[4], initial_leg_phase[4];

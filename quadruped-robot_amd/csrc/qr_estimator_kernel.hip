@@ -526,4 +526,86 @@ __global__ void __launch_bounds__(64) qr_gait_kernel(int n, GaitDesc D, float cu
 #undef ST
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Which legs swing + where they should land: qrRaibertSwingLegController::Update (default branch, QS/controllers/
+// qr_swing_leg_controller.cpp:211-236) and qrFootholdPlanner::ComputeHeuristicFootHold (QS/planner/qr_foothold_planner.cpp:110-239) on
+// flat ground (dR = baseRMat).  One thread per robot; same operation order as oracle/qr_oracle_swing.cpp (footholds), contraction off.
+// g_in [46][n] (include/qrgpu.h fh_in); rows 0-15 come from the gait kernel's arrays instead when those are given (legState and
+// allowSwitchLegState are rows 16-23 of gait_state, normalizedPhase / swingTimeRemaining rows 4-7 / 20-23 of gait_out).
+// Writes rows 0-3 of swing_in for every leg, rows 4-7 and 24-35 for the swinging ones.
+__global__ void __launch_bounds__(64) qr_foothold_kernel(int n, FootholdDesc D, const float *__restrict__ g_in, const float *__restrict__ g_gait_state,
+                                                         const float *__restrict__ g_gait_out, float *__restrict__ g_swing)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define FI(f) g_in[(size_t)(f) * N + i]
+    const float e0 = FI(33), e1 = FI(34), e2 = FI(35), e3 = FI(36);
+    float R[3][3];                                                        // baseRMat: body -> world (= dR on flat ground)
+    R[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); R[0][1] = 2 * (e1 * e2 - e0 * e3); R[0][2] = 2 * (e1 * e3 + e0 * e2);
+    R[1][0] = 2 * (e1 * e2 + e0 * e3); R[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); R[1][2] = 2 * (e2 * e3 - e0 * e1);
+    R[2][0] = 2 * (e1 * e3 - e0 * e2); R[2][1] = 2 * (e2 * e3 + e0 * e1); R[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    const float vdes[3] = {FI(16), FI(17), FI(18)}, wdes = FI(19), hdes = FI(20);
+    const float roll = FI(37);
+    const float vb[3] = {FI(40), FI(41), FI(42)}, w[3] = {FI(43), FI(44), FI(45)};
+    const float dh2 = hdes - D.foot_clearance;
+    const float c = cosf(roll), sn = sinf(roll);
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) {
+        const int st = (int)(g_gait_state ? g_gait_state[(size_t)(16 + leg) * N + i] : FI(leg));
+        const float allow = g_gait_state ? g_gait_state[(size_t)(20 + leg) * N + i] : FI(4 + leg);
+        const bool skip = (st == 1 && allow != 0.f) || st == 2;
+        g_swing[(size_t)leg * N + i] = skip ? 0.f : 1.f;
+        if (skip) continue;
+        const float side = (leg & 1) ? 1.f : -1.f;
+        const float ho[3] = {D.hip_offset[3 * leg], D.hip_offset[3 * leg + 1], D.hip_offset[3 * leg + 2]};
+        const float twist[3] = {-ho[1], ho[0], 0.f};
+        const float cr[3] = {w[1] * ho[2] - w[2] * ho[1], w[2] * ho[0] - w[0] * ho[2], w[0] * ho[1] - w[1] * ho[0]};
+        const float hv0[3] = {vb[0] + cr[0], vb[1] + cr[1], vb[2] + cr[2]};
+        float hv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hv[r] = (R[r][0] * hv0[0] + R[r][1] * hv0[1]) + R[r][2] * hv0[2];
+        hv[2] = 0.f;
+        const float tv[3] = {vdes[0] + wdes * twist[0], vdes[1] + wdes * twist[1], vdes[2] + wdes * twist[2]};
+        float ftp[3], phase;
+        if (allow == 0.f) {
+            const float hp[3] = {D.default_hip_position[3 * leg], D.default_hip_position[3 * leg + 1], D.default_hip_position[3 * leg + 2]};
+            const float d[3] = {FI(21 + 3 * leg) - hp[0], FI(22 + 3 * leg) - hp[1], FI(23 + 3 * leg) - hp[2]};
+            float t[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) t[r] = (R[r][0] * d[0] + R[r][1] * d[1]) + R[r][2] * d[2];
+            if ((double)t[1] > 0.01 + 0.00 * (double)(-side)) t[1] = (float)((double)t[1] - 0.005);
+            else if ((double)t[1] < -0.01 + 0.00 * (double)side) t[1] = (float)((double)t[1] + 0.005);
+            t[2] = (float)((double)t[2] - 0.02);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ftp[r] = ((R[0][r] * t[0] + R[1][r] * t[1]) + R[2][r] * t[2]) + hp[r];
+            phase = 1.0f;
+        } else {
+            const float s = g_gait_out ? g_gait_out[(size_t)(20 + leg) * N + i] : FI(8 + leg);
+            float u[3], dP[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) u[r] = tv[r] * s - D.swing_kp[r] * (tv[r] - hv[r]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dP[r] = (R[0][r] * u[0] + R[1][r] * u[1]) + R[2][r] * u[2];
+            const float th = 0.2f;
+            dP[0] = dP[0] < -th ? -th : (dP[0] > th ? th : dP[0]);
+            dP[1] = dP[1] < -th ? -th : (dP[1] > th ? th : dP[1]);
+            dP[2] = 0.f;
+            const float iy = D.hip_l * side;
+            const float rr[3] = {(0.f * 1.f + 0.f * iy) + 0.f * 0.f, (0.f * 0.f + c * iy) + sn * 0.f, (0.f * 0.f + -sn * iy) + c * 0.f};
+            const float a[3] = {ho[0], ho[1], 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ftp[r] = (dP[r] + a[r]) + rr[r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ftp[r] -= (R[0][r] * 0.f + R[1][r] * 0.f) + R[2][r] * dh2;
+            phase = g_gait_out ? g_gait_out[(size_t)(4 + leg) * N + i] : FI(12 + leg);
+        }
+        g_swing[(size_t)(4 + leg) * N + i] = phase;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g_swing[(size_t)(24 + 3 * leg + r) * N + i] = ftp[r];
+    }
+#undef FI
+}
+
 }  // namespace qrgpu

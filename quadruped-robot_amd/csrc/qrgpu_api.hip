@@ -29,6 +29,7 @@ __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_kernel(int n, EstimatorDesc D, const float *g_in, float *g_cmd, float *g_tgt_world, float *g_qdes);
+__global__ void qr_foothold_kernel(int n, FootholdDesc D, const float *g_in, const float *g_gait_state, const float *g_gait_out, float *g_swing);
 __global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
 __global__ void qr_estimator_kernel(int n, EstimatorDesc D, const float *g_in, const unsigned *g_tick, double *st, float *g_out);
 __global__ void qr_vmc_kernel(VmcLaunch P, const int *type_id, const float *g_in, const float *g_q, float *g_force, float *g_tau, int *g_status);
@@ -513,6 +514,30 @@ int qrgpu_gait_update_batch(qrgpu_ctx *c, int n, const qrgpu_gait_desc *desc, fl
     memcpy(D.initial_leg_state, desc->initial_leg_state, 16);
     D.contact_detection_phase_threshold = desc->contact_detection_phase_threshold; D.wait_time = desc->wait_time; D.advanced_trot = desc->advanced_trot;
     hipLaunchKernelGGL(qr_gait_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, current_time, robot_stop, reset, d_contact, d_gait_state, d_gait_out, d_fe_in);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+void qrgpu_foothold_desc_default(qrgpu_foothold_desc *d)
+{
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    const float ho[12] = {0.1805f, -0.047f, 0.f, 0.1805f, 0.047f, 0.f, -0.1805f, -0.047f, 0.f, -0.1805f, 0.047f, 0.f};
+    const float hp[12] = {0.185f, -0.135f, 0.f, 0.185f, 0.135f, 0.f, -0.185f, -0.135f, 0.f, -0.185f, 0.135f, 0.f};     // config/a1_sim/a1_sim.yaml:40-43
+    memcpy(d->hip_offset, ho, sizeof(ho)); memcpy(d->default_hip_position, hp, sizeof(hp));
+    d->hip_l = 0.08505f; d->swing_kp[0] = d->swing_kp[1] = d->swing_kp[2] = 0.16f; d->foot_clearance = 0.01f;
+}
+
+int qrgpu_footholds_batch(qrgpu_ctx *c, int n, const qrgpu_foothold_desc *desc, const float *d_fh_in, const float *d_gait_state,
+                          const float *d_gait_out, float *d_swing_in)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !d_fh_in || !d_swing_in) return QRGPU_ERR_BAD_ARG;
+    if ((d_gait_state == nullptr) != (d_gait_out == nullptr)) return QRGPU_ERR_BAD_ARG;      // both or neither
+    HIPCHK(c, hipSetDevice(c->device));
+    FootholdDesc D;
+    memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset)); memcpy(D.default_hip_position, desc->default_hip_position, sizeof(D.default_hip_position));
+    D.hip_l = desc->hip_l; memcpy(D.swing_kp, desc->swing_kp, sizeof(D.swing_kp)); D.foot_clearance = desc->foot_clearance;
+    hipLaunchKernelGGL(qr_foothold_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_fh_in, d_gait_state, d_gait_out, d_swing_in);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

@@ -52,6 +52,11 @@ class estimator_desc_struct(C.Structure):
                 ("body_height", C.c_float)]
 
 
+class foothold_desc_struct(C.Structure):
+    _fields_ = [("hip_offset", C.c_float * 12), ("default_hip_position", C.c_float * 12), ("hip_l", C.c_float), ("swing_kp", C.c_float * 3),
+                ("foot_clearance", C.c_float)]
+
+
 class gait_desc_struct(C.Structure):
     _fields_ = [("stance_duration", C.c_float * 4), ("duty_factor", C.c_float * 4), ("initial_leg_phase", C.c_float * 4),
                 ("initial_leg_state", C.c_int * 4), ("contact_detection_phase_threshold", C.c_float), ("wait_time", C.c_float),
@@ -67,7 +72,8 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
-           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch"]
+           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
+           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch"]
 
 
 def load_library():
@@ -103,6 +109,8 @@ def load_library():
     lib.qrgpu_gait_desc_default.argtypes = [C.POINTER(gait_desc_struct)]; lib.qrgpu_gait_desc_default.restype = None
     lib.qrgpu_gait_update_batch.argtypes = [vp, ip, C.POINTER(gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp]
     lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
+    lib.qrgpu_foothold_desc_default.argtypes = [C.POINTER(foothold_desc_struct)]; lib.qrgpu_foothold_desc_default.restype = None
+    lib.qrgpu_footholds_batch.argtypes = [vp, ip, C.POINTER(foothold_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_pack_state_batch.argtypes = [vp, ip, fp, vp, vp, vp, vp, vp]
     lib.qrgpu_vmc_force1.argtypes = [vp, ip, fp, fp, fp, fp, C.POINTER(ip)]
     lib.qrgpu_mpc_frontend_batch.argtypes = [vp, ip, ip, C.c_float, C.c_float] + [vp] * 6
@@ -285,6 +293,19 @@ class Context:
         d.contact_detection_phase_threshold = float(cfg19[16]); d.wait_time = float(cfg19[17]); d.advanced_trot = int(cfg19[18])
         self._chk(self._lib.qrgpu_gait_update_batch(self._h, n, C.byref(d), float(current_time), int(bool(stop)), int(bool(reset)), _dp(contact),
                                                     _dp(gait_state), _dp(gait_out), _dp(fe_in)))
+
+    def footholds_batch(self, n, desc29, fh_in, swing_in, gait_state=None, gait_out=None):
+        """Swing-leg selection + foothold heuristic (qr_swing_leg_controller.cpp:211-236, qr_foothold_planner.cpp:110-239).
+        desc29 = workload.foothold_cfg(): hip_offset[12], default_hip_position[12], hip_l, swing_kp[3], foot_clearance."""
+        d = foothold_desc_struct()
+        self._lib.qrgpu_foothold_desc_default(C.byref(d))
+        v = np.asarray(desc29, np.float32)
+        for i in range(12):
+            d.hip_offset[i] = float(v[i]); d.default_hip_position[i] = float(v[12 + i])
+        d.hip_l = float(v[24]); d.foot_clearance = float(v[28])
+        for i in range(3):
+            d.swing_kp[i] = float(v[25 + i])
+        self._chk(self._lib.qrgpu_footholds_batch(self._h, n, C.byref(d), _dp(fh_in), _dp(gait_state), _dp(gait_out), _dp(swing_in)))
 
     def swing_targets_batch(self, n, cfg20, swing_in, wbc_cmd=None, foot_target_world=None, qdes=None):
         """Swing-leg targets (qr_swing_leg_controller.cpp:362-424, ADVANCED_TROT).  cfg20 = workload.estimator_cfg() (geometry part)."""

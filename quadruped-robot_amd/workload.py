@@ -20,13 +20,15 @@ ROBOTS = {
                weights=(10, 10, 5, 40, 60, 100, 0, 0, 0.5, 5, 5, 1),
                hip_l=0.08505, upper_l=0.2, lower_l=0.2, body_size=(0.267, 0.194, 0.114),
                com_offset=(-0.008, 0.005, 0.0),
-               hip_offset=((0.1805, -0.047, 0.0), (0.1805, 0.047, 0.0), (-0.1805, -0.047, 0.0), (-0.1805, 0.047, 0.0))),
+               hip_offset=((0.1805, -0.047, 0.0), (0.1805, 0.047, 0.0), (-0.1805, -0.047, 0.0), (-0.1805, 0.047, 0.0)),
+               default_hip_position=((0.185, -0.135, 0.0), (0.185, 0.135, 0.0), (-0.185, -0.135, 0.0), (-0.185, 0.135, 0.0))),
     # Q/config/lite3_sim/robot.yaml, stance_leg_controller.yaml
     "lite3": dict(type_id=1, mass=8.742, inertia=(0.24, 0.8, 1.0),
                   weights=(20, 20, 10, 40, 40, 150, 0.5, 1, 1, 5, 5, 10),
                   hip_l=0.0985, upper_l=0.20, lower_l=0.20, body_size=(0.349, 0.124, 0.15),
                   com_offset=(-0.012, 0.0, 0.0),
-                  hip_offset=((0.175, -0.062, 0.0), (0.175, 0.062, 0.0), (-0.175, -0.062, 0.0), (-0.175, 0.062, 0.0))),
+                  hip_offset=((0.175, -0.062, 0.0), (0.175, 0.062, 0.0), (-0.175, -0.062, 0.0), (-0.175, 0.062, 0.0)),
+                  default_hip_position=((0.1745, -0.15, 0.0), (0.1745, 0.15, 0.0), (-0.1745, -0.15, 0.0), (-0.1745, 0.15, 0.0))),
 }
 DT_MPC = 0.06      # qr_mpc_stance_leg_controller.cpp:43
 MU_MPC = 0.45      # :90
@@ -352,6 +354,45 @@ def make_swing_batch(n, robot="a1", seed=0x5E):
     x[:, 46:58] = np.tile(np.array([0.0, 0.9, -1.8], f32), (n, 4))
     x[-1, 24:27] = (2.0, 0.0, -0.3)                      # an unreachable foothold: NaN angles fall back to the current ones
     x[-1, 0] = 1; x[-1, 4] = 0.9
+    return x
+
+
+def foothold_cfg(robot="a1", swing_kp=(0.16, 0.16, 0.16), foot_clearance=0.01):
+    """Packed float32[29]: hip_offset[12], default_hip_position[12], hip_l, swing_kp[3], foot_clearance
+    (robot_params.hip_offset / default_hip_positions, user_parameters.yaml swingKp.advanced_trot / footClearance)."""
+    r = ROBOTS[robot]
+    return np.array([*np.asarray(r["hip_offset"], f32).reshape(12), *np.asarray(r["default_hip_position"], f32).reshape(12), r["hip_l"],
+                     *swing_kp, foot_clearance], dtype=f32)
+
+
+def make_foothold_batch(n, robot="a1", seed=0xF0):
+    """Synthetic inputs of the foothold kernel, AoS [n][46] (layout: include/qrgpu.h fh_in): trotting leg states with a few early
+    contacts and lost contacts, some robots holding their schedule (allowSwitchLegState = 0 on a leg), commands up to the clip."""
+    rng = np.random.default_rng(seed)
+    r = ROBOTS[robot]
+    x = np.zeros((n, 46), f32)
+    pair = rng.integers(0, 3, n)
+    st = np.ones((n, 4), f32)
+    st[pair == 0] = (0, 1, 1, 0); st[pair == 1] = (1, 0, 0, 1)
+    odd = rng.random((n, 4))
+    st = np.where(odd < 0.03, 2, np.where(odd > 0.97, 3, st)).astype(f32)          # EARLY_CONTACT / LOSE_CONTACT
+    x[:, 0:4] = st
+    x[:, 4:8] = (rng.random((n, 4)) > 0.1)
+    x[:, 8:12] = rng.uniform(0.0, 0.25, (n, 4))
+    x[:, 12:16] = rng.uniform(0.0, 1.0, (n, 4))
+    x[:, 16:19] = np.stack([rng.uniform(-0.5, 1.5, n), rng.uniform(-0.5, 0.5, n), np.zeros(n)], 1)
+    x[: n // 8, 16] = 3.0                                                        # beyond the 0.2 m clip
+    x[:, 19] = rng.uniform(-1.5, 1.5, n)
+    x[:, 20] = 0.28 + 0.02 * rng.standard_normal(n)
+    hip = np.asarray(r["hip_offset"], f32)
+    side = np.array([-1, 1, -1, 1], f32) * r["hip_l"]
+    for leg in range(4):
+        x[:, 21 + 3 * leg:24 + 3 * leg] = hip[leg] + np.array([0, side[leg], -0.27], f32) + 0.04 * rng.standard_normal((n, 3))
+    rpy = np.stack([0.1 * rng.standard_normal(n), 0.1 * rng.standard_normal(n), rng.uniform(-np.pi, np.pi, n)], 1)
+    x[:, 33:37] = _quat_from_rpy(rpy)
+    x[:, 37:40] = rpy
+    x[:, 40:43] = np.stack([rng.uniform(-0.5, 1.5, n), rng.uniform(-0.5, 0.5, n), 0.1 * rng.standard_normal(n)], 1)
+    x[:, 43:46] = rng.uniform(-1.0, 1.0, (n, 3))
     return x
 
 

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 
@@ -56,7 +58,7 @@ def test_all_kernels_present(pkg):
     """Every kernel of the path and of the SURVEY 8f rows is in the gfx950 code object."""
     data = open(pkg._build.build(), "rb").read()
     for k in (b"qr_mpc_kernel", b"qr_wbc_kernel", b"qr_vmc_kernel", b"qr_frontend_kernel", b"qr_estimator_kernel", b"qr_pack_state_kernel",
-              b"qr_swing_kernel", b"qr_lpt_order_kernel"):
+              b"qr_swing_kernel", b"qr_gait_kernel", b"qr_foothold_kernel", b"qr_lpt_order_kernel"):
         assert k in data, k
 
 
@@ -67,6 +69,9 @@ def test_desc_defaults(pkg):
     e = pkg.qrgpu.estimator_desc_struct(); lib.qrgpu_estimator_desc_default(C.byref(e))
     assert e.window == 120 and abs(e.time_step - 0.002) < 1e-9 and abs(e.hip_offset[0] - 0.1805) < 1e-7
     assert lib.qrgpu_estimator_state_doubles(120) == 96 + 360 and lib.qrgpu_estimator_state_doubles(0) == 0
+    f = pkg.qrgpu.foothold_desc_struct(); lib.qrgpu_foothold_desc_default(C.byref(f))
+    assert abs(f.swing_kp[1] - 0.16) < 1e-7 and abs(f.foot_clearance - 0.01) < 1e-9 and abs(f.default_hip_position[1] + 0.135) < 1e-7
+    assert np.allclose(np.array(f.hip_offset[:] + f.default_hip_position[:] + [f.hip_l] + f.swing_kp[:] + [f.foot_clearance], np.float32), pkg.workload.foothold_cfg("a1"))
 
 
 @pytest.mark.gpu

@@ -38,3 +38,57 @@ def test_swing_targets_properties(pkg, oracle):
             fk = oracle.foot_positions(geom, ho, qfull).reshape(4, 3)[leg]
             np.testing.assert_allclose(fk, pb, atol=5e-6)
             assert np.all(o[60:72][sl] == 0)
+
+
+def _rot(quat):
+    w, x, y, z = [float(v) for v in quat]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_foothold_heuristic_properties(pkg, oracle):
+    """qrRaibertSwingLegController::Update (swing-leg selection) + qrFootholdPlanner::ComputeHeuristicFootHold restated
+    (qr_swing_leg_controller.cpp:211-236, qr_foothold_planner.cpp:110-239): pinned by what the formulas imply (Eigen cannot be compiled here)."""
+    W = pkg.workload
+    desc = W.foothold_cfg("a1")
+    ho, hp, hl, kp, clr = desc[:12].reshape(4, 3), desc[12:24].reshape(4, 3), desc[24], desc[25:28], desc[28]
+    x = W.make_foothold_batch(400, seed=3)
+    side = np.array([-1, 1, -1, 1])
+    seen = dict(stance=0, early=0, hold=0, clip=0, free=0)
+    for i in range(x.shape[0]):
+        prev = np.full(58, -777.0, np.float32)
+        o = oracle.footholds(desc, x[i], prev)
+        R = _rot(x[i, 33:37])
+        for leg in range(4):
+            st, allow = int(x[i, leg]), x[i, 4 + leg] != 0
+            skip = (st == 1 and allow) or st == 2
+            assert o[leg] == (0.0 if skip else 1.0)
+            if skip:
+                assert o[4 + leg] == -777.0 and np.all(o[24 + 3 * leg:27 + 3 * leg] == -777.0)      # the planner's members keep their values
+                seen["early" if st == 2 else "stance"] += 1
+                continue
+            f = o[24 + 3 * leg:27 + 3 * leg].astype(np.float64)
+            if not allow:
+                # the foot stays where it is relative to the default hip, 2 cm lower and 5 mm towards the body axis, in the world-aligned frame
+                t = R @ (x[i, 21 + 3 * leg:24 + 3 * leg] - hp[leg])
+                t[1] += -0.005 if t[1] > 0.01 else (0.005 if t[1] < -0.01 else 0.0)
+                t[2] -= 0.02
+                assert np.abs(f - (R.T @ t + hp[leg])).max() < 2e-6 and o[4 + leg] == 1.0
+                seen["hold"] += 1
+                continue
+            assert o[4 + leg] == x[i, 12 + leg]                                                  # phase = normalizedPhase
+            hv = R @ (x[i, 40:43] + np.cross(x[i, 43:46], ho[leg])); hv[2] = 0
+            tv = x[i, 16:19] + x[i, 19] * np.array([-ho[leg, 1], ho[leg, 0], 0])
+            dP = R.T @ (tv * x[i, 8 + leg] - kp * (tv - hv))
+            clipped = np.abs(dP[:2]).max() > 0.2
+            dP = np.array([np.clip(dP[0], -0.2, 0.2), np.clip(dP[1], -0.2, 0.2), 0.0])
+            c, s = np.cos(x[i, 37]), np.sin(x[i, 37])
+            expect = dP + np.array([ho[leg, 0], ho[leg, 1], 0]) + np.array([0, c * hl * side[leg], -s * hl * side[leg]]) - R.T @ np.array([0, 0, x[i, 20] - clr])
+            assert np.abs(f - expect).max() < 3e-6, (i, leg, f, expect)
+            seen["clip" if clipped else "free"] += 1
+    assert all(v > 0 for v in seen.values()), seen
+    # a robot standing still, level, with zero command: the foothold is under the hip joint, body height minus clearance below it
+    z = np.zeros(46, np.float32); z[0:4] = 0; z[4:8] = 1; z[20] = 0.28; z[33] = 1.0
+    o = oracle.footholds(desc, z)
+    for leg in range(4):
+        assert np.allclose(o[24 + 3 * leg:27 + 3 * leg], [ho[leg, 0], ho[leg, 1] + hl * side[leg], -(0.28 - clr)], atol=1e-7)
