@@ -16,7 +16,8 @@
  *   qrgpu_wbc_run_batch    <- the same, for n robots
  *   qrgpu_mpc_frontend_batch <- MPCStanceLegController::SetupCommand/Run/UpdateMPC (reference trajectory + contact table)
  *                             QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-382
- *   qrgpu_vmc_setup / qrgpu_vmc_force_batch <- Quadruped::ComputeContactForce (control-frame overload) + qrRobot::MapContactForceToJointTorques
+ *   qrgpu_vmc_setup / qrgpu_vmc_force_batch / qrgpu_vmc_force_world_batch <- Quadruped::ComputeContactForce (control-frame and world-frame
+ *                             overloads, :190-301, :304-398) + qrRobot::MapContactForceToJointTorques
  *                             QS/controllers/balance_controller/qr_qp_torque_optimizer.cpp:190-301, QS/robots/qr_robot.cpp:241-251
  *                             (what TorqueStanceLegController::GetAction calls, qr_torque_stance_leg_controller.cpp:500-507)
  *   qrgpu_estimator_update_batch <- qrRobot::UpdateDataFlow (leg kinematics) + qrRobotVelocityEstimator::Update + qrRobotPoseEstimator::Update
@@ -182,6 +183,13 @@ int qrgpu_mpc_frontend_batch(qrgpu_ctx *ctx, int n, int num_horizon_l, float dt_
 int qrgpu_vmc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_vmc_desc *desc);
 int qrgpu_vmc_force_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q /*[12][n], may be NULL*/,
                           float *d_force, float *d_tau /*may be NULL*/, int *d_status /*may be NULL*/);
+/* The world-frame overload of ComputeContactForce (qr_qp_torque_optimizer.cpp:304-398; what TorqueStanceLegController::GetAction calls when
+ * user_parameters.yaml computeForceInWorldFrame is true, qr_torque_stance_leg_controller.cpp:490-498): the same QP with, in d_vmc_in,
+ * Rcb := rotMat (base -> world, quaternionToRotationMatrix(quat)^T), gvec := (0, 0, 9.8), normal := (0, 0, 1) -- the tangents are then the
+ * world x and y axes, as GetAction passes them -- and per-leg force-window ratios d_ratio [8][n] = fMinRatio[4], fMaxRatio[4] (the Vec4
+ * members that the walk mode changes per tick, :128-152).  Forces come back in the base frame, as RigidTransform(0, quat, X^T) returns them. */
+int qrgpu_vmc_force_world_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_vmc_in, const float *d_ratio, const float *d_q,
+                                float *d_force, float *d_tau, int *d_status);
 
 /* Base velocity estimator (TinyEKF<3,3> + moving-window filters), the leg kinematics it reads and the pose estimator that follows it
  * (stance-foot height, planar odometry), for n robots and one control tick.
@@ -264,6 +272,8 @@ int qrgpu_wbc_run1(qrgpu_ctx *ctx, int type_id, const float fb_state[37], const 
 
 int qrgpu_vmc_force1(qrgpu_ctx *ctx, int type_id, const float vmc_in[37], const float q[12] /*may be NULL*/,
                      float force_out[12], float tau_out[12] /*may be NULL*/, int *status);
+int qrgpu_vmc_force_world1(qrgpu_ctx *ctx, int type_id, const float vmc_in[37], const float ratio[8] /* fMinRatio[4], fMaxRatio[4] */,
+                           const float q[12] /*may be NULL*/, float force_out[12], float tau_out[12] /*may be NULL*/, int *status);
 
 /* ---- inspection (parity tests): the fp32 QP data the MPC kernel assembled ----- */
 /* d_H: [n][12h*12h] row-major per robot, d_g: [n][12h]; entries that involve a swing

@@ -163,6 +163,29 @@ inline int VmcContactForce(Robot *robot, const float Rcb[9], const float g3[3], 
     return status;
 }
 
+// The world-frame overload, ComputeContactForce(robot, desiredAcc, contacts, accWeight, normal, tangent1, tangent2, fMinRatio, fMaxRatio, ...)
+// (qr_qp_torque_optimizer.cpp:304-398) as TorqueStanceLegController::GetAction calls it with the identity's columns (:490-498):
+// rotMat = quaternionToRotationMatrix(robot->GetBaseOrientation()).transpose(), row-major; V4 ratios are the controller's Vec4 members.
+template <class Robot, class V6, class V4b, class V4min, class V4max, class M34>
+inline int VmcContactForceWorld(Robot *robot, const float rotMat[9], const V6 &desiredAcc, const V4b &contacts, const V4min &fMinRatio, const V4max &fMaxRatio, M34 &out)
+{
+    auto &g = global();
+    if (!g.ctx) return QRGPU_ERR_NO_DEVICE;
+    float in[37], ratio[8];
+    auto fp = robot->GetFootPositionsInBaseFrame();
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) in[3 * l + i] = fp(i, l);
+    for (int i = 0; i < 6; ++i) in[12 + i] = desiredAcc[i];
+    for (int l = 0; l < 4; ++l) { in[18 + l] = contacts[l] ? 1.f : 0.f; ratio[l] = fMinRatio[l]; ratio[4 + l] = fMaxRatio[l]; }
+    for (int i = 0; i < 9; ++i) in[22 + i] = rotMat[i];
+    in[31] = 0.f; in[32] = 0.f; in[33] = 9.8f; in[34] = 0.f; in[35] = 0.f; in[36] = 1.f;
+    float f[12];
+    int status = 0;
+    int rc = qrgpu_vmc_force_world1(g.ctx, 0, in, ratio, nullptr, f, nullptr, &status);
+    if (rc != QRGPU_OK) return rc;
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) out(i, l) = f[3 * l + i];
+    return status;
+}
+
 inline int VmcSetup(const qrgpu_vmc_desc &d)
 {
     auto &g = global();

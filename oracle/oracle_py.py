@@ -230,19 +230,21 @@ def mpc_frontend(horizon, num_horizon_l, in64, st8, dt=0.002, dt_mpc=0.06):
     return dict(traj=traj, gait=gait, wbc15=wbc, contact=ct, state=st, updated=upd.value)
 
 
-def vmc_assemble(cfg20, in37):
+def vmc_assemble(cfg20, in37, ratio8=None):
     """fp32 QP data of ComputeContactForce: G[12,12], a[12], CI[12,24] (= A^T), b[24]"""
     G = np.zeros((12, 12), _f); a = np.zeros(12, _f); CI = np.zeros((12, 24), _f); b = np.zeros(24, _f)
-    lib().qro_vmc_assemble(_fp(np.ascontiguousarray(cfg20, _f)), _fp(np.ascontiguousarray(in37, _f)), _fp(G), _fp(a), _fp(CI), _fp(b))
+    r8 = np.ascontiguousarray(ratio8, _f) if ratio8 is not None else None
+    lib().qro_vmc_assemble(_fp(np.ascontiguousarray(cfg20, _f)), _fp(np.ascontiguousarray(in37, _f)), _fp(r8) if r8 is not None else None, _fp(G), _fp(a), _fp(CI), _fp(b))
     return G, a, CI, b
 
 
-def vmc_solve(cfg20, geom3, in37, q12=None):
+def vmc_solve(cfg20, geom3, in37, q12=None, ratio8=None):
     """-> force[12] (3*leg+axis, base frame), tau[12] or None, x[12] (raw QuadProg solution), stats, rc"""
     force = np.zeros(12, _f); tau = np.zeros(12, _f); x = np.zeros(12); st = np.zeros(4, np.int32)
     qa = np.ascontiguousarray(q12, _f) if q12 is not None else None
+    r8 = np.ascontiguousarray(ratio8, _f) if ratio8 is not None else None
     rc = lib().qro_vmc_solve(_fp(np.ascontiguousarray(cfg20, _f)), _fp(np.ascontiguousarray(geom3, _f)), _fp(np.ascontiguousarray(in37, _f)),
-                             _fp(qa) if qa is not None else None, _fp(force), _fp(tau) if qa is not None else None, _dp(x), _ip(st))
+                             _fp(r8) if r8 is not None else None, _fp(qa) if qa is not None else None, _fp(force), _fp(tau) if qa is not None else None, _dp(x), _ip(st))
     return force, (tau if qa is not None else None), x, dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])), rc
 
 

@@ -207,6 +207,8 @@ struct VmcInput {                 // per tick
     float Rcb[9];                 // row-major; identity on PLANE / PLUM_PILES terrain (:217-223)
     float gvec[3];                // g.head(3): (0,0,9.8) on a plane
     float normal[3];              // surfaceNormal
+    // world-frame overload (:304-398): per-leg force-window ratios fMinRatio[4], fMaxRatio[4] (Vec4 arguments); null = the scalar ones
+    const float *ratio8 = nullptr;
 };
 void vmc_assemble(const VmcConfig &c, const VmcInput &in, float G[144], float a[12], float CI[12 * 24], float b[24]);
 int vmc_solve(const VmcConfig &c, const VmcInput &in, float force[12], double xout[12], QpStats *st);

@@ -3,6 +3,10 @@
 // Force-balance ("VMC") stance QP, SURVEY.md 8f rank 2: restates
 //   ComputeMassMatrix / ComputeConstraintMatrix / ComputeObjectiveMatrix / ComputeWeightMatrix / ComputeContactForce
 //   QS/controllers/balance_controller/qr_qp_torque_optimizer.cpp:31-57, 60-110, 152-179, 183-187, 190-301  (control-frame overload)
+//   and the world-frame overload :304-398 with its ComputeMassMatrix / ComputeConstraintMatrix :401-427, :113-149 -- the same QP with
+//   Rcb := rotMat (base -> world), g := (0,0,9.8), normal / tangents := the world axes (TorqueStanceLegController::GetAction passes the
+//   identity's columns, qr_torque_stance_leg_controller.cpp:490-498) and per-leg force-window ratios; both overloads return the
+//   forces rotated back to the base frame ((X * Rcb)^T :300, RigidTransform(0, quat, X^T) :397)
 //   qrRobot::MapContactForceToJointTorques    QS/robots/qr_robot.cpp:241-251
 // The QP itself is QuadProg++ in the reference (solve_quadprog, :276) -- pinned by oracle/_ref (tests/golden/vmc_golden.npz).
 // The fp32 matrix assembly is Eigen's in the reference and cannot be compiled here: "parity unpinned" at that boundary.  The
@@ -87,7 +91,11 @@ void vmc_assemble(const VmcConfig &c, const VmcInput &in, float G[144], float a[
             CI[(3 * l + ax) * 24 + 8 + 4 * l + 2] = mn + t2[ax];
             CI[(3 * l + ax) * 24 + 8 + 4 * l + 3] = mn - t2[ax];
         }
-        if (in.contacts[l] > 0.f) { b[2 * l] = fMin; b[2 * l + 1] = -fMax; }
+        if (in.contacts[l] > 0.f && in.ratio8) {
+            // lb = fMinRatio[leg] * mpcBodyMass * 9.8 (:133-134): float product times the double literal, rounded to float on assignment
+            b[2 * l] = (float)((double)(in.ratio8[l] * c.mass) * 9.8); b[2 * l + 1] = (float)((double)(-in.ratio8[4 + l] * c.mass) * 9.8);
+        }
+        else if (in.contacts[l] > 0.f) { b[2 * l] = fMin; b[2 * l + 1] = -fMax; }
         else { b[2 * l] = 1e-7f; b[2 * l + 1] = 1e-7f; }
         for (int r = 0; r < 4; ++r) b[8 + 4 * l + r] = 0.f;
     }
@@ -148,14 +156,14 @@ static void unpack(const float *cfg20, const float *in37, qro::VmcConfig &c, qro
     for (int i = 0; i < 9; ++i) in.Rcb[i] = in37[22 + i];
     for (int i = 0; i < 3; ++i) { in.gvec[i] = in37[31 + i]; in.normal[i] = in37[34 + i]; }
 }
-void qro_vmc_assemble(const float *cfg20, const float *in37, float *G, float *a, float *CI, float *b)
+void qro_vmc_assemble(const float *cfg20, const float *in37, const float *ratio8, float *G, float *a, float *CI, float *b)
 {
-    qro::VmcConfig c; qro::VmcInput in; unpack(cfg20, in37, c, in);
+    qro::VmcConfig c; qro::VmcInput in; unpack(cfg20, in37, c, in); in.ratio8 = ratio8;
     qro::vmc_assemble(c, in, G, a, CI, b);
 }
-int qro_vmc_solve(const float *cfg20, const float *geom3, const float *in37, const float *q12, float *force, float *tau, double *x, int *stats4)
+int qro_vmc_solve(const float *cfg20, const float *geom3, const float *in37, const float *ratio8, const float *q12, float *force, float *tau, double *x, int *stats4)
 {
-    qro::VmcConfig c; qro::VmcInput in; unpack(cfg20, in37, c, in);
+    qro::VmcConfig c; qro::VmcInput in; unpack(cfg20, in37, c, in); in.ratio8 = ratio8;
     qro::QpStats st;
     const int rc = qro::vmc_solve(c, in, force, x, &st);
     if (q12 && tau) { qro::LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2]; qro::vmc_force_to_torque(g, q12, force, tau); }

@@ -75,6 +75,7 @@ struct VmcType {
 struct VmcLaunch {
     VmcType type[QR_MAX_TYPES];
     int n;
+    const float *ratio;      // [8][n] per-leg fMinRatio[4], fMaxRatio[4] of the world-frame overload, or null (the type's scalar ratios)
 };
 
 // Velocity-estimator parameters (qrgpu_estimator_desc)

@@ -37,7 +37,7 @@ __device__ __forceinline__ float chain3(float a0, float b0, float a1, float b1, 
 
 // fp32 QP data -> LDS.  sIn: the 37 inputs.  Outputs: Gf[144], af[12], cn[24][3], bf[24].
 __device__ __forceinline__ void vmc_assemble(int lane, const VmcType &C, const float *sIn, float *sA /*9*3 scratch*/, float *xc, float *Mm, float *Gf,
-                                             float *af, float *cn, float *bf)
+                                             float *af, float *cn, float *bf, const float *ratio /* fMinRatio[4], fMaxRatio[4] or null */)
 {
 #pragma clang fp contract(off)
     const float *pb = sIn, *acc_des = sIn + 12, *ct = sIn + 18, *R = sIn + 22, *gv = sIn + 31, *nrm = sIn + 34;
@@ -103,6 +103,12 @@ __device__ __forceinline__ void vmc_assemble(int lane, const VmcType &C, const f
             const int l = lane >> 1; const bool neg = lane & 1;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) cn[3 * lane + ax] = neg ? -nrm[ax] : nrm[ax];
+            if (ratio) {
+                // world-frame overload: lb = ratio[leg] * mass * 9.8 with the double literal (qr_qp_torque_optimizer.cpp:133-134)
+                const float rt = ratio[neg ? 4 + l : l];
+                const float w = (float)((double)((neg ? -rt : rt) * C.mass) * 9.8);
+                b = (ct[l] > 0.f) ? w : 1e-7f;
+            } else
             b = (ct[l] > 0.f) ? (neg ? -fMax : fMin) : 1e-7f;
         } else {
             const int r = (lane - 8) & 3;
@@ -129,13 +135,14 @@ __global__ void __launch_bounds__(64) qr_vmc_kernel(VmcLaunch P, const int *__re
     if (rid < 0) return;
     const VmcType &C = P.type[type_id ? type_id[rid] : 0];
 
-    __shared__ float sIn[40], sA[27], xc[12], Mm[72], Gf[144], af[12], cn[72], bf[24];
+    __shared__ float sIn[48], sA[27], xc[12], Mm[72], Gf[144], af[12], cn[72], bf[24];
     __shared__ double Md[144], colv[12], xd[12], wd[12], zd[12], Sq[13 * 13], dd[12], rr[12], uu[13], mna[12 * 12];
     __shared__ int act[12];
 
     if (lane < 37) sIn[lane] = g_in[(size_t)lane * n + rid];
+    if (P.ratio && lane >= 40 && lane < 48) sIn[lane] = P.ratio[(size_t)(lane - 40) * n + rid];
     vsync();
-    vmc_assemble(lane, C, sIn, sA, xc, Mm, Gf, af, cn, bf);
+    vmc_assemble(lane, C, sIn, sA, xc, Mm, Gf, af, cn, bf, P.ratio ? sIn + 40 : nullptr);
 
     // ---- G (mirrored lower triangle) -> fp64, c1 = tr G
     for (int e = lane; e < 144; e += 64) { const int i = e / 12, j = e - 12 * i; Md[e] = (double)Gf[12 * (i > j ? i : j) + (i > j ? j : i)]; }

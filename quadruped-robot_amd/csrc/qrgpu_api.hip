@@ -594,18 +594,31 @@ int qrgpu_vmc_setup(qrgpu_ctx *c, int type_id, const qrgpu_vmc_desc *d)
     return QRGPU_OK;
 }
 
-int qrgpu_vmc_force_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q, float *d_force, float *d_tau,
-                          int *d_status)
+static int launch_vmc(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_vmc_in, const float *d_ratio, const float *d_q, float *d_force,
+                      float *d_tau, int *d_status)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_vmc_in || !d_force) return QRGPU_ERR_BAD_ARG;
     if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
     if (!c->vmc_ready[0]) return QRGPU_ERR_NOT_SETUP;
     HIPCHK(c, hipSetDevice(c->device));
     VmcLaunch P = c->vmc;
-    P.n = n;
+    P.n = n; P.ratio = d_ratio;
     hipLaunchKernelGGL(qr_vmc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, P, d_type_id, d_vmc_in, d_q, d_force, d_tau, d_status);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
+}
+
+int qrgpu_vmc_force_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_vmc_in, const float *d_q, float *d_force, float *d_tau,
+                          int *d_status)
+{
+    return launch_vmc(c, n, d_type_id, d_vmc_in, nullptr, d_q, d_force, d_tau, d_status);
+}
+
+int qrgpu_vmc_force_world_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_vmc_in, const float *d_ratio, const float *d_q,
+                                float *d_force, float *d_tau, int *d_status)
+{
+    if (!d_ratio) return QRGPU_ERR_BAD_ARG;
+    return launch_vmc(c, n, d_type_id, d_vmc_in, d_ratio, d_q, d_force, d_tau, d_status);
 }
 
 int qrgpu_mpc_frontend_batch(qrgpu_ctx *c, int n, int num_horizon_l, float dt_ctrl, float dt_mpc, const float *d_fe_in, float *d_fe_state,
@@ -695,21 +708,24 @@ int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const fl
     return QRGPU_OK;
 }
 
-int qrgpu_vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const float q[12], float force_out[12], float tau_out[12], int *status)
+static int vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const float ratio[8], const float q[12], float force_out[12], float tau_out[12],
+                      int *status)
 {
     if (!c || !vmc_in || !force_out) return QRGPU_ERR_BAD_ARG;
     if (tau_out && !q) return QRGPU_ERR_BAD_ARG;
     if (type_id < 0 || type_id >= QR_MAX_TYPES || !c->vmc_ready[type_id]) return QRGPU_ERR_NOT_SETUP;
-    float in[37 + 12];
+    float in[37 + 12 + 8];
+    memset(in, 0, sizeof(in));
     memcpy(in, vmc_in, 37 * 4);
     if (q) memcpy(in + 37, q, 48);
+    if (ratio) memcpy(in + 49, ratio, 32);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->d_in1, in, sizeof(in), hipMemcpyHostToDevice, c->stream));
     int *d_type = nullptr;
     int tid_host = type_id;
     if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
     VmcLaunch P = c->vmc;
-    P.n = 1;
+    P.n = 1; P.ratio = ratio ? c->d_in1 + 49 : nullptr;
     hipLaunchKernelGGL(qr_vmc_kernel, dim3(8), dim3(64), 0, c->stream, P, d_type, c->d_in1, q ? c->d_in1 + 37 : nullptr, c->d_out1,
                        (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1);
     HIPCHK(c, hipGetLastError());
@@ -721,6 +737,18 @@ int qrgpu_vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const fl
     if (q && tau_out) memcpy(tau_out, out + 12, 48);
     if (status) *status = st;
     return QRGPU_OK;
+}
+
+int qrgpu_vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const float q[12], float force_out[12], float tau_out[12], int *status)
+{
+    return vmc_force1(c, type_id, vmc_in, nullptr, q, force_out, tau_out, status);
+}
+
+int qrgpu_vmc_force_world1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const float ratio[8], const float q[12], float force_out[12],
+                           float tau_out[12], int *status)
+{
+    if (!ratio) return QRGPU_ERR_BAD_ARG;
+    return vmc_force1(c, type_id, vmc_in, ratio, q, force_out, tau_out, status);
 }
 
 int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to disable */, int n)

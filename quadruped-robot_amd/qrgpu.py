@@ -73,7 +73,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
-           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch"]
+           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1"]
 
 
 def load_library():
@@ -103,6 +103,7 @@ def load_library():
     lib.qrgpu_vmc_desc_default.argtypes = [C.POINTER(vmc_desc_struct)]; lib.qrgpu_vmc_desc_default.restype = None
     lib.qrgpu_vmc_setup.argtypes = [vp, ip, C.POINTER(vmc_desc_struct)]
     lib.qrgpu_vmc_force_batch.argtypes = [vp, ip] + [vp] * 6
+    lib.qrgpu_vmc_force_world_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_estimator_desc_default.argtypes = [C.POINTER(estimator_desc_struct)]; lib.qrgpu_estimator_desc_default.restype = None
     lib.qrgpu_estimator_state_doubles.argtypes = [ip]
     lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
@@ -263,6 +264,10 @@ class Context:
     def vmc_force_batch(self, n, vmc_in, q, force, tau=None, status=None, type_id=None):
         """ComputeContactForce (+ MapContactForceToJointTorques) of n robots: qr_qp_torque_optimizer.cpp:190-301."""
         self._chk(self._lib.qrgpu_vmc_force_batch(self._h, n, _dp(type_id), _dp(vmc_in), _dp(q), _dp(force), _dp(tau), _dp(status)))
+
+    def vmc_force_world_batch(self, n, vmc_in, ratio, q, force, tau=None, status=None, type_id=None):
+        """World-frame overload (qr_qp_torque_optimizer.cpp:304-398): vmc_in carries Rcb = rotMat, gvec = (0,0,9.8), normal = e_z; ratio [8][n]."""
+        self._chk(self._lib.qrgpu_vmc_force_world_batch(self._h, n, _dp(type_id), _dp(vmc_in), _dp(ratio), _dp(q), _dp(force), _dp(tau), _dp(status)))
 
     def vmc_force1(self, vmc_in, q=None, type_id=0):
         a = np.ascontiguousarray(vmc_in, np.float32); qa = np.ascontiguousarray(q, np.float32) if q is not None else None

@@ -285,6 +285,27 @@ def make_vmc_batch(n, robot="a1", seed=0xB2, sloped=0.0, excite=1.0):
     return vin, q
 
 
+def make_vmc_world_batch(n, robot="a1", seed=0xB3, excite=1.0):
+    """Inputs of the world-frame overload of the force-balance QP (qr_qp_torque_optimizer.cpp:304-398): vmc_in as make_vmc_batch with
+    Rcb = rotMat of a random base attitude, gvec = (0,0,9.8), normal = e_z; plus per-leg ratios [n][8] = fMinRatio[4], fMaxRatio[4] --
+    the trot values (0.01, 10) for most robots, the walk mode's loading / unloading values (0.001, 10 * phase) for the rest
+    (qr_torque_stance_leg_controller.cpp:128-152).  -> vin [n][37], q [n][12], ratio [n][8]"""
+    rng = np.random.default_rng(seed)
+    vin, q = make_vmc_batch(n, robot, seed=seed + 1, sloped=0.0, excite=excite)
+    rpy = np.stack([0.3 * rng.uniform(-1, 1, n), 0.3 * rng.uniform(-1, 1, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    R = _rot_body_to_world(rpy)
+    vin[:, 22:31] = R.reshape(n, 9).astype(f32)
+    vin[:, 31:34] = (0, 0, 9.8)
+    vin[:, 34:37] = (0, 0, 1)
+    ratio = np.zeros((n, 8), f32)
+    ratio[:, 0:4] = 0.01; ratio[:, 4:8] = 10.0
+    walk = rng.random(n) < 0.4
+    ph = rng.uniform(0.001, 1.0, (n, 4)).astype(f32)
+    ratio[walk, 0:4] = 0.001
+    ratio[walk, 4:8] = np.where(rng.random((int(walk.sum()), 4)) < 0.5, 10.0, 10.0 * ph[walk])
+    return vin, q, ratio
+
+
 def estimator_cfg(robot="a1", time_step=0.002, accelerometer_variance=0.1, sensor_variance=0.1, window=120, body_height=0.28):
     """Packed estimator parameters: leg lengths, robot->timeStep, the three user_parameters.yaml values, hip offsets[12], robot->bodyHeight."""
     r = ROBOTS[robot]

@@ -121,6 +121,20 @@ def vmc_golden():
     print("vmc_golden.npz: 48 cases, %d with QuadProg++ returning +inf" % int(np.sum(infs)))
 
 
+def vmc_world_golden():
+    """World-frame overload of the force-balance QP (:304-398): tilted base, per-leg force-window ratios; x from the reference's QuadProg++."""
+    cfg = W.vmc_cfg("a1"); geom = W.model_desc("a1")[:3]
+    vin, q, ratio = W.make_vmc_world_batch(40, seed=3004)
+    Gs, As, bs, xs, infs = [], [], [], [], []
+    for i in range(40):
+        G, a, CI, b = O.vmc_assemble(cfg, vin[i], ratio[i])
+        x, f = O.ref_quadprog(G.T.astype(np.float64), -a.astype(np.float64), np.zeros((12, 0)), np.zeros(0), CI.astype(np.float64), -b.astype(np.float64))
+        Gs.append(G); As.append(a); bs.append(b); xs.append(x); infs.append(not np.isfinite(f))
+    np.savez_compressed(os.path.join(OUT, "vmc_world_golden.npz"), cfg=cfg, geom=geom, vin=vin, q=q, ratio=ratio, G=np.array(Gs), a=np.array(As),
+                        b=np.array(bs), x_quadprog=np.array(xs), quadprog_inf=np.array(infs))
+    print("vmc_world_golden.npz: 40 cases, %d with QuadProg++ returning +inf" % int(np.sum(infs)))
+
+
 def ekf_golden():
     """States of the reference's TinyEKF<3,3> (compiled from /root/reference) over three 200-step sequences."""
     rng = np.random.default_rng(4004)
@@ -148,5 +162,6 @@ if __name__ == "__main__":
     save("mpc_golden.npz", mpc_cases())
     save("wbc_golden.npz", wbc_cases())
     vmc_golden()
+    vmc_world_golden()
     ekf_golden()
     save("qp_golden.npz", qp_cases())

@@ -64,6 +64,17 @@ int main()
         printf("vmcstatus %d\nvmcforce", vst);
         for (int i = 0; i < 12; ++i) printf(" %.9g", F.m[i]);
         printf("\n");
+        // world-frame overload: 8 more numbers (fMinRatio[4], fMaxRatio[4]); Rcb of the input is then rotMat
+        float ratio[8];
+        bool have_world = true;
+        for (float &x : ratio) if (scanf("%f", &x) != 1) { have_world = false; break; }
+        if (have_world) {
+            Mat34f FW;
+            int wst = qrgpu_adapters::VmcContactForceWorld(&robot, vin + 22, acc, ct, ratio, ratio + 4, FW);
+            printf("vmcwstatus %d\nvmcwforce", wst);
+            for (int i = 0; i < 12; ++i) printf(" %.9g", FW.m[i]);
+            printf("\n");
+        }
     }
     return 0;
 }

@@ -81,3 +81,54 @@ def test_vmc_edge_cases(gpu_ctx, pkg, oracle):
     assert abs(-f1[:, 2].sum() - 13 * 9.8) < 0.05 * 13 * 9.8          # the feet push down with the robot's weight (leg force = -GRF)
     f3 = g["force"][3].reshape(4, 3)
     assert np.all(-f3[:, 2] <= 10 * 13 * 9.8 * (1 + 1e-6))
+
+
+WGOLD = os.path.join(os.path.dirname(__file__), "golden", "vmc_world_golden.npz")
+
+
+def _run_world(ctx, pkg, vin, q, ratio):
+    n = vin.shape[0]
+    S = pkg.to_soa
+    d_in = ctx.alloc((37, n)).upload(S(vin)); d_q = ctx.alloc((12, n)).upload(S(q)); d_r = ctx.alloc((8, n)).upload(S(ratio))
+    d_f = ctx.alloc((12, n)); d_t = ctx.alloc((12, n)); d_s = ctx.alloc((n,), np.int32)
+    ctx.vmc_force_world_batch(n, d_in, d_r, d_q, d_f, d_t, d_s)
+    ctx.sync()
+    out = dict(force=d_f.download().T.copy(), tau=d_t.download().T.copy(), status=d_s.download())
+    for v in (d_in, d_q, d_r, d_f, d_t, d_s):
+        v.free()
+    return out
+
+
+def test_vmc_world_frame_parity(gpu_ctx, pkg, oracle):
+    """World-frame overload (qr_qp_torque_optimizer.cpp:304-398) against the oracle, and against QuadProg++ through the golden file."""
+    W = pkg.workload
+    cfg = W.vmc_cfg("a1"); geom = pkg.model_desc("a1")[:3]
+    gpu_ctx.vmc_setup_packed(0, cfg, geom)
+    n = 800
+    vin, q, ratio = W.make_vmc_world_batch(n, seed=23)
+    g = _run_world(gpu_ctx, pkg, vin, q, ratio)
+    flags = g["status"] & 0xff
+    assert np.all((flags & ~0x80) == 0), np.unique(flags)
+    n_inf = 0
+    for i in range(n):
+        force, tau, x, st, rc = oracle.vmc_solve(cfg, geom, vin[i], q[i], ratio[i])
+        assert bool(flags[i] & 0x80) == (rc == 1), (i, flags[i], rc)
+        n_inf += rc == 1
+        assert np.abs(g["force"][i] - force).max() <= 1e-5 * max(1.0, np.abs(force).max()), (i, np.abs(g["force"][i] - force).max())
+        assert np.all(np.abs(g["tau"][i] - tau) <= tau_tol(tau, 1e-4)), i
+    assert 0 < n_inf < n
+    gd = np.load(WGOLD)
+    gpu_ctx.vmc_setup_packed(0, gd["cfg"], gd["geom"])
+    out = _run_world(gpu_ctx, pkg, gd["vin"], gd["q"], gd["ratio"])
+    for i in range(gd["vin"].shape[0]):
+        R = gd["vin"][i, 22:31].reshape(3, 3).astype(np.float64)
+        f_ref = ((-gd["x_quadprog"][i].reshape(4, 3)) @ R).reshape(-1)
+        assert np.abs(out["force"][i] - f_ref).max() <= 1e-5 * max(1.0, np.abs(f_ref).max()), i
+        assert bool(out["status"][i] & 0x80) == bool(gd["quadprog_inf"][i])
+    # the ratio array is mandatory for this entry point
+    with pytest.raises(pkg.QrgpuError):
+        d = gpu_ctx.alloc((37, 4)); f = gpu_ctx.alloc((12, 4))
+        try:
+            gpu_ctx.vmc_force_world_batch(4, d, None, None, f)
+        finally:
+            d.free(); f.free()
