@@ -695,8 +695,15 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     __syncthreads();               // every block is in registers: the M region can now carry the pivot panels
     {
         double *panel0 = Mb, *panel1 = Mb + NL * 9;
+#ifdef QR_SWEEP_STAMPS
+        long long vs_t[4] = {0, 0, 0, 0}, vs_0 = clock64();
+#define VS_STAMP(i) do { const long long t_ = clock64(); vs_t[i] += t_ - vs_0; vs_0 = t_; } while (0)
+#else
+#define VS_STAMP(i) do { } while (0)
+#endif
         for (int k = 0; k < nls; ++k) {
             double *pan = (k & 1) ? panel1 : panel0;
+            VS_STAMP(3);
 #pragma unroll
             for (int sl = 0; sl < MAXB; ++sl) {
                 if (bb[sl] == k) {                       // block (a, k), a >= k: C_a = A
@@ -709,7 +716,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         for (int j = 0; j < 3; ++j) pan[9 * bb[sl] + 3 * j + i] = A[sl].m[3 * i + j];
                 }
             }
+            VS_STAMP(0);
             __syncthreads();
+            VS_STAMP(1);
             // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per thread
             double Pi[9];
             {
@@ -724,6 +733,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
                 Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
             }
+#ifdef QR_SWEEP_STAMPS
+            asm volatile("" :: "v"(Pi[0]), "v"(Pi[4]), "v"(Pi[8]), "v"(Pi[5]));
+#endif
+            VS_STAMP(2);
 #pragma unroll
             for (int sl = 0; sl < MAXB; ++sl) {
                 const int a = ba[sl], b = bb[sl];
@@ -753,6 +766,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef QR_SWEEP_STAMPS
+        VS_STAMP(3);
+        if (dbgT && tid == 0) { dbgT[(size_t)rid * 16 + 8] = vs_t[0]; dbgT[(size_t)rid * 16 + 9] = vs_t[1]; dbgT[(size_t)rid * 16 + 10] = vs_t[2]; dbgT[(size_t)rid * 16 + 11] = vs_t[3]; dbgT[(size_t)rid * 16 + 12] = 0; }
+#endif
         __syncthreads();           // everybody is done with the panels before M overwrites them
 #pragma unroll
         for (int sl = 0; sl < MAXB; ++sl) {

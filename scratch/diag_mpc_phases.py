@@ -26,7 +26,7 @@ tot = (buf[:, 6] - buf[:, 0])
 print("total per WG mean %.0f max %.0f ; GI ticks per iteration mean %.0f ; iters mean %.1f max %d; ns mean %.0f" % (tot.mean(), tot.max(), (d[:, 4] / np.maximum(it, 1)).mean(), it.mean(), it.max(), buf[:, 7].mean()))
 print("span first start -> last end: %.0f ticks" % (buf[:, 6].max() - buf[:, 0].min()))
 
-print("sweep stamps per pivot (extract, barrier, Pinv+q, mfma groups, masks): mean", (buf[:, 8:13] / np.maximum(buf[:, 7:8] // 3, 1)).mean(0).round(0), " nls=40 robots:", (buf[buf[:, 7] == 120, 8:13] / 40.0).mean(0).round(0))
+print("sweep stamps per pivot (panel write, barrier, P^-1, block updates): mean", (buf[:, 8:13] / np.maximum(buf[:, 7:8] // 3, 1)).mean(0).round(0), " nls=40 robots:", (buf[buf[:, 7] == 120, 8:13] / 40.0).mean(0).round(0))
 sub = buf[:, 8:14].astype(np.float64)
 nm2 = ["update,bookkeeping,scan (0)", "w,delta,d,publish (1)", "X1 wait (2)", "r partial + B2 (3)", "r,dr,t1,t2,flags (4)", "B3 wait (5)"]
 for k, nm in enumerate(nm2):
