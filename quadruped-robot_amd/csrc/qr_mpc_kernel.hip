@@ -701,21 +701,23 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #else
 #define VS_STAMP(i) do { } while (0)
 #endif
-        for (int k = 0; k < nls; ++k) {
-            double *pan = (k & 1) ? panel1 : panel0;
-            VS_STAMP(3);
+        // the pivot column of step kk out of block sl: block (a, kk), a >= kk, is C_a; block (kk, b), b < kk, is C_b'
+        auto write_panel = [&](int sl, int kk, double *pn) {
+            if (bb[sl] == kk) {
 #pragma unroll
-            for (int sl = 0; sl < MAXB; ++sl) {
-                if (bb[sl] == k) {                       // block (a, k), a >= k: C_a = A
+                for (int i = 0; i < 9; ++i) pn[9 * ba[sl] + i] = A[sl].m[i];
+            } else if (ba[sl] == kk) {
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) pan[9 * ba[sl] + i] = A[sl].m[i];
-                } else if (ba[sl] == k) {                // block (k, b), b < k: C_b = A'
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) pan[9 * bb[sl] + 3 * j + i] = A[sl].m[3 * i + j];
-                }
+                    for (int j = 0; j < 3; ++j) pn[9 * bb[sl] + 3 * j + i] = A[sl].m[3 * i + j];
             }
+        };
+#pragma unroll
+        for (int sl = 0; sl < MAXB; ++sl) write_panel(sl, 0, panel0);
+        for (int k = 0; k < nls; ++k) {
+            double *pan = (k & 1) ? panel1 : panel0, *pnext = (k & 1) ? panel0 : panel1;
+            VS_STAMP(3);
             VS_STAMP(0);
             __syncthreads();
             VS_STAMP(1);
@@ -763,6 +765,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #pragma unroll
                         for (int j = 0; j < 3; ++j) A[sl].m[3 * i + j] = piv ? -Pi[3 * i + j] : (tr ? D[3 * j + i] : D[3 * i + j]);
                 }
+                // this block is final for step k: if it lies in the next pivot's column, publish it now (the other panel: its readers
+                // passed this step's barrier), so the copy overlaps the remaining blocks instead of being a phase of its own
+                write_panel(sl, k + 1, pnext);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
