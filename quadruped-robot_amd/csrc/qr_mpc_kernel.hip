@@ -721,6 +721,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             VS_STAMP(0);
             __syncthreads();
             VS_STAMP(1);
+            // the first block's operands do not depend on P^-1: their LDS round trip hides behind its computation
+            double Cx0[9], Cb0[9];
+            {
+                const int a0 = ba[0] < 0 ? 0 : ba[0], b0 = ba[0] < 0 ? 0 : bb[0];
+                const double *Cx = pan + 9 * (a0 == k ? b0 : a0), *Cb = pan + 9 * b0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { Cx0[i] = Cx[i]; Cb0[i] = Cb[i]; }
+            }
             // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per thread
             double Pi[9];
             {
@@ -744,14 +752,22 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 const int a = ba[sl], b = bb[sl];
                 if (a < 0) continue;
                 // D = C_x P^-1, x = the non-pivot index of the block (any index for the pivot block itself)
-                const double *Cx = pan + 9 * (a == k ? b : a);
+                double Cxv[9], Cb[9];
+                if (sl == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { Cxv[i] = Cx0[i]; Cb[i] = Cb0[i]; }
+                } else {
+                    const double *Cxp = pan + 9 * (a == k ? b : a), *Cbp = pan + 9 * b;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { Cxv[i] = Cxp[i]; Cb[i] = Cbp[i]; }
+                }
+                const double *Cx = Cxv;
                 double D[9];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) D[3 * i + j] = Cx[3 * i] * Pi[j] + Cx[3 * i + 1] * Pi[3 + j] + Cx[3 * i + 2] * Pi[6 + j];
                 if (a != k && b != k) {
-                    const double *Cb = pan + 9 * b;
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
