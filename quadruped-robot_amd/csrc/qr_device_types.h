@@ -110,7 +110,8 @@ __host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h, bool multi)
     size_t b;
     if (multi) b = 8 * (NV + 4 * NV + 4 * 64 + NL);       // gl xz xr fmk
     else b = 8 * (3 * NV + QR_QH + NL);                                // gl wl yl rl fmk
-    b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h);                // sT sU sSt sTraj sGait sV
+    b += 4 * (36 + 36 + 28 + NV + NL + 13 * (size_t)h + (4 * h <= 44 ? 36 : 0));   // sT sU sSt sTraj sGait sV, sJ (h <= 11 only: at h = 16 an
+                                                                       // all-stance inverse Hessian fills the CU's LDS to the last 100 bytes)
     b += 4 * (NL + QR_QH);                                             // sLs sAct
     b += 2 * (6 * NL + ((6 * NL) & 1));                                // sPos
     b += 4 * 16;                                                       // sMisc (+ the control block of the control/worker loop)

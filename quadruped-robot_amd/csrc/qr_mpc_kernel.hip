@@ -180,12 +180,39 @@ __device__ __forceinline__ Blk hess_block(const float *sT, const float *sU, int 
 
 // Phase 6: first-step forces (staged in LDS, 12 doubles) -> force[12][n], and tau = J^T (-R^T f) per leg
 // (qr_mpc_stance_leg_controller.cpp:402-409,139-153; AnalyticalLegJacobian QS/robots/qr_robot.cpp:148-172).
-__device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const double *yl, const float (&R)[3][3], const MpcType &C,
+// Column j of the analytic leg Jacobian of leg `leg` (AnalyticalLegJacobian, QS/robots/qr_robot.cpp:148-172) from the joint angles in HBM:
+// thread (leg, j) of phase 0 stores it in LDS, so that the torque map at the very end is three multiply-adds instead of a global-memory
+// round trip and twenty sinf / cosf on the critical path of every robot.
+__device__ __forceinline__ void mpc_jacobian_column(int leg, int j, int rid, int n, const MpcType &C, const float *__restrict__ g_q, float *sJ3)
+{
+    const float t0 = g_q[(size_t)(3 * leg) * n + rid], t1 = g_q[(size_t)(3 * leg + 1) * n + rid], t2 = g_q[(size_t)(3 * leg + 2) * n + rid];
+    const float lu = C.upper_l, ll = C.lower_l;
+    const float sh = C.hip_l * ((leg & 1) ? 1.f : -1.f);
+    const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
+    const float tEff = t1 + t2 / 2;
+    float J0, J1, J2;
+    if (j == 0) {
+        J0 = 0;
+        J1 = -sh * sinf(t0) + lEff * cosf(t0) * cosf(tEff);
+        J2 = sh * cosf(t0) + lEff * sinf(t0) * cosf(tEff);
+    } else if (j == 1) {
+        J0 = -lEff * cosf(tEff);
+        J1 = -lEff * sinf(t0) * sinf(tEff);
+        J2 = lEff * sinf(tEff) * cosf(t0);
+    } else {
+        J0 = ll * lu * sinf(t2) * sinf(tEff) / lEff - lEff * cosf(tEff) / 2;
+        J1 = -ll * lu * sinf(t0) * sinf(t2) * cosf(tEff) / lEff - lEff * sinf(t0) * sinf(tEff) / 2;
+        J2 = ll * lu * sinf(t2) * cosf(t0) * cosf(tEff) / lEff + lEff * sinf(tEff) * cosf(t0) / 2;
+    }
+    sJ3[0] = J0; sJ3[1] = J1; sJ3[2] = J2;
+}
+
+__device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const double *yl, const float (&R)[3][3], const float *sJ, const MpcType &C,
                                             const float *__restrict__ g_q, float *__restrict__ g_force, float *__restrict__ g_force_wbc,
                                             int force_stride, float *__restrict__ g_tau)
 {
     if (lane < 12) {
-        const int leg = lane / 3, j = lane - 3 * leg;
+        const int leg = lane / 3;
         const float fx = (float)yl[3 * leg], fy = (float)yl[3 * leg + 1], fz = (float)yl[3 * leg + 2];
         g_force[(size_t)lane * n + rid] = (float)yl[lane];
         if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yl[lane];
@@ -194,25 +221,9 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
             float fff[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) fff[i] = (-R[0][i]) * fx + (-R[1][i]) * fy + (-R[2][i]) * fz;
-            const float t0 = g_q[(size_t)(3 * leg) * n + rid], t1 = g_q[(size_t)(3 * leg + 1) * n + rid], t2 = g_q[(size_t)(3 * leg + 2) * n + rid];
-            const float lu = C.upper_l, ll = C.lower_l;
-            const float sh = C.hip_l * ((leg & 1) ? 1.f : -1.f);
-            const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(t2));
-            const float tEff = t1 + t2 / 2;
-            float J0, J1, J2;     // column j of the leg Jacobian
-            if (j == 0) {
-                J0 = 0;
-                J1 = -sh * sinf(t0) + lEff * cosf(t0) * cosf(tEff);
-                J2 = sh * cosf(t0) + lEff * sinf(t0) * cosf(tEff);
-            } else if (j == 1) {
-                J0 = -lEff * cosf(tEff);
-                J1 = -lEff * sinf(t0) * sinf(tEff);
-                J2 = lEff * sinf(tEff) * cosf(t0);
-            } else {
-                J0 = ll * lu * sinf(t2) * sinf(tEff) / lEff - lEff * cosf(tEff) / 2;
-                J1 = -ll * lu * sinf(t0) * sinf(t2) * cosf(tEff) / lEff - lEff * sinf(t0) * sinf(tEff) / 2;
-                J2 = ll * lu * sinf(t2) * cosf(t0) * cosf(tEff) / lEff + lEff * sinf(tEff) * cosf(t0) / 2;
-            }
+            float Jl[3];
+            if (!sJ) mpc_jacobian_column(leg, lane - 3 * leg, rid, n, C, g_q, Jl);      // (h = 16 variants: no LDS to spare for the early copy)
+            const float J0 = sJ ? sJ[3 * lane] : Jl[0], J1 = sJ ? sJ[3 * lane + 1] : Jl[1], J2 = sJ ? sJ[3 * lane + 2] : Jl[2];
             g_tau[(size_t)lane * n + rid] = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
         }
     }
@@ -294,7 +305,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     float *sTraj = sSt + 28;           // [12h]
     float *sGait = sTraj + NV;         // [4h]
     float *sV = sGait + NL;            // [13h]
-    int *sLs = (int *)(sV + 13 * h);   // [NL] free leg-step -> original leg-step
+    float *sJ = (MAXB <= 4) ? sV + 13 * h : nullptr;   // [12][3] columns of the leg Jacobians (the torque map of phase 6, computed while the data loads; h <= 11)
+    int *sLs = (int *)(sV + 13 * h + (MAXB <= 4 ? 36 : 0));   // [NL] free leg-step -> original leg-step
     int *sAct = sLs + NL;              // [QH] active constraint ids (6*k + t)
     short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> position in sAct, or -1
     int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [16]: [0] free leg-steps, [8..13] control block
@@ -460,6 +472,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const float two_alpha = 2.f * C.alpha;
 
     // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
+    // (the torque map's Jacobian columns first, on twelve lanes of the last wave: it owns the fewest blocks, so this hides behind wave 0's)
+    if (MAXB <= 4 && g_tau && tid >= 192 && tid < 204) { const int e = tid - 192; mpc_jacobian_column(e / 3, e - 3 * (e / 3), rid, n, C, g_q, sJ + 3 * e); }
     int ba[MAXB], bb[MAXB];
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
@@ -1121,7 +1135,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             wave_sync();
             if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
             wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
             if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
             if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
@@ -1443,7 +1457,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             wave_sync();
             if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
             wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
             if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
             if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
@@ -1720,7 +1734,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     wave_sync();
     if (own) { const int ls = sLs[kme]; if (ls < 4) { yl[3 * ls] = x0; yl[3 * ls + 1] = x1; yl[3 * ls + 2] = x2; } }
     wave_sync();
-    mpc_outputs(lane, rid, n, yl, R, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
+    mpc_outputs(lane, rid, n, yl, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
     if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
     if (tid == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
     QR_TS(6);
