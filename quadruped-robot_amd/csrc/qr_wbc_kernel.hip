@@ -952,14 +952,17 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                     // z = w - M N r ; x += t z
                     if (lane < nz) {
                         real acc = 0.0;
-                        {   // sum_j Nq[act[j]][lane] r_j, all loads first
-                            int aj[18]; real nv[18], rv2[18];
+                        // sum_j Nq[act[j]][lane] r_j in chunks of six working-set positions, a chunk's loads first (q is 7-14 typically)
 #pragma unroll
-                            for (int j = 0; j < 18; ++j) aj[j] = (j < q) ? act[j] : 0;
+                        for (int c = 0; c < 18; c += 6) {
+                            if (c >= q) continue;
+                            int aj[6]; real nv[6], rv2[6];
 #pragma unroll
-                            for (int j = 0; j < 18; ++j) { nv[j] = (j < q) ? Nq[aj[j] * 18 + lane] : 0.0; rv2[j] = (j < q) ? qr_[j] : 0.0; }
+                            for (int j = 0; j < 6; ++j) aj[j] = (c + j < q) ? act[c + j] : 0;
 #pragma unroll
-                            for (int j = 0; j < 18; ++j) acc += nv[j] * rv2[j];
+                            for (int j = 0; j < 6; ++j) { nv[j] = (c + j < q) ? Nq[aj[j] * 18 + lane] : 0.0; rv2[j] = (c + j < q) ? qr_[c + j] : 0.0; }
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) acc += nv[j] * rv2[j];
                         }
                         const real wl_ = (lane == pj) ? w0 : (lane == pj + 1) ? w1 : (lane == pj + 2) ? w2 : 0.0;
                         qz[lane] = wl_ - Minv(lane) * acc;
