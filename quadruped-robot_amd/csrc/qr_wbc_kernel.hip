@@ -303,6 +303,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 {
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
+    int qp_iters = 0;
     const int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x;
     if (rid < 0) return;
@@ -862,6 +863,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         // one "add constraint c" attempt; returns 0 added, 1 dropped-one-and-retry, 2 failure/infeasible, 3 dependent
         int iter = 0;
         const int maxit = 200;
+        int *iter_out = &qp_iters;
         bool fail = false;
         int *act = sI;             // active ids
         int *posi = sI + 32;       // constraint -> position or -1
@@ -899,114 +901,127 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             q = 6; next_eq = np_;
             wsync();
         }
+        // Working-set vectors in registers: position i lives in lane i (constraint id act_r, multiplier u_r, and d, r of the current
+        // change); lane c also knows whether constraint c is active.  Only S^-1, the normals and x go through LDS; uniform gathers are
+        // v_readlane, reductions DPP.  (The six equalities are already in and are never dropped: every row handled here is an inequality.)
+        int act_r = (lane < 6) ? lane : 0;
+        real u_r = (lane < 6) ? qu_[lane] : 0.0;
+        bool active_c = lane < 6;
+        const real INF_ = __builtin_inf();
         while (!fail) {
             int p;
-            if (next_eq < np_) p = next_eq;
-            else {
-                real bs = -1e-10; int bc = 0x7fffffff;
-                if (lane >= 6 && lane < np_ + mi && posi[lane] < 0) {
+            {
+                real bs = -1e-10; bool cand = false;
+                if (lane >= 6 && lane < np_ + mi && !active_c) {
                     const int cj = 6 + 3 * ((lane - 6) / 6);                    // the three force unknowns of this row's contact
-                    const real s = qc0[lane] + (Nq[lane * 18 + cj] * qx[cj] + Nq[lane * 18 + cj + 1] * qx[cj + 1] + Nq[lane * 18 + cj + 2] * qx[cj + 2]);
-                    if (s < bs) { bs = s; bc = lane; }
+                    const real s_ = qc0[lane] + (Nq[lane * 18 + cj] * qx[cj] + Nq[lane * 18 + cj + 1] * qx[cj + 1] + Nq[lane * 18 + cj + 2] * qx[cj + 2]);
+                    if (s_ < bs) { bs = s_; cand = true; }
                 }
-                {   // lowest-id lane holding the minimum (lane == constraint id here)
-                    const real mn = wave_min_d(bs);
-                    bc = (mn < -1e-10) ? first_lane(bs == mn && bc != 0x7fffffff) : 0x7fffffff;
-                    if (bc < 0) bc = 0x7fffffff;
-                }
-                if (bc == 0x7fffffff) break;
-                p = bc;
+                const real mn = wave_min_d(bs);
+                if (!(mn < -1e-10)) break;
+                p = first_lane(cand && bs == mn);                               // lowest-id row holding the minimum (lane == constraint id)
+                if (p < 0) break;
             }
             real up = 0.0;
             for (;;) {
                 if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
+                *iter_out = iter;
                 // an inequality row touches the three force unknowns of one contact: its products are three terms, not a reduction
                 const int pj = 6 + 3 * ((p - 6) / 6);
                 const real pn0 = Nq[p * 18 + pj], pn1 = Nq[p * 18 + pj + 1], pn2 = Nq[p * 18 + pj + 2];
                 const real delta = (pn0 * pn0 + pn1 * pn1 + pn2 * pn2) * iw_fr;
                 // w = M n_p is iw_fr * n_p on those three unknowns and zero elsewhere
                 const real w0 = iw_fr * pn0, w1 = iw_fr * pn1, w2 = iw_fr * pn2;
-                if (lane < q) { const real *na = Nq + act[lane] * 18 + pj; qd_[lane] = na[0] * w0 + na[1] * w1 + na[2] * w2; }
-                wsync();
-                real dr = 0.0;
-                if (lane < q) { const real acc = dot18(Sq + lane * 18, 1, qd_, 1, q); qr_[lane] = acc; dr = acc * qd_[lane]; }
-                dr = wsum(dr);
-                wsync();
-                const real zc = delta - dr;
-                real t1 = __builtin_inf(); int lpos = 0x7fffffff;
-                if (lane < q && act[lane] >= np_) { const real rj = qr_[lane]; if (rj > 0.0) { t1 = qu_[lane] * fast_rcp(rj); lpos = lane; } }
+                real dq_ = 0.0;
+                if (lane < q) { const real *na = Nq + act_r * 18 + pj; dq_ = na[0] * w0 + na[1] * w1 + na[2] * w2; }
+                // r = S^-1 d: lane i walks row i, d_j by v_readlane
+                real rq_ = 0.0;
                 {
-                    const real mn = wave_min_d(t1);
-                    lpos = (mn < __builtin_inf()) ? first_lane(t1 == mn && lpos != 0x7fffffff) : 0x7fffffff;
-                    t1 = mn;
+                    const real *Srow = Sq + ((lane < q) ? lane : 0) * 18;
+#pragma unroll
+                    for (int c = 0; c < 18; c += 6) {           // chunks of six columns, a chunk's loads in flight together
+                        if (c >= q) continue;
+                        real sv[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) sv[j] = Srow[c + j];                        // (row stride 18: in bounds; columns >= q are stale, masked below)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) rq_ += (c + j < q) ? sv[j] * readlane_d(dq_, c + j) : 0.0;
+                    }
+                    if (lane >= q) rq_ = 0.0;
+                }
+                const real dr = wave_sum_d(rq_ * dq_);
+                const real zc = delta - dr;
+                real t1; int lpos;
+                {
+                    const real tt = (lane < q && act_r >= np_ && rq_ > 0.0) ? u_r * fast_rcp(rq_) : INF_;
+                    t1 = wave_min_d(tt);
+                    lpos = (t1 < INF_) ? first_lane(tt == t1) : 0x7fffffff;
                 }
                 const real sp = qc0[p] + (pn0 * qx[pj] + pn1 * qx[pj + 1] + pn2 * qx[pj + 2]);
                 const bool have_z = zc > 1e-13 * delta;
-                const bool is_eq = p < np_;
                 const real izc = fast_rcp(zc);
-                const real t2 = have_z ? -sp * izc : __builtin_inf();
-                if (is_eq && !have_z) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }     // dependent equalities
-                const real t = is_eq ? t2 : (t1 < t2 ? t1 : t2);        // equalities take the full (signed) step
-                if (!is_eq && !(t < __builtin_inf())) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
+                const real t2 = have_z ? -sp * izc : INF_;
+                const real t = t1 < t2 ? t1 : t2;
+                if (!(t < INF_)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
                 if (have_z) {
                     // z = w - M N r ; x += t z
+                    real acc = 0.0;
+                    const int lz = (lane < nz) ? lane : 0;
+#pragma unroll
+                    for (int c = 0; c < 18; c += 6) {
+                        if (c >= q) continue;
+                        real nv[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) nv[j] = Nq[__builtin_amdgcn_readlane(act_r, c + j) * 18 + lz];     // (lanes >= q hold act_r = 0: a valid row)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc += (c + j < q) ? nv[j] * readlane_d(rq_, c + j) : 0.0;
+                    }
                     if (lane < nz) {
-                        real acc = 0.0;
-                        // sum_j Nq[act[j]][lane] r_j in chunks of six working-set positions, a chunk's loads first (q is 7-14 typically)
-#pragma unroll
-                        for (int c = 0; c < 18; c += 6) {
-                            if (c >= q) continue;
-                            int aj[6]; real nv[6], rv2[6];
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) aj[j] = (c + j < q) ? act[c + j] : 0;
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) { nv[j] = (c + j < q) ? Nq[aj[j] * 18 + lane] : 0.0; rv2[j] = (c + j < q) ? qr_[c + j] : 0.0; }
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) acc += nv[j] * rv2[j];
-                        }
                         const real wl_ = (lane == pj) ? w0 : (lane == pj + 1) ? w1 : (lane == pj + 2) ? w2 : 0.0;
-                        qz[lane] = wl_ - Minv(lane) * acc;
-                        qx[lane] += t * qz[lane];
+                        qx[lane] += t * (wl_ - Minv(lane) * acc);
                     }
                 }
-                if (lane < q) qu_[lane] -= t * qr_[lane];
+                u_r -= t * rq_;
                 up += t;
-                wsync();
-                if (have_z && (is_eq || t == t2)) {
+                if (have_z && t == t2) {
                     const real isg = izc;
-                    { const int rq_ = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq_), j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; } }
-                    if (lane < q) { Sq[q * 18 + lane] = -qr_[lane] * isg; Sq[lane * 18 + q] = -qr_[lane] * isg; }
-                    if (lane == 0) { Sq[q * 18 + q] = isg; act[q] = p; posi[p] = q; qu_[q] = up; }
+                    if (lane < q) qr_[lane] = rq_;
+                    wsync();                                                    // r and the new x are in LDS
+                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; } }
+                    if (lane < q) { Sq[q * 18 + lane] = -rq_ * isg; Sq[lane * 18 + q] = -rq_ * isg; }
+                    if (lane == 0) Sq[q * 18 + q] = isg;
+                    if (lane == q) { act_r = p; u_r = up; }
+                    if (lane == p) active_c = true;
                     ++q;
                     wsync();
                     break;
                 }
-                // drop lpos
+                // partial or dual-only step: position lpos leaves
                 {
                     const int l = lpos, last = q - 1;
+                    const int cdrop = __builtin_amdgcn_readlane(act_r, l), alast = __builtin_amdgcn_readlane(act_r, last);
+                    const real ulast = readlane_d(u_r, last);
                     if (lane < q) qd_[lane] = Sq[lane * 18 + l];
                     wsync();
                     const real isl = 1.0 / qd_[l];
-                    { const int rq_ = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq_), j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; } }
+                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; } }
                     wsync();
                     if (l != last) {
                         if (lane < last) qr_[lane] = (lane == l) ? Sq[last * 18 + last] : Sq[last * 18 + lane];
                         wsync();
                         if (lane < last) { Sq[l * 18 + lane] = qr_[lane]; Sq[lane * 18 + l] = qr_[lane]; }
+                        if (lane == l) { act_r = alast; u_r = ulast; }
                     }
-                    if (lane == 0) {
-                        posi[act[l]] = -1;
-                        if (l != last) { act[l] = act[last]; qu_[l] = qu_[last]; posi[act[l]] = l; }
-                    }
+                    if (lane == cdrop) active_c = false;
                     --q;
                     wsync();
                 }
             }
-            if (next_eq < np_) ++next_eq;
         }
     }
 
     QW_TS(8);
+    if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + 10] = qp_iters;
     // ---------------- GetSolution (:210-228) + store ----------------
     // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
     if (lane < 12) {

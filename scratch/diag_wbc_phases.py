@@ -20,3 +20,7 @@ names = ["load", "per-leg dyn", "base block (+dbg)", "A^-1", "tasks+contacts", "
 for k, nm in enumerate(names[:9]):
     print("  %-16s mean %8.0f  p50 %8.0f  max %8.0f" % (nm, d[:, k].mean(), np.median(d[:, k]), d[:, k].max()))
 print("total mean %.0f max %.0f" % ((buf[:, 9] - buf[:, 0]).mean(), (buf[:, 9] - buf[:, 0]).max()))
+
+it = buf[:, 10].astype(np.float64); qp = d[:, 7]
+A = np.stack([np.ones(n), it], 1); coef, *_ = np.linalg.lstsq(A, qp, rcond=None)
+print("QP: iterations mean %.1f p50 %d max %d ; cycles ~ %.0f + %.0f per iteration (least squares)" % (it.mean(), np.median(it), it.max(), coef[0], coef[1]))
