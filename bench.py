@@ -173,6 +173,8 @@ def main():
                     help="also time the loop with slot-order dispatch (no longest-first history); off by default so that a profile of the "
                          "default command holds only launches of the measured configuration")
     ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE.json configs[4] per GPU: A1 and Lite3 interleaved (type_id per robot), usually with --horizon 16; mode tick only")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +222,17 @@ def main():
     # every rank owns its own contiguous shard of the global robot population (seed offset by rank)
     b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite,
                        **(dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}))
+    d_type = None
+    if args.mixed:
+        if args.mode != "tick" or n % 2:
+            raise SystemExit("--mixed needs --mode tick and an even --robots")
+        ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h)
+        ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
+        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite)
+        bl = pkg.make_batch(n // 2, h, "lite3", seed=0x173 + 1000 * rank, excite=args.excite)
+        for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+            b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+        d_type = torch.from_numpy(pkg.shard.interleave_types(n, 2)).to(dev)
     S = pkg.to_soa
     T = lambda a: torch.from_numpy(S(a)).to(dev)
     d_state, d_traj, d_gait = T(b["mpc_state"]), T(b["traj"]), T(b["gait"])
@@ -243,7 +256,7 @@ def main():
         if gathered[par] is not None:
             stream.wait_event(gathered[par])
         if args.mode == "tick":
-            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, tau, d_status)
+            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, tau, d_status, d_type)
         elif args.mode == "mpc":
             ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_force, tau, d_status)
         else:
@@ -377,7 +390,8 @@ def main():
             "value": value, "unit": "ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
+            "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, full MPC+WBC tick (fp32 assembly, fp64 QP)" % (n // 2, n // 2, h)) if args.mixed
+                       else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
                        "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques overlapped with the next tick" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
@@ -389,7 +403,7 @@ def main():
                          "algorithmic_flop_per_robot": dom_flop, "other_kernel_ms": wbc_ms if dom_name == "qr_mpc_kernel" else mpc_ms,
                          "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.mixed:
             out["cpu_baseline"] = cpu_baseline(pkg, b, h, mode=0 if args.mode == "mpc" else 1) if args.mode != "wbc" else None
             if out["cpu_baseline"] is not None:
                 # BASELINE's metric quotes the torque error beside the rate: one more (untimed) call from the batch's initial WBC memory,
