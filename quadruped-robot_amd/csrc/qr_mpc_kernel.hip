@@ -850,7 +850,15 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         const int tril = tri(lane);
         const double tol = 1e-9;
         const double INF = __builtin_inf();
-        if (qcap > 64) qcap = 64;
+        // h = 16 variants: working-set positions 64 .. 95 live in a SECOND set of per-lane registers (position lane + 64), so a solve that
+        // outgrows the 64 lanes stays in this loop instead of handing over to the single-wave one (which costs ~40 k cycles per change at
+        // 86 rows).  The second half of the r exchange lives in the float arrays of phases 0-2, dead by now (2.2 KB at h = 16).
+        constexpr bool BIG = MAXB > 4;
+        const bool big2 = BIG && (100 + 29 * h) * 4 >= 2048 && qcap_full > 64;
+        double *xr2 = (double *)sT;
+        const int tril2 = tri(lane + 64);
+        if (qcap > (big2 ? QR_QH : 64)) qcap = big2 ? QR_QH : 64;
+        auto rd2 = [&](double v0, double v1, int j) { return j < 64 ? readlane_d(v0, j) : readlane_d(v1, j - 64); };       // j uniform
         int *sCtl = sMisc + 8;                            // [0] command (0 go, 1 exit), [1] q, [2] flags, [3] dropped position, [4,5] 1/z'c
         double *dd = xz;                                  // d of the iteration (wave 0 produces no z partial: its slot is free)
         enum { F_FULL = 1, F_DROP = 2 };
@@ -883,7 +891,18 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         bool fastz = qW > 0;
 #endif
         // r partial over columns j = wv (mod 4); (i, j) at tri(i) + j for j <= i, else tri(j) + i
-        auto r_partial = [&](int q, double dq) {
+        auto r_partial = [&](int q, double dq, double dq2) {
+            if (BIG && q > 64) {
+                const int i1 = (lane + 64 < q) ? lane + 64 : 0;
+                double pa = 0.0, pb = 0.0;
+                for (int j = wv; j < q; j += 4) {
+                    const double dj = rd2(dq, dq2, j);
+                    pa += Sinv[(j <= lane) ? tril + j : tri(j) + lane] * dj;
+                    pb += Sinv[(j <= i1) ? tri(i1) + j : tri(j) + i1] * dj;
+                }
+                xr[wv * 64 + lane] = pa; xr2[wv * 64 + lane] = pb;
+                return;
+            }
             const int i0 = (lane < q) ? lane : 0;
             double pr = 0.0;
             int j = wv;
@@ -904,11 +923,14 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 __syncthreads();                          // X1
                 if (__builtin_amdgcn_readfirstlane(sCtl[0]) != 0) return;
                 const int q = __builtin_amdgcn_readfirstlane(sCtl[1]);
+                const bool hi = BIG && q > 64;
                 const double dq = (lane < q) ? dd[lane] : 0.0;
-                r_partial(q, dq);
+                const double dq2 = (hi && lane + 64 < q) ? dd[lane + 64] : 0.0;
+                r_partial(q, dq, dq2);
                 __syncthreads();                          // B2
-                double rq;
+                double rq, rq2 = 0.0;
                 { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
+                if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
                 // z partial: W_A r over the positions i = g (mod 3), or M (N_A r) over every third active leg-step
                 double p0 = 0.0, p1 = 0.0, p2 = 0.0;
                 if (fastz) {
@@ -927,7 +949,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #pragma unroll
                     for (int tq = 0; tq < 6; ++tq) {
                         const int ps = own ? (int)sPos[6 * kme + tq] : -1;
-                        const double rr = __shfl(rq, ps < 0 ? 0 : ps, 64);
+                        double rr = __shfl(rq, ps < 0 ? 0 : (ps & 63), 64);
+                        if (hi) { const double r2 = __shfl(rq2, ps < 0 ? 0 : (ps & 63), 64); rr = ps >= 64 ? r2 : rr; }
                         if (ps >= 0) { double a0, a1, a2; cons_vec(tq, im, a0, a1, a2); y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr; hasrow = true; }
                     }
                     const unsigned long long kall = __ballot(hasrow);
@@ -953,6 +976,20 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     const bool act0 = lane < q;
                     const double ri = rq * isg;
                     int j = g;
+                    if (hi) {
+                        const bool act1 = lane + 64 < q;
+                        const double ri2 = rq2 * isg;
+                        for (; j < q; j += 3) {
+                            const double rj = rd2(rq, rq2, j);
+                            if (j <= lane) Sinv[tril + j] += ri * rj;
+                            if (act1 && j <= lane + 64) Sinv[tril2 + j] += ri2 * rj;
+                        }
+                        if (g == 0) {
+                            Sinv[tri(q) + lane] = -rq * isg;
+                            if (act1) Sinv[tri(q) + 64 + lane] = -rq2 * isg;
+                            if (lane == 0) Sinv[tri(q) + q] = isg;
+                        }
+                    } else {
                     for (; j + 9 < q; j += 12) {
                         double sv[4], rj[4];
 #pragma unroll
@@ -965,23 +1002,28 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (act0) Sinv[tri(q) + lane] = -rq * isg;
                         if (lane == 0) Sinv[tri(q) + q] = isg;
                     }
+                    }
                     if (fastz && !(q < qW)) fastz = false;      // the same rule wave 0 applies when it stores the cache row
                 } else if (flags & F_DROP) {
                     const int l = __builtin_amdgcn_readfirstlane(sCtl[3]), last = q - 1;
-                    double sl = 0.0;
+                    double sl = 0.0, sl2 = 0.0;
                     if (lane < q) sl = Sinv[pidx(lane, l)];
-                    const double isl = fast_rcp(readlane_d(sl, l));
+                    if (hi && lane + 64 < q) sl2 = Sinv[pidx(lane + 64, l)];
+                    const double isl = fast_rcp(rd2(sl, sl2, l));
                     __syncthreads();                      // D1: everyone has column l before anyone changes S^-1
                     for (int j = g; j < q; j += 3) {
                         if (j == l) continue;
-                        const double sj = readlane_d(sl, j) * isl;
+                        const double sj = rd2(sl, sl2, j) * isl;
                         if (lane < q && lane != l && j <= lane) Sinv[tril + j] -= sl * sj;
+                        if (hi && lane + 64 < q && lane + 64 != l && j <= lane + 64) Sinv[tril2 + j] -= sl2 * sj;
                     }
                     __syncthreads();                      // D2
-                    double m0 = 0.0;
+                    double m0 = 0.0, m1 = 0.0;
                     if (l != last && g == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
+                    if (hi && l != last && g == 0 && lane + 64 < last) m1 = (lane + 64 == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane + 64)];
                     __syncthreads();                      // D3
                     if (l != last && g == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
+                    if (hi && l != last && g == 0 && lane + 64 < last) Sinv[pidx(l, lane + 64)] = m1;
                 }
             }
         }
@@ -997,6 +1039,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
         int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
         double uq = 0.0;                                  // its multiplier
+        int ck2 = 0, ct2 = 0;                             // (h = 16 variants) the same for position lane + 64
+        double uq2 = 0.0;
         const int maxit = 40 * nls + 100;
         bool done = (nls == 0);
         while (!done) {
@@ -1046,22 +1090,34 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
                     dq = (lane < q) ? a0 * g0 + a1 * g1 + a2 * g2 : 0.0;
                 }
+                const bool hi = BIG && q > 64;
+                double dq2 = 0.0;
+                if (hi) {
+                    double a0, a1, a2;
+                    cons_vec(ct2, im, a0, a1, a2);
+                    const double g0 = __shfl(w0, ck2, 64), g1 = __shfl(w1, ck2, 64), g2 = __shfl(w2_, ck2, 64);
+                    dq2 = (lane + 64 < q) ? a0 * g0 + a1 * g1 + a2 * g2 : 0.0;
+                    if (lane + 64 < q) dd[lane + 64] = dq2;
+                }
                 if (lane < q) dd[lane] = dq;
                 if (lane == 0) { sCtl[0] = 0; sCtl[1] = q; }
                 CS_STAMP(1);
                 __syncthreads();                          // X1
                 CS_STAMP(2);
-                r_partial(q, dq);
+                r_partial(q, dq, dq2);
                 __syncthreads();                          // B2
                 CS_STAMP(3);
-                double rq;
+                double rq, rq2 = 0.0;
                 { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
-                const double dr = wave_sum_d(rq * dq);
+                if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
+                const double dr = wave_sum_d(hi ? rq * dq + rq2 * dq2 : rq * dq);
                 const double zc = delta - dr;
-                double tt;
+                double tt, tt2 = INF;
                 { const double tq_ = uq * fast_rcp(rq); tt = (lane < q && rq > 0.0) ? tq_ : INF; }
-                const double t1 = wave_min_d(tt);
-                const int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
+                if (hi) { const double tq_ = uq2 * fast_rcp(rq2); tt2 = (lane + 64 < q && rq2 > 0.0) ? tq_ : INF; }
+                const double t1 = wave_min_d(hi ? (tt < tt2 ? tt : tt2) : tt);
+                int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
+                if (hi && t1 < INF && lpos < 0) lpos = 64 + first_lane(tt2 == t1);
                 const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
                 const bool have_z = zc > 1e-13 * delta;
                 const double izc = fast_rcp(zc);
@@ -1080,7 +1136,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 CS_STAMP(5);
                 if (degenerate) { if (lane == kp) xmask |= 1u << tp; break; }
                 if (over) {
-                    if (q == 64 && qcap_full > 64) handoff = true; else st |= QRGPU_ST_MPC_OVERFLOW_D;
+                    if (!big2 && q == 64 && qcap_full > 64) handoff = true; else st |= QRGPU_ST_MPC_OVERFLOW_D;
                     done = true; break;
                 }
                 if (have_z) {
@@ -1090,6 +1146,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                     x0 += t * z0; x1 += t * z1; x2 += t * z2;
                 }
                 uq -= t * rq;
+                if (hi) uq2 -= t * rq2;
                 up += t;
                 if (full) {
                     if (fastz) {
@@ -1097,6 +1154,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         else fastz = false;
                     }
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
+                    if (BIG && lane + 64 == q) { uq2 = up; ck2 = kp; ct2 = tp; }
                     if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); sPos[6 * kp + tp] = (short)q; }
                     xmask = 0;
                     ++q;
@@ -1105,14 +1163,18 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 // partial or dual-only step: position lpos leaves (the workers downdate S^-1 between D1 and D3)
                 {
                     const int l = lpos, last = q - 1;
-                    const int clk = __builtin_amdgcn_readlane(ck, l), clt = __builtin_amdgcn_readlane(ct, l);
-                    const int cmk = __builtin_amdgcn_readlane(ck, last), cmt = __builtin_amdgcn_readlane(ct, last);
+                    int clk, clt, cmk, cmt;
+                    double ulast;
+                    if (BIG && l >= 64) { clk = __builtin_amdgcn_readlane(ck2, l - 64); clt = __builtin_amdgcn_readlane(ct2, l - 64); }
+                    else { clk = __builtin_amdgcn_readlane(ck, l); clt = __builtin_amdgcn_readlane(ct, l); }
+                    if (BIG && last >= 64) { cmk = __builtin_amdgcn_readlane(ck2, last - 64); cmt = __builtin_amdgcn_readlane(ct2, last - 64); ulast = readlane_d(uq2, last - 64); }
+                    else { cmk = __builtin_amdgcn_readlane(ck, last); cmt = __builtin_amdgcn_readlane(ct, last); ulast = readlane_d(uq, last); }
                     __syncthreads();                      // D1
                     if (fastz && l != last && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
                     __syncthreads();                      // D2
                     if (l != last) {
-                        const double ulast = readlane_d(uq, last);
                         if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
+                        if (BIG && lane + 64 == l) { uq2 = ulast; ck2 = cmk; ct2 = cmt; }
                     }
                     if (lane == clk) { amask &= ~(1u << clt); sPos[6 * clk + clt] = (short)-1; }
                     if (l != last && lane == cmk) { posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt)); sPos[6 * cmk + cmt] = (short)l; }

@@ -163,6 +163,33 @@ def test_handover_beyond_64_rows(gpu_ctx, pkg, oracle):
     assert big >= 10, "the batch must exercise the hand-over"
 
 
+def test_h16_beyond_64_rows_stays_in_the_multi_wave_loop(gpu_ctx, pkg, oracle):
+    """h = 16: working sets beyond the 64 lanes keep a second position per lane (64..95) in the control / worker loop of the MAXB = 9
+    variants -- no hand-over to the single-wave loop.  The batch is the A1 half of `bench.py --mixed --horizon 16` (one robot ends
+    with 84 active rows, an all-stance one with 66); every robot the oracle finds beyond 60 rows, and a sample of the others, is
+    compared with the oracle."""
+    h, n = 16, 512
+    gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    try:
+        b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2, excite=1.0)
+        out = G.run_mpc(gpu_ctx, pkg, b)
+        assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+        it = out["status"] >> 8
+        cfg = pkg.mpc_cfg("a1")
+        cand = list(np.argsort(-it)[:24]) + list(range(0, n, 37))
+        big = 0
+        for i in cand:
+            u, st, rc = oracle.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+            assert rc == 0
+            big += st["n_active"] > 64
+            assert np.abs(out["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max()), (i, st["n_active"])
+        assert big >= 2, "the batch must exercise positions beyond 64"
+        out2 = G.run_mpc(gpu_ctx, pkg, b)
+        assert np.array_equal(out["force"], out2["force"]) and np.array_equal(out["status"], out2["status"])      # deterministic
+    finally:
+        G.setup_a1(gpu_ctx, pkg, 10)
+
+
 def test_rescue_pass_lds_limited_robots(gpu_ctx, pkg, oracle):
     """All-stance robots at h = 10 leave LDS for 56 rows of S^-1 (no hand-over possible): beyond that the robot is flagged
     QRGPU_ST_MPC_OVERFLOW without the rescue pass and re-solved by the single-wave variant with the whole CU's LDS with it."""
