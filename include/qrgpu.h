@@ -138,8 +138,8 @@ int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
 int  qrgpu_set_lpt_schedule(qrgpu_ctx *ctx, int on);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
- * Hessian at h = 10 leaves room for 56 rows): they are re-solved by the single-wave variant with the whole CU's LDS in a second, normally
- * empty launch, at most max(64, n/16) robots per call, h <= 11 only (at h = 16 such robots keep S^-1 in a global scratch instead).
+ * Hessian at h = 10 leaves room for 56 rows): they are re-solved by the same kernel with the whole CU's LDS in a second, normally
+ * empty launch, at most 64 robots per call (the rest keep QRGPU_ST_MPC_OVERFLOW), h <= 11 only (at h = 16 such robots keep S^-1 in a global scratch instead).
  * A robot nothing can hold keeps QRGPU_ST_MPC_OVERFLOW. */
 int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
 const char *qrgpu_last_error(const qrgpu_ctx *ctx);

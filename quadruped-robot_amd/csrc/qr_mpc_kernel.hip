@@ -234,11 +234,26 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
 // dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
 // the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
 // leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
-__device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restrict__ cost, int *__restrict__ order, int *hist /* 256 ints of LDS */)
+__device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restrict__ cost, int *__restrict__ order, int *hist /* >= 2048 ints of LDS */)
 {
     const int chunk = (n + 7) >> 3;
     const int lo = x * chunk;
     const int hi = (lo + chunk < n) ? lo + chunk : n;
+    if (hi - lo <= 2048) {
+        // rank by comparison: robot i goes to slot #{j : c_j > c_i, or c_j = c_i and j < i}.  Every thread reads the same c_j (an LDS
+        // broadcast), no atomics -- the counting sort below spends ~0.5 ms at 512 robots per chunk on atomics to a few hot bins -- and the
+        // order is stable, i.e. the same for the same costs.
+        const int m = hi - lo;
+        for (int i = threadIdx.x; i < m; i += 256) hist[i] = cost[lo + i] & 255;
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 256) {
+            const int ci = hist[i];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) { const int cj = hist[j]; rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
+            order[lo + rank] = lo + i;
+        }
+        return;
+    }
     hist[threadIdx.x] = 0;
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
@@ -252,7 +267,7 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
 }
 __global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
 {
-    __shared__ int hist[256];
+    __shared__ int hist[2048];
     lpt_order_chunk(blockIdx.x, n, cost, order, hist);
 }
 

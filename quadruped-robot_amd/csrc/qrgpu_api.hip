@@ -390,17 +390,20 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
-        // list capacity served per call: 64 robots (one per CU at h = 16), or a sixteenth of a large batch
+        // list capacity served per call: 64 robots.  (It used to grow to n / 16, but workgroups that ask for a whole CU's LDS are dispatched
+        // one every ~2 us: the empty pass cost 0.55 ms at 4096 robots, 1.3 ms at 16384.)
         int rgrid = small ? 64 : c->num_cu;
-        if (n / 16 > rgrid) rgrid = n / 16;
         if (rgrid > n) rgrid = n;
-        const void *rfn = small ? (const void *)qr_mpc_kernel<4, false> : (const void *)qr_mpc_kernel<9, false>;
-        if (c->configured_rescue[small ? 0 : 1] < R.lds_bytes) {
+        // h <= 11: the multi-wave variant again, now with the whole CU's LDS (64 rows and the W_A cache even for an all-stance robot; it
+        // hands over to its single-wave tail beyond 64 rows) -- three times faster than re-solving in the single-wave variant
+        const void *rfn = small ? (const void *)qr_mpc_kernel<4, true> : (const void *)qr_mpc_kernel<9, false>;
+        int &conf = small ? c->configured_lds[0] : c->configured_rescue[1];
+        if (conf < R.lds_bytes) {
             HIPCHK(c, hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
-            c->configured_rescue[small ? 0 : 1] = R.lds_bytes;
+            conf = R.lds_bytes;
         }
         if (small)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
+            hipLaunchKernelGGL((qr_mpc_kernel<4, true>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
                                d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
         else
             hipLaunchKernelGGL((qr_mpc_kernel<9, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,

@@ -192,7 +192,7 @@ def test_h16_beyond_64_rows_stays_in_the_multi_wave_loop(gpu_ctx, pkg, oracle):
 
 def test_rescue_pass_lds_limited_robots(gpu_ctx, pkg, oracle):
     """All-stance robots at h = 10 leave LDS for 56 rows of S^-1 (no hand-over possible): beyond that the robot is flagged
-    QRGPU_ST_MPC_OVERFLOW without the rescue pass and re-solved by the single-wave variant with the whole CU's LDS with it."""
+    QRGPU_ST_MPC_OVERFLOW without the rescue pass and re-solved in a second launch with the whole CU's LDS with it."""
     h = 10
     G.setup_a1(gpu_ctx, pkg, h)
     b = pkg.make_batch(64, h, "a1", seed=0xBEE5, excite=1.5, frac_all_stance=1.0, frac_three_leg=0.0)
