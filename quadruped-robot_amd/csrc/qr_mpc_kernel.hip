@@ -271,7 +271,8 @@ __global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__r
     lpt_order_chunk(blockIdx.x, n, cost, order, hist);
 }
 
-template <int MAXB, bool MULTI>
+// TAG only names the instance: the rescue launch runs <4, true, 1>, so that a kernel trace keeps it apart from the main launches <4, true, 0>
+template <int MAXB, bool MULTI, int TAG>
 __global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
 void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
                    const float *__restrict__ g_traj, const float *__restrict__ g_gait, const float *__restrict__ g_q,
@@ -1820,13 +1821,13 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 #endif
 }
 
-#define QR_MPC_INST(MAXB, MULTI)                                                                                                      \
-    template __global__ void qr_mpc_kernel<MAXB, MULTI>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, \
-                                                        float *, float *, int *, float *, float *, float *, int, long long *);
-QR_MPC_INST(4, true)
-QR_MPC_INST(4, false)
-QR_MPC_INST(9, true)
-QR_MPC_INST(9, false)
+#define QR_MPC_INST(MAXB, MULTI, TAG)                                                                                                 \
+    template __global__ void qr_mpc_kernel<MAXB, MULTI, TAG>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, \
+                                                             float *, float *, int *, float *, float *, float *, int, long long *);
+QR_MPC_INST(4, true, 0)
+QR_MPC_INST(4, true, 1)
+QR_MPC_INST(9, true, 0)
+QR_MPC_INST(9, false, 0)
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

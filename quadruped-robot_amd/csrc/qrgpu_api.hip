@@ -14,17 +14,17 @@
 #include "qr_device_types.h"
 
 namespace qrgpu {
-template <int MAXB, bool MULTI>
+template <int MAXB, bool MULTI, int TAG>
 __global__ void qr_mpc_kernel(MpcLaunch P, const int *type_id, const float *g_state, const float *g_traj, const float *g_gait,
                               const float *g_q, float *g_force, float *g_tau, int *g_status, float *dbgH, float *dbgG,
                               float *g_force_wbc, int force_stride, long long *dbgT);
-#define QR_MPC_DECL(MAXB, MULTI)                                                                                                             \
-    extern template __global__ void qr_mpc_kernel<MAXB, MULTI>(MpcLaunch, const int *, const float *, const float *, const float *,         \
+#define QR_MPC_DECL(MAXB, MULTI, TAG)                                                                                                             \
+    extern template __global__ void qr_mpc_kernel<MAXB, MULTI, TAG>(MpcLaunch, const int *, const float *, const float *, const float *,         \
                                                                const float *, float *, float *, int *, float *, float *, float *, int, long long *);
-QR_MPC_DECL(4, true)
-QR_MPC_DECL(4, false)
-QR_MPC_DECL(9, true)
-QR_MPC_DECL(9, false)
+QR_MPC_DECL(4, true, 0)
+QR_MPC_DECL(4, true, 1)
+QR_MPC_DECL(9, true, 0)
+QR_MPC_DECL(9, false, 0)
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -364,7 +364,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave with in-place hand-over>, 2 = <9, single-wave> (QRGPU_H16_SINGLE=1)
     const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
-    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true> : var == 1 ? (const void *)qr_mpc_kernel<9, true> : (const void *)qr_mpc_kernel<9, false>;
+    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true, 0> : var == 1 ? (const void *)qr_mpc_kernel<9, true, 0> : (const void *)qr_mpc_kernel<9, false, 0>;
     if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
         c->configured_lds[var] = P.lds_bytes;
@@ -374,13 +374,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         const dim3 grid(8 * ((n + 7) / 8)), block(256);
         long long *dbg = (long long *)c->d_dbg_cycles;
         if (var == 0)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, true>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+            hipLaunchKernelGGL((qr_mpc_kernel<4, true, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
                                d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
         else if (var == 1)
-            hipLaunchKernelGGL((qr_mpc_kernel<9, true>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+            hipLaunchKernelGGL((qr_mpc_kernel<9, true, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
                                d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
         else
-            hipLaunchKernelGGL((qr_mpc_kernel<9, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
+            hipLaunchKernelGGL((qr_mpc_kernel<9, false, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
                                d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
     }
     HIPCHK(c, hipGetLastError());
@@ -396,17 +396,17 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         if (rgrid > n) rgrid = n;
         // h <= 11: the multi-wave variant again, now with the whole CU's LDS (64 rows and the W_A cache even for an all-stance robot; it
         // hands over to its single-wave tail beyond 64 rows) -- three times faster than re-solving in the single-wave variant
-        const void *rfn = small ? (const void *)qr_mpc_kernel<4, true> : (const void *)qr_mpc_kernel<9, false>;
-        int &conf = small ? c->configured_lds[0] : c->configured_rescue[1];
+        const void *rfn = small ? (const void *)qr_mpc_kernel<4, true, 1> : (const void *)qr_mpc_kernel<9, false, 0>;
+        int &conf = c->configured_rescue[small ? 0 : 1];
         if (conf < R.lds_bytes) {
             HIPCHK(c, hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
             conf = R.lds_bytes;
         }
         if (small)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, true>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
+            hipLaunchKernelGGL((qr_mpc_kernel<4, true, 1>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
                                d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
         else
-            hipLaunchKernelGGL((qr_mpc_kernel<9, false>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
+            hipLaunchKernelGGL((qr_mpc_kernel<9, false, 0>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
                                d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
         HIPCHK(c, hipGetLastError());
         c->rescue_parity ^= 1;

@@ -16,7 +16,7 @@ for nm in ("fetch", "write", "sq"):
     d = d[d["Kernel_Name"].str.contains("qrgpu::")]
     g = d.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].mean()
     for (k, c), v in g.items():
-        if "qr_mpc_kernel<4, true>" in k or "qr_mpc_kernelILi4ELb1" in k: key = "qr_mpc_kernel"          # the main pass, not the rescue launch
+        if "qr_mpc_kernel<4, true, 0>" in k or "qr_mpc_kernelILi4ELb1ELi0" in k: key = "qr_mpc_kernel"          # the main pass, not the rescue launch
         elif "qr_wbc_kernel" in k: key = "qr_wbc_kernel"
         else: continue
         rows.setdefault(key, {})[c] = float(v)
@@ -27,10 +27,10 @@ lines = ["# rocprofv3 summary (%s): `python3 bench.py` = 1024 A1 robots, h=10, f
 for _, r in stats.iterrows():
     if "qrgpu::" in r["Name"]:
         nm = r["Name"]
-        base = [k for k in ("qr_mpc_kernel<4, true>", "qr_mpc_kernel<4, false>", "qr_mpc_kernel<9, true>", "qr_mpc_kernel<9, false>", "qr_mpc_kernel", "qr_wbc_kernel",
+        base = [k for k in ("qr_mpc_kernel<4, true, 0>", "qr_mpc_kernel<4, true, 1>", "qr_mpc_kernel<9, true, 0>", "qr_mpc_kernel<9, false, 0>", "qr_mpc_kernel", "qr_wbc_kernel",
                             "qr_frontend_kernel", "qr_vmc_kernel", "qr_lpt_order_kernel", "qr_selftest_kernel") if k in nm]
         label = base[0] if base else nm[:40]
-        if label == "qr_mpc_kernel<4, false>": label += " (rescue launch, carries the longest-first sort)"
+        if label == "qr_mpc_kernel<4, true, 1>": label += " (rescue launch, carries the longest-first sort)"
         lines.append("| %s | %d | %.0f | %d | %d |" % (label, r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"]))
 lines += ["", "PMC (separate passes, mean per launch).  FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md §HBM the read side",
           "is doubled (gfx950 tallies 128-B requests at 64 B; exact only for wide coalesced streams, an upper bound here):", "",
