@@ -5,11 +5,21 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one qrgpu_tick_batch over this rank's 1024 robots (inputs already resident in HBM) and, for
-N > 1, one RCCL all-gather of the per-robot torques on a second stream, overlapped with the next tick (weak scaling: every rank
-owns 1024 robots; the timed region ends when the last gather has landed).
-torch is plumbing only (device buffers, the stream, torch.distributed); the tick itself is two
-hand-written HIP kernels behind the C ABI of include/qrgpu.h.  Rank 0 prints ONE JSON line.
+A step = one qrgpu_tick_batch over this rank's 1024 robots -- K1-K14 of SURVEY.md 8(a): MPC, then WBC with the kinematic projection
+(K12) on and the motor tail (K14: abad compensation, +-23 N m clip) applied -- with inputs already resident in HBM, and, for N > 1,
+one all-gather of the per-robot torques (qrgpu_allgather_tau: RCCL over xGMI on the context's own stream, overlapped with the next
+tick; weak scaling: every rank owns 1024 robots; the timed region ends when the last gather has landed).
+
+What is stepped through.  Not one batch over and over: the K timed steps are split over D = 8 robot populations ("draws", different
+generator seeds, different on every rank), and inside a draw consecutive steps see consecutive batches of a temporally coherent
+sequence (the same robots 0.03 s later: workload.make_batch_sequence, 8 batches walked back and forth), so the scheduler's history
+(longest-first dispatch from the previous step's solve times) is a prediction, never a replay.  Every draw gets W untimed warm-up steps
+and its share of the K timed steps, bracketed by barrier + synchronize; `value` is the MEDIAN over the draws of the draw's rate (max
+over ranks of its time), min / max / per-draw rates beside it.
+
+torch is plumbing only (device buffers, the launch stream, torch.distributed's CPU backend for the launcher's barrier / max-reduce
+and for handing rank 0's communicator id to the other ranks); the tick and the collective are behind the C ABI of include/qrgpu.h.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib.util
@@ -31,6 +41,7 @@ FLOP_WBC = 0.35e6
 BYTES_PER_TICK = 1216                            # algorithmic HBM bytes per full tick at h = 10
 PEAK_F32_MATRIX_TFLOPS = 157.3                   # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
+EST_IN_ROWS, EST_OUT_ROWS = 54, 42                # QRGPU_EST_IN_ROWS / QRGPU_EST_OUT_ROWS (include/qrgpu.h)
 
 
 def _load_pkg():
@@ -43,8 +54,9 @@ def _load_pkg():
     return mod
 
 
-def cpu_baseline(pkg, b, horizon, mode=1):
-    """The CPU restatement (oracle/, kind "port") timed on this box's host cores over a bounded sample."""
+def cpu_baseline(pkg, b, horizon, mode=1, epilogue=3, budget_s=6.0):
+    """The CPU restatement (oracle/, kind "port") timed on this box's host cores over a bounded sample: the same tick the GPU runs
+    (K12 always runs on the CPU side, as in the reference; K14 tail on)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     O.build()
@@ -57,22 +69,52 @@ def cpu_baseline(pkg, b, horizon, mode=1):
     args = (mode, cfg, horizon, md[:3], md, b["mpc_state"], b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"])
     n = b["n"]
     # single thread on a 128-robot slice, all cores on the whole batch
-    sl = {k: (v[:128] if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+    m1 = min(n, 128)
+    sl = {k: (v[:m1] if isinstance(v, np.ndarray) else v) for k, v in b.items()}
     t0 = time.perf_counter()
     O.tick_batch(mode, cfg, horizon, md[:3], md, sl["mpc_state"], sl["traj"], sl["gait"], sl["fb_state"], sl["wbc_cmd"],
-                 sl["prev_ori_vel"].copy(), nthreads=1)
+                 sl["prev_ori_vel"].copy(), nthreads=1, epilogue=epilogue)
     t1 = time.perf_counter() - t0
     passes, wall = 0, 0.0
-    while wall < 4.0 and passes < 8:
+    while wall < budget_s and passes < 8:
         t0 = time.perf_counter()
-        f_cpu, tau_cpu, st_cpu, _, _ = O.tick_batch(*args, b["prev_ori_vel"].copy(), nthreads=cores)
+        f_cpu, tau_cpu, st_cpu, _, _, q_cpu = O.tick_batch(*args, b["prev_ori_vel"].copy(), nthreads=cores, epilogue=epilogue, want_qdes=True)
         wall += time.perf_counter() - t0
         passes += 1
-    cpu_baseline.outputs = (f_cpu, tau_cpu, st_cpu)      # the checker's answer on this batch, for max_rel_*_err_vs_cpu
-    return dict(value=passes * n / wall, unit="ticks/s", cores=cores, kind="port",
-                sample="%d passes over the same %d-robot batch on %d threads (oracle/ CPU restatement, own fp64 active-set QP)"
-                       % (passes, n, cores),
-                single_thread_value=128 / t1)
+    cpu_baseline.outputs = (f_cpu, tau_cpu, st_cpu, q_cpu)      # the checker's answer on this batch, for max_rel_*_err_vs_cpu
+    out = dict(value=passes * n / wall, unit="ticks/s", cores=cores, kind="port",
+               sample="%d passes over one %d-robot batch (draw 0, first batch) on %d threads: oracle/ CPU restatement, own fp64 active-set QP, "
+                      "K12 and the K14 tail included" % (passes, n, cores),
+               single_thread_value=m1 / t1)
+    out.update(reference_solver(pkg, O, b, horizon))
+    return out
+
+
+def reference_solver(pkg, O, b, horizon, sample=24):
+    """How the port's solver relates to the reference's: qpOASES 3.2.0 compiled from the reference tree (oracle/_ref, travels as a built
+    .so) fed exactly what qr_mpc_interface.cpp:418-438 feeds it (asymmetric fp32 H, nWSR = 100), against the port's solver on the same QPs,
+    one thread, `sample` robots of the bench batch.  Also returns the reference's as-called first-step forces for the parity figure."""
+    if O.ref() is None:
+        return dict(reference_solver_ratio=None, reference_solver_note="oracle/_ref not present on this box")
+    cfg = pkg.mpc_cfg("a1")
+    A = O.mpc_constraint_matrix(horizon, float(cfg[1]))
+    idx = np.arange(min(sample, b["n"]))
+    t_ref = t_port = 0.0
+    f_ref = np.zeros((idx.size, 12)); nwsr = np.zeros(idx.size, int); rc = np.zeros(idx.size, int)
+    for j, i in enumerate(idx):
+        H, g, ub = O.mpc_assemble(cfg, horizon, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        t0 = time.perf_counter()
+        x, info = O.ref_qpoases_mpc(H.astype(np.float64), g.astype(np.float64), A, np.zeros(20 * horizon), ub.astype(np.float64), 100)
+        t_ref += time.perf_counter() - t0
+        f_ref[j], nwsr[j], rc[j] = x[:12], info["nWSR"], info["init_rc"]
+        t0 = time.perf_counter()
+        O.mpc_solve(cfg, horizon, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        t_port += time.perf_counter() - t0
+    reference_solver.as_called = (idx, f_ref, nwsr, rc)
+    return dict(reference_solver_ratio=t_ref / t_port,
+                reference_solver_ms_per_solve=1e3 * t_ref / idx.size, port_solver_ms_per_solve=1e3 * t_port / idx.size,
+                reference_solver_note="qpOASES 3.2.0 from the reference tree as qr_mpc_interface.cpp:428-438 calls it vs the port's assemble+solve, "
+                                      "%d QPs of the bench batch, one thread (the port's time includes its fp32 assembly)" % idx.size)
 
 
 def side_mode(args, pkg, ctx, torch, dev, stream):
@@ -102,12 +144,14 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
         xs, stamps = W.make_estimator_sequence(n, 4, seed=0xE5)
         d_in = T(xs[0]); d_tick = torch.from_numpy(stamps[0].astype(np.int64)).to(dev).to(torch.int32)
         S_ = ctx.estimator_state_doubles(int(cfg[6]))
-        d_state = torch.zeros((S_, n), dtype=torch.float64, device=dev); d_out = torch.zeros((36, n), dtype=torch.float32, device=dev)
+        d_state = torch.zeros((S_, n), dtype=torch.float64, device=dev)
+        d_out = torch.zeros((EST_OUT_ROWS, n), dtype=torch.float32, device=dev)          # QRGPU_EST_OUT_ROWS of include/qrgpu.h
         step = lambda: ctx.estimator_update_batch(n, cfg, d_in, d_tick, d_state, d_out)
         seq = np.repeat(xs[0][None, :1], 200, 0)[:, 0]
         cpu_all = lambda: O.estimator_run(cfg, seq, (1000 + 2 * np.arange(200)).astype(np.uint32))
         cpu = None
-        alg_bytes = (41 + 1 + 36) * 4 + 2 * (32 + 6) * 8
+        assert xs[0].shape[1] == EST_IN_ROWS
+        alg_bytes = (EST_IN_ROWS + 1 + EST_OUT_ROWS) * 4 + 2 * (32 + 6) * 8     # inputs + tick + outputs, and the touched part of the filter memory (read + write)
         metric, unit, kernel = "velocity-estimator robot-ticks/s (batched robots)", "robot-ticks/s", "qr_estimator_kernel"
         alg_flop = 0
     else:
@@ -161,17 +205,19 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps in total, split over the draws")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps in front of every draw's timed steps")
     ap.add_argument("--robots", type=int, default=1024, help="robots per GPU")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--excite", type=float, default=1.0)
+    ap.add_argument("--draws", type=int, default=8, help="robot populations (generator seeds) the timed steps are split over; value = median")
+    ap.add_argument("--seq", type=int, default=8, help="batches per temporally coherent sequence (walked back and forth)")
+    ap.add_argument("--same-seed-ranks", action="store_true",
+                    help="control experiment: every rank draws the same populations (identical work per GPU) instead of its own")
     ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend", "estimator"],
-                    help="tick = the headline; vmc / frontend = the SURVEY 8f rows (force-balance QP, MPC front-end), single GPU")
+                    help="tick = the headline; vmc / frontend / estimator = the SURVEY 8f rows, single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--compare-dispatch", action="store_true",
-                    help="also time the loop with slot-order dispatch (no longest-first history); off by default so that a profile of the "
-                         "default command holds only launches of the measured configuration")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (slot-order dispatch, K12 off, replayed batch, PCIe, 8f kernels)")
     ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE.json configs[4] per GPU: A1 and Lite3 interleaved (type_id per robot), usually with --horizon 16; mode tick only")
@@ -187,19 +233,16 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
         args.gpus = world
-    # QRGPU_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- a functional rehearsal of the N > 1 code path on a
-    # one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
+    # QRGPU_BENCH_REHEARSAL=1: every rank on cuda:0, the gather through gloo on host copies -- a functional rehearsal of the N > 1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
     rehearsal = os.environ.get("QRGPU_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="gloo")      # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     pkg = _load_pkg()
     if rank == 0 or (local_rank == 0 and not rehearsal):
@@ -219,128 +262,146 @@ def main():
         ctx.close()
         return
 
-    # every rank owns its own contiguous shard of the global robot population
-    # Weak scaling wants the SAME work on every GPU.  A 1024-robot draw is not that: the kernel time is its slowest robot's solve, and
-    # draws differ by 2.5x (seeds 0..7 of this generator: 0.29 - 0.78 ms per step on one GPU, the slow ones holding one robot that needs
-    # the rescue pass) -- a max over ranks of different draws would measure sampling noise, not the system.  So every rank draws its
-    # robots with the same seed; QRGPU_BENCH_SEED_RANK=r times draw r instead (scratch/rank_seeds.sh lists all eight).
-    seed_rank = int(os.environ.get("QRGPU_BENCH_SEED_RANK", "0"))
-    b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2 + 1000 * seed_rank, excite=args.excite,
-                       **(dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}))
+    if world > 1 and not rehearsal:
+        ctx.comm_init_rank(pkg.shard.exchange_comm_id(rank, pkg.qrgpu.comm_unique_id), world, rank)     # RCCL communicator owned by the context
+    ctx.set_torque_epilogue(hip_comp=True, clip=True)          # K14 tail is part of the tick SURVEY 8(d) defines
+
+    # ---- populations: D draws x a coherent sequence each, all resident in HBM before anything is timed -----------------------
+    D = max(1, min(args.draws, args.steps))
+    SEQ = max(1, args.seq)
+    S = pkg.to_soa
+    T = lambda a: torch.from_numpy(S(a)).to(dev)
+    seed_rank = 0 if args.same_seed_ranks else rank
+    extra = dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}
     d_type = None
     if args.mixed:
         if args.mode != "tick" or n % 2:
             raise SystemExit("--mixed needs --mode tick and an even --robots")
         ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h)
         ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
-        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 2 + 1000 * seed_rank, excite=args.excite)
-        bl = pkg.make_batch(n // 2, h, "lite3", seed=0x173 + 1000 * seed_rank, excite=args.excite)
-        for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
-            b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
         d_type = torch.from_numpy(pkg.shard.interleave_types(n, 2)).to(dev)
-    S = pkg.to_soa
-    T = lambda a: torch.from_numpy(S(a)).to(dev)
-    d_state, d_traj, d_gait = T(b["mpc_state"]), T(b["traj"]), T(b["gait"])
-    d_fb, d_cmd, d_prev = T(b["fb_state"]), T(b["wbc_cmd"]), T(b["prev_ori_vel"])
+
+    def population(d):
+        seed = 0xA1 + 2 + 1000 * d + 100000 * seed_rank          # draw 0 of rank 0 is make_batch(seed = 0xA1 + 2): BASELINE configs[2]'s seed rule
+        if not args.mixed:
+            return pkg.make_batch_sequence(n, h, "a1", seed=seed, steps=SEQ, excite=args.excite, **extra)
+        sa = pkg.make_batch_sequence(n // 2, h, "a1", seed=seed, steps=SEQ, excite=args.excite)
+        sl = pkg.make_batch_sequence(n // 2, h, "lite3", seed=seed + 0xD2, steps=SEQ, excite=args.excite)
+        out = []
+        for ba, bl in zip(sa, sl):
+            b = dict(ba); b["n"] = n
+            for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+                b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+            out.append(b)
+        return out
+
+    keys = ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd")
+    host0 = None
+    dev_seq = []
+    for d in range(D):
+        seq = population(d)
+        if d == 0:
+            host0 = seq
+        dev_seq.append([[T(b[k]) for k in keys] for b in seq])
+    walk = list(range(SEQ)) + list(range(SEQ - 2, 0, -1))        # 0 1 .. S-1 S-2 .. 1 | 0 1 ..: every step's batch is a neighbour of the last one
+    d_prev = torch.zeros((3, n), dtype=torch.float32, device=dev)
     d_force = torch.zeros((12, n), dtype=torch.float32, device=dev)
-    d_tau = torch.zeros((12, n), dtype=torch.float32, device=dev)
     d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
     d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
-    d_tau_all = torch.zeros((world * 12, n), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major [world][12][n]
-    # N > 1: the all-gather of tick i runs on its own stream while tick i+1 computes (the ticks never wait for a collective; they only
-    # wait, two ticks later, for the gather that is still reading the torque buffer they are about to overwrite)
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    d_tau2 = [d_tau, torch.zeros_like(d_tau)] if world > 1 else [d_tau]
-    gathered = [None, None]
+    d_tau2 = [torch.zeros((12, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    d_tau_all = torch.zeros((world, 12, n), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major
     nstep = [0]
+    cur = dict(draw=0, k12=True, fixed=None)
 
     def step():
-        par = nstep[0] & 1 if world > 1 else 0
+        i = nstep[0]
         nstep[0] += 1
-        tau = d_tau2[par]
-        if gathered[par] is not None:
-            stream.wait_event(gathered[par])
+        slot = i & 1 if world > 1 else 0
+        tau = d_tau2[slot]
+        ds, dt_, dg, dfb, dcmd = dev_seq[cur["draw"]][cur["fixed"] if cur["fixed"] is not None else walk[i % len(walk)]]
+        if world > 1 and not rehearsal:
+            ctx.allgather_fence(slot)                          # the gather of two steps ago has finished reading this buffer
         if args.mode == "tick":
-            ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_force, tau, d_status, d_type)
+            ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_force, tau, d_status, d_type, qdes=d_qdes if cur["k12"] else None)
         elif args.mode == "mpc":
-            ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_force, tau, d_status)
+            ctx.mpc_solve_batch(n, ds, dt_, dg, dfb[13:25], d_force, tau, d_status)
         else:
-            ctx.wbc_run_batch(n, d_fb, d_cmd, d_prev, tau, d_qdes, d_status)
+            ctx.wbc_run_batch(n, dfb, dcmd, d_prev, tau, d_qdes, d_status)
         if world > 1:
-            comm_stream.wait_stream(stream)                    # this tick's torques are complete
-            with torch.cuda.stream(comm_stream):
-                if rehearsal:
-                    dist.all_gather(list(d_tau_all.view(world, 12, n).unbind(0)), tau)
-                else:
-                    dist.all_gather_into_tensor(d_tau_all, tau)    # RCCL over xGMI: the only exchange of the path
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
-            gathered[par] = ev
+            if rehearsal:
+                torch.cuda.synchronize()
+                parts = [torch.empty((12, n)) for _ in range(world)]
+                dist.all_gather(parts, tau.cpu())
+                d_tau_all.copy_(torch.stack(parts))
+            else:
+                ctx.allgather_tau(tau, n, d_tau_all, slot)     # RCCL over xGMI on the context's own stream: the only exchange of the path
 
     def fence():
         if world > 1:
+            if not rehearsal:
+                ctx.comm_sync()
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    def timed(steps, warmup, draw, k12=True, fixed=None, lpt=True):
+        """`warmup` untimed then `steps` timed steps on one population with a fresh scheduler history.  -> seconds (max over ranks)"""
+        cur.update(draw=draw, k12=k12, fixed=fixed)
+        ctx.set_lpt_schedule(lpt)                               # forgets the dispatch history: another population
+        d_prev.zero_()
+        nstep[0] = 0
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---- the timed region: K steps split over the draws -------------------------------------------------------------------
+    share = [args.steps // D + (1 if d < args.steps % D else 0) for d in range(D)]
     ctx.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    draw_s = [timed(share[d], args.warmup, d) for d in range(D)]
     if world > 1:
-        # the last gather's block for this rank must be this rank's last torques (every rank checks its own block)
-        own = d_tau_all.view(world, 12, n)[rank]
+        own = d_tau_all[rank]
         if not torch.equal(own, d_tau2[(nstep[0] - 1) & 1]):
             raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
     mpc_ms, mpc_cnt = ctx.get_timing(0)
     wbc_ms, wbc_cnt = ctx.get_timing(1)
     ctx.enable_timing(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    status = d_status.cpu().numpy()
+    rates = [world * n * share[d] / draw_s[d] for d in range(D)]
+    value = float(np.median(rates))
 
-    # the same loop without the longest-first dispatch history (DESIGN.md "tail"): what a batch with no temporal coherence gets
-    value_no_lpt = None
-    if world == 1 and args.compare_dispatch:
-        ctx.set_lpt_schedule(False)
-        for _ in range(3):
-            step()
-        fence()
-        tq0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        value_no_lpt = n * args.steps / (time.perf_counter() - tq0)
-        ctx.set_lpt_schedule(True)
-
-    # PCIe-inclusive rate (never `value`): host buffers in, torques out, every step
-    pcie_value = None
-    if world == 1 and args.mode == "tick":
-        host_in = [torch.from_numpy(S(b[k])).pin_memory() for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd")]
-        dev_in = [d_state, d_traj, d_gait, d_fb, d_cmd]
+    side = {}
+    if world == 1 and not args.no_side and args.mode == "tick":
+        ks = max(10, args.steps // 4)
+        side["ticks_per_s_slot_order_dispatch"] = n * ks / timed(ks, 3, 0, lpt=False)          # no scheduling history at all
+        side["ticks_per_s_without_k12"] = n * ks / timed(ks, args.warmup, 0, k12=False)
+        side["ticks_per_s_same_batch_replayed"] = n * ks / timed(ks, args.warmup, 0, fixed=0)   # round 1's methodology (history = replay)
+        # PCIe-inclusive rate (never `value`): host buffers in, torques out, every step
+        host_in = [torch.from_numpy(S(host0[0][k])).pin_memory() for k in keys]
         host_tau = torch.empty((12, n), dtype=torch.float32).pin_memory()
-        ctx.enable_timing(False)
+        cur.update(draw=0, k12=True, fixed=0)
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
         for _ in range(20):
-            for hsrc, ddst in zip(host_in, dev_in):
+            for hsrc, ddst in zip(host_in, dev_seq[0][0]):
                 ddst.copy_(hsrc, non_blocking=True)
             step()
-            host_tau.copy_(d_tau, non_blocking=True)
+            host_tau.copy_(d_tau2[0], non_blocking=True)
             torch.cuda.synchronize()
-        pcie_value = n * 20 / (time.perf_counter() - tp0)
-
-    # MPC front-end timed on its own: it is a streaming kernel in front of the tick, not part of `value`
-    fe_us = None
-    if world == 1:
+        side["pcie_inclusive_ticks_per_s"] = n * 20 / (time.perf_counter() - tp0)
+        # SURVEY 8f kernels in front of the tick, timed on their own (never part of `value`)
         fe, fst = pkg.workload.make_frontend_batch(n, seed=0xFE)
         d_fe, d_fst = T(fe), T(fst)
-        d_traj2, d_gait2, d_cmd2 = torch.empty_like(d_traj), torch.empty_like(d_gait), torch.empty_like(d_cmd)
+        d_traj2, d_gait2, d_cmd2 = (torch.empty_like(x) for x in (dev_seq[0][0][1], dev_seq[0][0][2], dev_seq[0][0][4]))
         d_upd = torch.zeros((n,), dtype=torch.int32, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
@@ -350,16 +411,12 @@ def main():
             ctx.mpc_frontend_batch(n, d_fe, d_fst, d_traj2, d_gait2, d_cmd2, d_upd)
         e1.record(stream)
         torch.cuda.synchronize()
-        fe_us = 1e3 * e0.elapsed_time(e1) / 50
-    # force-balance (VMC) stance QP, also timed on its own
-    vmc_us = None
-    if world == 1:
+        side["frontend_kernel_us"] = 1e3 * e0.elapsed_time(e1) / 50
         ctx.vmc_setup_packed(0, pkg.workload.vmc_cfg("a1"), pkg.model_desc("a1")[:3])
         vin, vq = pkg.workload.make_vmc_batch(n, seed=0xB2)
         d_vin, d_vq = T(vin), T(vq)
         d_vf, d_vt = torch.empty((12, n), dtype=torch.float32, device=dev), torch.empty((12, n), dtype=torch.float32, device=dev)
         d_vs = torch.zeros((n,), dtype=torch.int32, device=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
         e0.record(stream)
@@ -367,15 +424,12 @@ def main():
             ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
         e1.record(stream)
         torch.cuda.synchronize()
-        vmc_us = 1e3 * e0.elapsed_time(e1) / 20
-
-    status = d_status.cpu().numpy()
-    iters = (status >> 8).astype(np.float64)
-    flags = status & 0xff
+        side["vmc_qp_kernel_us"] = 1e3 * e0.elapsed_time(e1) / 20
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * n * args.steps / elapsed
+        iters = ((status >> 8) & 0xffff).astype(np.float64)
+        flags = status.astype(np.int64) & 0xff0000ff
+        ms_per_step = 1e3 * world * n / value
         it_mean = float(iters.mean()) if args.mode != "wbc" else 0.0
         flop_mpc = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + it_mean * FLOP_K6_PER_ITER
         if args.mode == "wbc":
@@ -383,50 +437,63 @@ def main():
         else:
             dom_ms, dom_flop, dom_name = mpc_ms, flop_mpc, "qr_mpc_kernel"
         achieved = (dom_flop * n) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp) and n == 1024 and h == 10 and args.mode == "tick":     # the PMC passes profile the default command only
-            try:
-                traffic = json.load(open(tp)).get(dom_name)
-            except Exception:
-                traffic = None
+        what = "full MPC+WBC tick (K1-K14: kinematic projection on, motor tail on)"
         out = {
             "metric": "MPC+WBC control ticks/s (batched robots)" if args.mode == "tick" else "%s-only control ticks/s (batched robots)" % args.mode.upper(),
             "value": value, "unit": "ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, full MPC+WBC tick (fp32 assembly, fp64 QP)" % (n // 2, n // 2, h)) if args.mixed
-                       else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, full MPC+WBC tick" % (n, h)
+            "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, %s (fp32 assembly, fp64 QP)" % (n // 2, n // 2, h, what)) if args.mixed
+                       else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, %s" % (n, h, what)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
-                       "robots_per_gpu": n, "horizon": h, "excite": args.excite, "rank_batches": "every rank draws its robots with the same seed (identical work per GPU)", "parallelism": "robots sharded over %d GPU(s), all-gather of torques overlapped with the next tick" % world,
+                       "robots_per_gpu": n, "horizon": h, "excite": args.excite,
+                       "value_is": "median over %d draws (robot populations) of the draw's rate; each draw: %d warm-up + its share of the %d timed steps over a "
+                                   "temporally coherent sequence of %d batches 0.03 s apart" % (D, args.warmup, args.steps, SEQ),
+                       "draws": D, "ticks_per_s_min": float(min(rates)), "ticks_per_s_max": float(max(rates)), "ticks_per_s_per_draw": [float(r) for r in rates],
+                       "ticks_per_s_all_steps": world * n * args.steps / sum(draw_s),
+                       "rank_batches": "every rank draws the same populations (control)" if args.same_seed_ranks else "every rank draws its own populations",
+                       "parallelism": "robots sharded over %d GPU(s); qrgpu_allgather_tau (RCCL, context-owned stream) overlapped with the next tick" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
-                       "pcie_inclusive_ticks_per_s": pcie_value, "frontend_kernel_us": fe_us, "vmc_qp_kernel_us": vmc_us,
-                       "dispatch": "longest-first from the previous step's per-robot solve time", "ticks_per_s_slot_order_dispatch": value_no_lpt},
+                       "dispatch": "longest-first from the previous step's per-robot solve time (a prediction: consecutive steps see different batches)",
+                       **side},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                          "kernel_ms": dom_ms, "kernel_launches": mpc_cnt if dom_name == "qr_mpc_kernel" else wbc_cnt,
                          "algorithmic_flop_per_robot": dom_flop, "other_kernel_ms": wbc_ms if dom_name == "qr_mpc_kernel" else mpc_ms,
                          "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.mixed:
-            out["cpu_baseline"] = cpu_baseline(pkg, b, h, mode=0 if args.mode == "mpc" else 1) if args.mode != "wbc" else None
-            if out["cpu_baseline"] is not None:
-                # BASELINE's metric quotes the torque error beside the rate: one more (untimed) call from the batch's initial WBC memory,
-                # against what the CPU pass above returned for the same inputs; robots either side flags are counted, not compared
-                d_prev.copy_(T(b["prev_ori_vel"]))
-                d_f1, d_t1, d_s1 = torch.zeros_like(d_force), torch.zeros_like(d_tau), torch.zeros_like(d_status)
-                if args.mode == "tick":
-                    ctx.tick_batch(n, d_state, d_traj, d_gait, d_fb, d_cmd, d_prev, d_f1, d_t1, d_s1)
-                else:
-                    ctx.mpc_solve_batch(n, d_state, d_traj, d_gait, d_fb[13:25], d_f1, d_t1, d_s1)
-                torch.cuda.synchronize()
-                f_cpu, tau_cpu, st_cpu = cpu_baseline.outputs
-                ok = ((d_s1.cpu().numpy() & 0xff) == 0) & (st_cpu == 0)
-                f_gpu, tau_gpu = d_f1.cpu().numpy().T, d_t1.cpu().numpy().T
-                out["config"]["max_rel_force_err_vs_cpu"] = float((np.abs(f_gpu - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
-                if args.mode == "tick":
-                    out["config"]["max_rel_torque_err_vs_cpu"] = float((np.abs(tau_gpu - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
-                out["config"]["robots_compared_with_cpu"] = int(ok.sum())
+        if world == 1 and not args.no_cpu_baseline and not args.mixed and args.mode != "wbc":
+            b0 = host0[0]
+            out["cpu_baseline"] = cpu_baseline(pkg, b0, h, mode=0 if args.mode == "mpc" else 1)
+            # BASELINE's metric quotes the torque error beside the rate: one more (untimed) call on draw 0's first batch from fresh WBC
+            # memory, against what the CPU pass returned for the same inputs; robots flagged on either side are counted, not compared
+            d_prev.zero_()
+            d_f1, d_t1, d_s1, d_q1 = torch.zeros_like(d_force), torch.zeros_like(d_tau2[0]), torch.zeros_like(d_status), torch.zeros_like(d_qdes)
+            ds, dt_, dg, dfb, dcmd = dev_seq[0][0]
+            if args.mode == "tick":
+                ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_f1, d_t1, d_s1, d_type, qdes=d_q1)
+            else:
+                ctx.mpc_solve_batch(n, ds, dt_, dg, dfb[13:25], d_f1, d_t1, d_s1)
+            torch.cuda.synchronize()
+            f_cpu, tau_cpu, st_cpu, q_cpu = cpu_baseline.outputs
+            ok = ((d_s1.cpu().numpy().astype(np.int64) & 0xff0000ff) == 0) & (st_cpu == 0)
+            f_gpu, tau_gpu = d_f1.cpu().numpy().T, d_t1.cpu().numpy().T
+            cfgo = out["config"]
+            cfgo["max_rel_force_err_vs_cpu"] = float((np.abs(f_gpu - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
+            cfgo["max_rel_torque_err_vs_cpu"] = float((np.abs(tau_gpu - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
+            if args.mode == "tick":
+                cfgo["max_abs_qdes_err_vs_cpu"] = float(np.abs(d_q1.cpu().numpy().T - q_cpu)[ok].max())
+            cfgo["robots_compared_with_cpu"] = int(ok.sum())
+            if getattr(reference_solver, "as_called", None) is not None:
+                # against the reference's solver exactly as the reference calls it (asymmetric fp32 H, nWSR = 100): DESIGN.md 2
+                idx, f_ref, nwsr, rc = reference_solver.as_called
+                conv = (rc == 0) & (nwsr < 100) & ok[idx]
+                rel = np.abs(f_gpu[idx] - f_ref).max(1) / np.maximum(1.0, np.abs(f_ref).max(1))
+                cfgo["parity_vs_reference_as_called"] = {
+                    "robots": int(idx.size), "reference_converged": int(conv.sum()), "reference_hit_nwsr_100": int((nwsr >= 100).sum()),
+                    "max_rel_force_err": float(rel[conv].max()) if conv.any() else None,
+                    "note": "first-step forces of this batch's first robots vs qpOASES 3.2.0 fed the asymmetric fp32 H with nWSR = 100 "
+                            "(qr_mpc_interface.cpp:418-438); the reference's own H <-> H^T ambiguity bounds this figure (DESIGN.md 2, tests/test_gpu_golden.py)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

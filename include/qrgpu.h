@@ -29,6 +29,10 @@
  *                             QS/controllers/qr_swing_leg_controller.cpp:211-236, QS/planner/qr_foothold_planner.cpp:110-239
  *   qrgpu_tick_batch       <- one MPC solve + one WBC tick per robot, WBC fed with that MPC's Fr_des
  *                             (QS/fsm/qr_fsm_state_locomotion.cpp:130-158 without the MPC/WBC time-slicing)
+ *   qrgpu_set_torque_epilogue <- the motor-command tail of that state: abad compensation (:141-151) and the +-23 N m clip
+ *                             (QS/fsm/qr_safety_checker.cpp:48-66)
+ *   qrgpu_comm_* / qrgpu_allgather_tau <- no reference equivalent (the reference runs one robot per process): the all-gather of torques
+ *                             of BASELINE.json's sharded configurations
  *
  * Error behaviour mirrors the reference: no exceptions; the reference prints
  * "failed to solve!" and carries on (qr_mpc_interface.cpp:440-442) -- here every
@@ -83,17 +87,22 @@ typedef enum {
     QRGPU_ERR_BAD_ARG = 2,
     QRGPU_ERR_NOT_SETUP = 3,      /* solve before setup */
     QRGPU_ERR_LAUNCH = 4,         /* kernel launch or runtime error (see qrgpu_last_error) */
-    QRGPU_ERR_ALLOC = 5
+    QRGPU_ERR_ALLOC = 5,
+    QRGPU_ERR_COMM = 6            /* RCCL failure (librccl missing, communicator error; see qrgpu_last_error) */
 } qrgpu_error;
 
-/* Per-robot status word written by the kernels: bits 0-7 are the flags below (0 = converged), bits 8 and up
- * hold the number of MPC active-set iterations (diagnostic).  Test `(status & 0xff) == 0`. */
+/* Per-robot status word written by the kernels: bits 0-7 and 24-31 are the flags below (0 = converged), bits 8-23
+ * hold the number of MPC active-set iterations (diagnostic).  Test `(status & QRGPU_ST_FLAG_MASK) == 0`. */
+#define QRGPU_ST_FLAG_MASK     0xff0000ffu
+#define QRGPU_ST_ITERATIONS(s) (((s) >> 8) & 0xffff)
 #define QRGPU_ST_OK            0
 #define QRGPU_ST_MPC_MAXITER   0x1    /* active-set iteration cap reached            */
 #define QRGPU_ST_MPC_INFEAS    0x2    /* no feasible step for a violated row, or the solve ended with a row it had set aside as
                                          dependent violated, or an active row not tight, by more than 1e-4 N: the forces are not the optimum */
 #define QRGPU_ST_MPC_OVERFLOW  0x4    /* working set outgrew its LDS allotment       */
 #define QRGPU_ST_MPC_NOTSPD    0x8    /* Hessian pivot <= 0                          */
+#define QRGPU_ST_BAD_TYPE      0x01000000  /* d_type_id names a type outside [0, QRGPU_MAX_TYPES) or one that was never set up: the robot was
+                                         computed with the first type that was set up and its result must not be used */
 #define QRGPU_ST_WBC_MAXITER   0x10
 #define QRGPU_ST_WBC_INFEAS    0x20
 #define QRGPU_ST_VMC_MAXITER   0x40
@@ -164,10 +173,23 @@ int qrgpu_wbc_run_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float
                         float *d_qdes /* [24][n]: desiredJPos, desiredJVel; may be NULL */, int *d_status);
 /* Full tick: MPC, then WBC with Fr_des := that MPC's forces (the Fr_des rows of d_wbc_cmd are ignored).
  * d_tau receives the WBC torque on stance legs and the MPC J^T f torque on swing legs
- * (UpdateLegCMD only overwrites stance legs, qr_wbc_locomotion_controller.cpp:205-219). */
+ * (UpdateLegCMD only overwrites stance legs, qr_wbc_locomotion_controller.cpp:205-219).
+ * d_qdes [24][n] (may be NULL): desiredJPos, desiredJVel of the kinematic multitask projection (K12, qrMultitaskProjection::FindConfiguration,
+ * which qrWbcLocomotionController::Run always executes, qr_wbc_locomotion_controller.cpp:124-129); with NULL that projection is skipped
+ * (its outputs do not enter the torque). */
 int qrgpu_tick_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_mpc_state,
                      const float *d_traj, const float *d_gait, const float *d_fb_state,
-                     const float *d_wbc_cmd, float *d_prev_ori, float *d_force, float *d_tau, int *d_status);
+                     const float *d_wbc_cmd, float *d_prev_ori, float *d_force, float *d_tau, float *d_qdes, int *d_status);
+
+/* Motor-command tail of the locomotion state (K14), off by default -- the single-robot drop-in keeps the FSM doing it:
+ *   QRGPU_EPILOGUE_HIP_COMP  the +-0.9 N m abad compensation of qrFSMStateLocomotion::Run (QS/fsm/qr_fsm_state_locomotion.cpp:141-151:
+ *                            legs FR, RR -0.9, legs FL, RL +0.9, added to every leg's command BEFORE the WBC overwrites its stance legs,
+ *                            so in the full tick it survives on swing legs only; in qrgpu_mpc_solve_batch on every leg)
+ *   QRGPU_EPILOGUE_CLIP      the +-23 N m clip of qrSafetyChecker::CheckForceFeedForward (QS/fsm/qr_safety_checker.cpp:48-66)
+ * Applies to d_tau of qrgpu_tick_batch and qrgpu_mpc_solve_batch. */
+#define QRGPU_EPILOGUE_HIP_COMP 1
+#define QRGPU_EPILOGUE_CLIP     2
+int qrgpu_set_torque_epilogue(qrgpu_ctx *ctx, int flags);
 
 /* MPC front-end of n robots for one control tick: MPCStanceLegController::SetupCommand + Run + UpdateMPC without the solve
  * (QS/controllers/mpc/qr_mpc_stance_leg_controller.cpp:158-204, 207-334, 337-382).  Writes the contact table d_gait every tick,
@@ -205,6 +227,8 @@ typedef struct {
 } qrgpu_estimator_desc;
 void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d);
 int qrgpu_estimator_state_doubles(int window);
+#define QRGPU_EST_IN_ROWS  54     /* rows of est_in  */
+#define QRGPU_EST_OUT_ROWS 42     /* rows of est_out */
 int qrgpu_estimator_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out);
 
@@ -261,6 +285,26 @@ int qrgpu_footholds_batch(qrgpu_ctx *ctx, int n, const qrgpu_foothold_desc *desc
  * Either output may be NULL. */
 int qrgpu_pack_state_batch(qrgpu_ctx *ctx, int n, const float com_offset[3], const float *d_est_in, const float *d_est_out, const float *d_rpy,
                            float *d_mpc_state, float *d_fb_state);
+
+/* ---- multi-GPU: all-gather of the per-robot torques over RCCL / xGMI ----------------------------------------
+ * One process per GPU, one context per process; rank r of N owns a contiguous shard of the robot population and there is no exchange
+ * inside a tick.  The only collective of the path collects every rank's tau[12][n_local] on every rank:
+ *     d_tau_all [nranks][12][n_local]   (rank-major; block r is rank r's d_tau)
+ * The communicator is created from a 128-byte id blob (ncclUniqueId) that rank 0 makes and the launcher hands to the other ranks by
+ * whatever channel it has (MPI, a file, torch.distributed's CPU backend ...): no collective library appears in this ABI's signatures.
+ * qrgpu_allgather_tau takes either that context-owned communicator (nccl_comm = NULL) or the caller's own ncclComm_t.  It is asynchronous:
+ * the gather waits for the work queued on the context's compute stream so far, runs on a stream of the context's own, and the next
+ * tick may be issued at once.  `slot` (0 / 1) names the torque buffer being read for double buffering: call qrgpu_allgather_fence(slot)
+ * before queueing work that overwrites that buffer, qrgpu_comm_sync to wait on the host for every gather issued so far. */
+#define QRGPU_COMM_ID_BYTES 128
+int qrgpu_comm_unique_id(unsigned char id[QRGPU_COMM_ID_BYTES]);
+int qrgpu_comm_init_rank(qrgpu_ctx *ctx, const unsigned char id[QRGPU_COMM_ID_BYTES], int nranks, int rank);
+int qrgpu_comm_info(const qrgpu_ctx *ctx, int *nranks, int *rank);
+int qrgpu_comm_destroy(qrgpu_ctx *ctx);
+int qrgpu_allgather_tau(qrgpu_ctx *ctx, void *nccl_comm /* ncclComm_t, or NULL = the context's */, const float *d_tau /* [12][n_local] */,
+                        int n_local, float *d_tau_all /* [nranks][12][n_local] */, int slot);
+int qrgpu_allgather_fence(qrgpu_ctx *ctx, int slot);
+int qrgpu_comm_sync(qrgpu_ctx *ctx);
 
 /* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */
 int qrgpu_mpc_solve1(qrgpu_ctx *ctx, int type_id, const float p[3], const float v[3], const float quat_wxyz[4],

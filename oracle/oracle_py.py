@@ -31,13 +31,22 @@ def _ip(a):
     return _ptr(a, C.c_int)
 
 
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(x) > t for x in sources if os.path.exists(x))
+
+
 def build(force=False):
-    """Compile libqr_oracle.so (and _ref when /root/reference exists)."""
+    """Compile libqr_oracle.so (and _ref when /root/reference exists).  make decides what is out of date."""
     so = os.path.join(_HERE, "libqr_oracle.so")
-    if force or not os.path.exists(so):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h")) and f != "ref_shim.cpp"] + [os.path.join(_HERE, "Makefile")]
+    if force or _stale(so, srcs):
         subprocess.check_call(["make", "-C", _HERE, "-j4", "all"], stdout=subprocess.DEVNULL)
+    refso = os.path.join(_HERE, "_ref", "libqr_ref.so")
     if os.path.isdir("/root/reference/quadruped/extern/qpOASES/src") and (
-            force or not os.path.exists(os.path.join(_HERE, "_ref", "libqr_ref.so"))):
+            force or _stale(refso, [os.path.join(_HERE, "ref_shim.cpp"), os.path.join(_HERE, "Makefile")])):
         subprocess.check_call(["make", "-C", _HERE, "-j4", "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -209,15 +218,19 @@ def lu_inverse(A):
     return out
 
 
-def tick_batch(mode, cfg, horizon, geom, model, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori_vel, nthreads=1):
-    """Robot-major (AoS) batched tick on host threads.  -> force[n,12], tau[n,12], status[n], seconds"""
+def tick_batch(mode, cfg, horizon, geom, model, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori_vel, nthreads=1, epilogue=0, want_qdes=False):
+    """Robot-major (AoS) batched tick on host threads.  -> force[n,12], tau[n,12], status[n], seconds, prev (, qdes[n,24] with want_qdes)
+    epilogue: 1 = abad hip compensation, 2 = +-23 N m clip (K14 tail, qr_fsm_state_locomotion.cpp:141-151, qr_safety_checker.cpp:48-66)."""
     n = mpc_state.shape[0]
     force = np.zeros((n, 12), _f); tau = np.zeros((n, 12), _f); status = np.zeros(n, np.int32)
+    qdes = np.zeros((n, 24), _f) if want_qdes else None
     arrs = [np.ascontiguousarray(a, _f) for a in (mpc_state, traj, gait, fb_state, wbc_cmd)]
     prev = np.ascontiguousarray(prev_ori_vel, _f)
     sec = lib().qro_tick_batch(n, int(nthreads), int(mode), _fp(cfg), horizon, _fp(np.ascontiguousarray(geom, _f)),
                                _fp(np.ascontiguousarray(model, _f)), _fp(arrs[0]), _fp(arrs[1]), _fp(arrs[2]), _fp(arrs[3]),
-                               _fp(arrs[4]), _fp(prev), _fp(force), _fp(tau), _ip(status))
+                               _fp(arrs[4]), _fp(prev), _fp(force), _fp(tau), _ip(status), int(epilogue), _fp(qdes) if want_qdes else None)
+    if want_qdes:
+        return force, tau, status, sec, prev, qdes
     return force, tau, status, sec, prev
 
 

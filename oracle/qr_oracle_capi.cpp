@@ -10,6 +10,7 @@
 //                  pFoot_des[12], vFoot_des[12], aFoot_des[12], Fr_des[12], contact[4] (0/1)
 //   model[6]     = hip_l, upper_l, lower_l, body_size[3]
 #include "qr_oracle.h"
+#include <cmath>
 #include <thread>
 #include <chrono>
 
@@ -188,11 +189,12 @@ void qro_lu_inverse_f32(int n, const float *A, float *out)
 // (SURVEY.md 8d).  Arrays are AoS per robot here (robot-major); returns seconds.
 //   mode: 0 = MPC only (tau = K7 torques), 1 = full tick (tau = WBC torques on stance
 //   legs, K7 torques on swing legs untouched by UpdateLegCMD :205-219)
+//   epilogue: bit 0 = abad hip compensation, bit 1 = +-23 clip (K14 tail); qdes24_out (may be null): desiredJPos, desiredJVel of K12
 // ---------------------------------------------------------------------------
 double qro_tick_batch(int nrobots, int nthreads, int mode, const float *cfg, int horizon, const float *geom3, const float *model,
                       const float *mpc_state28, const float *traj, const float *gait,
                       const float *fb_state37, const float *wbc_cmd67, float *prev_ori_vel3,
-                      float *force12_out, float *tau12_out, int *status_out)
+                      float *force12_out, float *tau12_out, int *status_out, int epilogue, float *qdes24_out)
 {
     auto t0 = std::chrono::steady_clock::now();
     MpcConfig c = unpack_cfg(cfg, horizon);
@@ -210,6 +212,14 @@ double qro_tick_batch(int nrobots, int nthreads, int mode, const float *cfg, int
             float tau[12];
             mpc_force_to_torque(g, fs, fs + 13, u.data(), tau);
             for (int k = 0; k < 12; ++k) force12_out[12 * i + k] = (float)u[k];
+            // legCmd[motor].tua (a double, qrMotorCommand) as qrFSMStateLocomotion::Run leaves it (QS/fsm/qr_fsm_state_locomotion.cpp:131-156):
+            // hybridAction's tua, then +-0.9 on every abad motor (:141-151), then -- full tick -- UpdateLegCMD overwrites the stance legs
+            // (qr_wbc_locomotion_controller.cpp:205-219), then the +-23 clip of CheckForceFeedForward (QS/fsm/qr_safety_checker.cpp:48-66)
+            double tua[12];
+            for (int k = 0; k < 12; ++k) {
+                tua[k] = (double)tau[k];
+                if ((epilogue & 1) && k % 3 == 0) { float comp = 0.9f * (float)std::pow(-1.0, (double)((k / 3 + 1) % 2)); tua[k] += comp; }
+            }
             if (mode == 1) {
                 float cmd[67];
                 memcpy(cmd, wbc_cmd67 + 67 * i, sizeof(cmd));
@@ -217,10 +227,12 @@ double qro_tick_batch(int nrobots, int nthreads, int mode, const float *cfg, int
                 WbcOut<float> o;
                 wbc_run(md, unpack_state(fs), unpack_cmd(cmd), prev_ori_vel3 + 3 * i, o);
                 for (int l = 0; l < 4; ++l)
-                    if (cmd[63 + l] != 0.f) for (int j = 0; j < 3; ++j) tau[3 * l + j] = o.tau[3 * l + j];
+                    if (cmd[63 + l] != 0.f) for (int j = 0; j < 3; ++j) tua[3 * l + j] = (double)o.tau[3 * l + j];
+                if (qdes24_out) for (int k = 0; k < 12; ++k) { qdes24_out[24 * i + k] = o.qdes[k]; qdes24_out[24 * i + 12 + k] = o.qddes[k]; }
                 rc |= o.qp_status << 4;
             }
-            for (int k = 0; k < 12; ++k) tau12_out[12 * i + k] = tau[k];
+            if (epilogue & 2) for (int k = 0; k < 12; ++k) { if (tua[k] > 23) tua[k] = 23; else if (tua[k] < -23) tua[k] = -23; }
+            for (int k = 0; k < 12; ++k) tau12_out[12 * i + k] = (float)tua[k];
             if (status_out) status_out[i] = rc;
         }
     };

@@ -12,4 +12,4 @@ from . import ticklog                   # noqa: F401
 from . import replay                    # noqa: F401
 from .qrgpu import (Context, QrgpuError, MissingExtension, lib_path, load_library,   # noqa: F401
                     MPCInterface, WbcLocomotionController, model_desc_struct)
-from .workload import make_batch, mpc_cfg, model_desc, to_soa, ROBOTS    # noqa: F401
+from .workload import make_batch, make_batch_sequence, mpc_cfg, model_desc, to_soa, ROBOTS    # noqa: F401

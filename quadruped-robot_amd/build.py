@@ -5,11 +5,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libqrgpu.so")
-SOURCES = ["qr_mpc_kernel.hip", "qr_wbc_kernel.hip", "qr_frontend_kernel.hip", "qr_vmc_kernel.hip", "qr_estimator_kernel.hip", "qrgpu_api.hip"]
+SOURCES = ["qr_mpc_kernel.hip", "qr_wbc_kernel.hip", "qr_frontend_kernel.hip", "qr_vmc_kernel.hip", "qr_estimator_kernel.hip", "qrgpu_api.hip", "qrgpu_comm.hip"]
 # The fp32 MPC assembly must execute exactly the written fmaf chain (bit-identical to the CPU oracle, see
 # DESIGN.md "bit-exact assembly"): those functions carry `#pragma clang fp contract(off)`; everything else
 # (fp64 sweep / active set / WBC) is free to fuse multiply-adds.  NB plain -ffp-contract=fast would IGNORE those pragmas.
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast-honor-pragmas", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast-honor-pragmas", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
 def _stale():
@@ -54,7 +54,7 @@ def _build_locked(verbose):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return SO
 

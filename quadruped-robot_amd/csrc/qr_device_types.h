@@ -17,6 +17,7 @@ namespace qrgpu {
 #define QRGPU_ST_WBC_INFEAS_D   0x20
 #define QRGPU_ST_VMC_MAXITER_D  0x40
 #define QRGPU_ST_VMC_INFEAS_D   0x80
+#define QRGPU_ST_BAD_TYPE_D     0x01000000   // type id out of range or never set up (bit 24: above the flag byte and the 16-bit iteration count)
 
 // XCD-aware robot index.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8
 // share an XCD) and each XCD has its own L2.  The SoA inputs put 32 consecutive robots in one 128-B line, so with
@@ -62,6 +63,8 @@ struct MpcLaunch {
     // scratch instead ([robot][tri(QR_QH)] doubles, L2-resident), MAXB = 9 variants only
     double *sinv_spill;
     int no_wcache;              // diagnostic (QRGPU_NO_WCACHE=1): always take the z = w - M (N_A r) form
+    int type_ready;             // bit t: type t was set up (robots naming any other type are flagged QRGPU_ST_BAD_TYPE)
+    int epilogue;               // QRGPU_EPILOGUE_* bits applied to g_tau (MPC-only batches; 0 inside the fused tick)
 };
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.

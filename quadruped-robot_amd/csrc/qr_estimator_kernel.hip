@@ -32,51 +32,42 @@ __device__ __forceinline__ void mulmat3(const double *a, const double *b, double
             c[3 * i + j] = acc;
         }
 }
-__device__ __forceinline__ int cholsl3(const double *A, double *a, double *p)
+// Inverse of a symmetric positive-definite 3x3 (row-major) through its Cholesky factor, written out entry by entry.
+// Returns 1 when a pivot is not positive.  The Kalman step is compared bit for bit with the reference's compiled filter
+// (tests/test_oracle_estimator.py), whose inverse runs factor -> inverse of the factor -> product of the inverse factors; bit identity
+// needs those roundings in that sequence, so every statement below is one IEEE operation (contraction off) in that dependency order,
+// including the `0.0 -` / `0.0 +` starts of the accumulated sums.
+__device__ __forceinline__ int spd3_inverse(const double *A, double *inv)
 {
 #pragma clang fp contract(off)
-    const int n = 3;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) a[i] = A[i];
-#pragma unroll
-    for (int i = 0; i < n; i++)
-#pragma unroll
-        for (int j = i; j < n; j++) {
-            double sum = a[i * n + j];
-#pragma unroll
-            for (int k = i - 1; k >= 0; k--) sum -= a[i * n + k] * a[j * n + k];
-            if (i == j) { if (sum <= 0) return 1; p[i] = sqrt(sum); }
-            else a[j * n + i] = sum / p[i];
-        }
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-        a[i * n + i] = 1 / p[i];
-#pragma unroll
-        for (int j = i + 1; j < n; j++) {
-            double sum = 0;
-#pragma unroll
-            for (int k = i; k < j; k++) sum -= a[j * n + k] * a[k * n + i];
-            a[j * n + i] = sum / p[j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < n; i++)
-#pragma unroll
-        for (int j = i + 1; j < n; j++) a[i * n + j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-        a[i * n + i] *= a[i * n + i];
-#pragma unroll
-        for (int k = i + 1; k < n; k++) a[i * n + i] += a[k * n + i] * a[k * n + i];
-#pragma unroll
-        for (int j = i + 1; j < n; j++)
-#pragma unroll
-            for (int k = j; k < n; k++) a[i * n + j] += a[k * n + i] * a[k * n + j];
-    }
-#pragma unroll
-    for (int i = 0; i < n; i++)
-#pragma unroll
-        for (int j = 0; j < i; j++) a[i * n + j] = a[j * n + i];
+    // factor A = L L^T: d0..d2 the diagonal of L, l10 l20 l21 below it
+    if (A[0] <= 0) return 1;
+    const double d0 = sqrt(A[0]);
+    const double l10 = A[1] / d0, l20 = A[2] / d0;
+    const double s11 = A[4] - l10 * l10;
+    if (s11 <= 0) return 1;
+    const double d1 = sqrt(s11);
+    const double l21 = (A[5] - l10 * l20) / d1;
+    const double s22 = (A[8] - l21 * l21) - l20 * l20;
+    if (s22 <= 0) return 1;
+    const double d2 = sqrt(s22);
+    // K = L^-1 (lower triangular), column by column
+    const double k00 = 1 / d0;
+    const double k10 = (0.0 - l10 * k00) / d1;
+    const double k20 = ((0.0 - l20 * k00) - l21 * k10) / d2;
+    const double k11 = 1 / d1;
+    const double k21 = (0.0 - l21 * k11) / d2;
+    const double k22 = 1 / d2;
+    // A^-1 = K^T K, upper triangle then mirrored
+    const double i00 = (k00 * k00 + k10 * k10) + k20 * k20;
+    const double i01 = (0.0 + k10 * k11) + k20 * k21;
+    const double i02 = 0.0 + k20 * k22;
+    const double i11 = k11 * k11 + k21 * k21;
+    const double i12 = 0.0 + k21 * k22;
+    const double i22 = k22 * k22;
+    inv[0] = i00; inv[1] = i01; inv[2] = i02;
+    inv[3] = i01; inv[4] = i11; inv[5] = i12;
+    inv[6] = i02; inv[7] = i12; inv[8] = i22;
     return 0;
 }
 
@@ -219,7 +210,7 @@ __global__ void __launch_bounds__(64) qr_estimator_kernel(int n, EstimatorDesc D
         for (int r = 0; r < 3; ++r) tmp3[4 * r] += rv;
 #pragma unroll
         for (int r = 0; r < 9; ++r) if (r % 4 != 0) tmp3[r] += 0.0;
-        if (!cholsl3(tmp3, tmp4, tmp5)) {
+        if (!spd3_inverse(tmp3, tmp4)) {
             mulmat3(tmp1, tmp4, G);
 #pragma unroll
             for (int r = 0; r < 3; ++r) tmp5[r] = z[r] - fx[r];

@@ -207,9 +207,20 @@ __device__ __forceinline__ void mpc_jacobian_column(int leg, int j, int rid, int
     sJ3[0] = J0; sJ3[1] = J1; sJ3[2] = J2;
 }
 
+// epilogue (MPC-only batches; in the fused tick the WBC kernel applies it after the stance/swing merge): bit 0 = the +-0.9 N m abad
+// compensation of qrFSMStateLocomotion::Run (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), bit 1 = the +-23 N m clip of
+// qrSafetyChecker::CheckForceFeedForward (QS/fsm/qr_safety_checker.cpp:48-66); legCmd.tua is a double there.
+__device__ __forceinline__ float torque_epilogue(float tau, int motor, bool comp, int epilogue)
+{
+    double t = (double)tau;
+    if (comp && (epilogue & 1) && motor % 3 == 0) t += (double)(((motor / 3) & 1) ? 0.9f : -0.9f);     // tua_ * pow(-1, (leg + 1) % 2)
+    if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
+    return (float)t;
+}
+
 __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const double *yl, const float (&R)[3][3], const float *sJ, const MpcType &C,
                                             const float *__restrict__ g_q, float *__restrict__ g_force, float *__restrict__ g_force_wbc,
-                                            int force_stride, float *__restrict__ g_tau)
+                                            int force_stride, float *__restrict__ g_tau, int epilogue)
 {
     if (lane < 12) {
         const int leg = lane / 3;
@@ -224,7 +235,8 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
             float Jl[3];
             if (!sJ) mpc_jacobian_column(leg, lane - 3 * leg, rid, n, C, g_q, Jl);      // (h = 16 variants: no LDS to spare for the early copy)
             const float J0 = sJ ? sJ[3 * lane] : Jl[0], J1 = sJ ? sJ[3 * lane + 1] : Jl[1], J2 = sJ ? sJ[3 * lane + 2] : Jl[2];
-            g_tau[(size_t)lane * n + rid] = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
+            const float tq = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
+            g_tau[(size_t)lane * n + rid] = epilogue ? torque_epilogue(tq, lane, true, epilogue) : tq;
         }
     }
 }
@@ -302,7 +314,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         if (P.rescue_count && blockIdx.x == 0 && tid == 0) P.rescue_count[P.rescue_parity ^ 1] = 0;     // the next call's counter
     }
     const long long t_begin = P.cost ? clock64() : 0;
-    const MpcType &C = P.type[type_id ? type_id[rid] : 0];
+    // a type id outside the table, or one that was never set up, would read garbage (mass 0 => 1/mass = inf): the robot is solved with the
+    // first valid type's constants and carries QRGPU_ST_BAD_TYPE
+    int tyid = type_id ? type_id[rid] : 0;
+    const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((P.type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
+    if (bad_type) tyid = __builtin_ctz(P.type_ready | (1 << QR_MAX_TYPES));
+    const MpcType &C = P.type[tyid & (QR_MAX_TYPES - 1)];
     const int h = P.horizon;
     const int NV = 12 * h, NL = 4 * h;
 
@@ -477,7 +494,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         if (qW > 64) qW = 64;
         if (P.no_wcache == 1) qW = 0;
     }
-    int st = 0;
+    int st = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
     if (npairs > MAXB * QR_MPC_THREADS) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
 
     float w2[13];
@@ -1213,8 +1230,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             wave_sync();
             if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
             wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
-            if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
+            if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
             if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
             QR_TS(6);
@@ -1535,8 +1552,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             wave_sync();
             if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
             wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
-            if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
+            if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
             if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
             QR_TS(6);
@@ -1812,8 +1829,8 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     wave_sync();
     if (own) { const int ls = sLs[kme]; if (ls < 4) { yl[3 * ls] = x0; yl[3 * ls + 1] = x1; yl[3 * ls + 2] = x2; } }
     wave_sync();
-    mpc_outputs(lane, rid, n, yl, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau);
-    if (lane == 0 && g_status) g_status[rid] = st | (iter << 8);
+    mpc_outputs(lane, rid, n, yl, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
+    if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
     if (tid == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
     QR_TS(6);
 #ifndef QR_TRACE

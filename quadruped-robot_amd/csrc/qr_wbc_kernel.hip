@@ -299,7 +299,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
                    float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT,
-                   const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */)
+                   const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */,
+                   int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */)
 {
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
@@ -307,7 +308,10 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     const int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x;
     if (rid < 0) return;
-    const WbcConst &K = types[type_id ? type_id[rid] : 0];
+    int tyid = type_id ? type_id[rid] : 0;
+    const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
+    if (bad_type) tyid = __builtin_ctz(type_ready | (1 << QR_MAX_TYPES));     // computed with the first valid type, flagged QRGPU_ST_BAD_TYPE
+    const WbcConst &K = types[tyid & (QR_MAX_TYPES - 1)];
 
     __shared__ real sm[QR_WBC_LDS_DOUBLES];
     real *A = sm;                  // 324  mass matrix
@@ -854,7 +858,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     }
     if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
     wsync();
-    int stw = 0;
+    int stw = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
     {
         // Goldfarb-Idnani, Schur-complement form, M = W^-1 diagonal, dense normals.
         int q = 0;
@@ -1030,7 +1034,18 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         for (int k = 0; k < 6; ++k) acc += A[row * 18 + k] * qx[k];
         for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + row] * qx[6 + k];
         const int leg = lane / 3;
-        if (!merge_tau || cm[63 + leg] != 0.0) g_tau[(size_t)lane * n + rid] = (float)acc;
+        const bool stance = cm[63 + leg] != 0.0;
+        if (!epilogue) {
+            if (!merge_tau || stance) g_tau[(size_t)lane * n + rid] = (float)acc;
+        } else {
+            // K14 tail (fused tick): UpdateLegCMD overwrites the stance legs (:205-219) AFTER qrFSMStateLocomotion::Run added the +-0.9 N m abad
+            // compensation to every leg (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), so the compensation survives on swing legs only (their
+            // command is what the MPC kernel left in g_tau); then the +-23 N m clip (QS/fsm/qr_safety_checker.cpp:48-66).  legCmd.tua is a double.
+            double t = stance ? (double)(float)acc : (double)g_tau[(size_t)lane * n + rid];
+            if (!stance && (epilogue & 1) && lane % 3 == 0) t += (double)((leg & 1) ? 0.9f : -0.9f);
+            if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
+            g_tau[(size_t)lane * n + rid] = (float)t;
+        }
     }
     if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
     QW_TS(9);

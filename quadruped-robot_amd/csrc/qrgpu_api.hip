@@ -10,8 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/qrgpu.h"
-#include "qr_device_types.h"
+#include "qrgpu_ctx.h"
 
 namespace qrgpu {
 template <int MAXB, bool MULTI, int TAG>
@@ -37,57 +36,8 @@ __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
-                              const float *g_fr);
+                              const float *g_fr, int type_ready, int epilogue);
 }
-using namespace qrgpu;
-
-struct qrgpu_ctx {
-    int device = 0;
-    int max_batch = 0;
-    int horizon_max = 0;
-    hipStream_t stream = nullptr;
-    MpcLaunch mpc{};
-    bool mpc_ready[QR_MAX_TYPES] = {false, false, false, false};
-    bool wbc_ready[QR_MAX_TYPES] = {false, false, false, false};
-    VmcLaunch vmc{};
-    bool vmc_ready[QR_MAX_TYPES] = {false, false, false, false};
-    WbcConst wbc_host[QR_MAX_TYPES];
-    WbcConst *d_wbc = nullptr;
-    bool wbc_dirty = true;
-    // scratch for the single-robot calls and the fused tick
-    float *d_in1 = nullptr;       // staging: single-robot inputs
-    float *d_out1 = nullptr;      // staging: single-robot outputs
-    int *d_st1 = nullptr;
-    int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
-    int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
-    int configured_lds[3] = {0, 0, 0};     // dynamic-LDS limit already set on this context's device, per kernel variant
-    int configured_rescue[2] = {0, 0};
-    double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
-    int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
-    int rescue_parity = 0;
-    int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
-    bool lpt = true;
-    bool rescue = true;
-    float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
-    void *d_dbg_cycles_wbc = nullptr;
-    void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
-    int lds_per_cu = 0, num_cu = 0;
-    std::string name;
-    std::string err;
-    // timing
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
-    size_t ev_used[2] = {0, 0};
-};
-
-#define HIPCHK(ctx, call)                                                                    \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
-            return QRGPU_ERR_LAUNCH;                                                         \
-        }                                                                                    \
-    } while (0)
 
 // h > 11: the four-wave active set is the default; a working set that reaches its 64 lanes is handed over in place to the single-wave
 // loop (up to 96 rows), so no rescue launch is needed there.  QRGPU_H16_SINGLE=1 selects the single-wave variant for the whole solve.
@@ -259,6 +209,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    qrgpu_comm_destroy(c);
     for (int k = 0; k < 2; ++k) for (auto &e : c->ev[k]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->d_in1) hipFree(c->d_in1);
     if (c->d_out1) hipFree(c->d_out1);
@@ -333,15 +284,20 @@ static int upload_wbc(qrgpu_ctx *c)
     return QRGPU_OK;
 }
 
+static int ready_mask(const bool *r) { int m = 0; for (int t = 0; t < QR_MAX_TYPES; ++t) if (r[t]) m |= 1 << t; return m; }
+
 static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_traj, const float *d_gait,
-                      const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc)
+                      const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc, int epilogue = 0)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state || !d_traj || !d_gait || !d_force) return QRGPU_ERR_BAD_ARG;
     if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
-    if (!c->mpc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    // without a type array every robot is type 0; with one, the kernel flags robots whose type was never set up (QRGPU_ST_BAD_TYPE)
+    if (!(d_type ? ready_mask(c->mpc_ready) != 0 : c->mpc_ready[0])) return QRGPU_ERR_NOT_SETUP;
     HIPCHK(c, hipSetDevice(c->device));
     MpcLaunch P = c->mpc;
     P.n = n;
+    P.type_ready = ready_mask(c->mpc_ready);
+    P.epilogue = epilogue;
     P.lds_bytes = mpc_lds_bytes(c, P.horizon);
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
@@ -421,18 +377,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 }
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
-                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr)
+                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
-    if (!c->wbc_ready[0]) return QRGPU_ERR_NOT_SETUP;
+    if (!(d_type ? ready_mask(c->wbc_ready) != 0 : c->wbc_ready[0])) return QRGPU_ERR_NOT_SETUP;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_wbc(c);
     if (rc) return rc;
     {
         TimerScope ts(c, 1);
         hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
-                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr);
+                           d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
+                           ready_mask(c->wbc_ready), epilogue);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -441,7 +398,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 int qrgpu_mpc_solve_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
                           const float *d_gait, const float *d_q, float *d_force, float *d_tau_mpc, int *d_status)
 {
-    return launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_q, d_force, d_tau_mpc, d_status, nullptr, nullptr, nullptr);
+    return launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_q, d_force, d_tau_mpc, d_status, nullptr, nullptr, nullptr, c ? c->epilogue : 0);
 }
 
 int qrgpu_mpc_assemble_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
@@ -639,17 +596,25 @@ int qrgpu_mpc_frontend_batch(qrgpu_ctx *c, int n, int num_horizon_l, float dt_ct
 
 int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_mpc_state, const float *d_traj,
                      const float *d_gait, const float *d_fb_state, const float *d_wbc_cmd, float *d_prev_ori,
-                     float *d_force, float *d_tau, int *d_status)
+                     float *d_force, float *d_tau, float *d_qdes, int *d_status)
 {
     if (!c || !d_fb_state || !d_wbc_cmd || !d_tau || !d_prev_ori) return QRGPU_ERR_BAD_ARG;
     if (n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written
+    // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written.
+    // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
     int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, d_force ? d_force : c->d_cmd_tick, d_tau, d_status,
-                        nullptr, nullptr, nullptr);
+                        nullptr, nullptr, nullptr, 0);
     if (rc) return rc;
-    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, nullptr, d_status, nullptr, 1, d_status ? 1 : 0,
-                      d_force ? d_force : c->d_cmd_tick);
+    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0,
+                      d_force ? d_force : c->d_cmd_tick, c->epilogue);
+}
+
+int qrgpu_set_torque_epilogue(qrgpu_ctx *c, int flags)
+{
+    if (!c || (flags & ~(QRGPU_EPILOGUE_HIP_COMP | QRGPU_EPILOGUE_CLIP))) return QRGPU_ERR_BAD_ARG;
+    c->epilogue = flags;
+    return QRGPU_OK;
 }
 
 int qrgpu_mpc_solve1(qrgpu_ctx *c, int type_id, const float p[3], const float v[3], const float quat[4], const float w[3],

@@ -1,0 +1,165 @@
+// ============================================================================
+// libqrgpu.so, multi-GPU: the one exchange of the path -- the all-gather of per-robot torques over RCCL / xGMI
+//  -- behind the C ABI, so that a C++ caller needs neither torch nor its own collective code.
+//
+// Robots are independent: rank r owns a contiguous shard and there is no exchange inside a tick.  After a tick every
+// rank holds tau[12][n_local]; one ncclAllGather leaves tau_all[nranks][12][n_local] on every rank.  48 KB per rank at 1024
+// robots: latency bound, so it runs on a stream of its own, behind an event of the compute stream, while the next tick computes;
+// the compute stream only waits (qrgpu_allgather_fence) for the gather that still reads the buffer it is about to overwrite.
+//
+// librccl is opened at first use (dlopen): single-GPU users of libqrgpu.so never load it.
+// ============================================================================
+#include <dlfcn.h>
+#include <cstring>
+#include <rccl/rccl.h>
+
+#include "qrgpu_ctx.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl()
+{
+    static Rccl R;
+    if (R.handle || !R.err.empty()) return &R;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (R.handle) break;
+    }
+    if (!R.handle) { R.err = std::string("dlopen librccl: ") + dlerror(); return &R; }
+    auto sym = [&](const char *s) { void *p = dlsym(R.handle, s); if (!p && R.err.empty()) R.err = std::string("librccl lacks ") + s; return p; };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+    R.CommCount = (decltype(R.CommCount))sym("ncclCommCount");
+    R.CommUserRank = (decltype(R.CommUserRank))sym("ncclCommUserRank");
+    R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    return &R;
+}
+
+#define NCCLCHK(ctx, R, call)                                                                         \
+    do {                                                                                              \
+        ncclResult_t r_ = (call);                                                                     \
+        if (r_ != ncclSuccess) {                                                                      \
+            (ctx)->err = std::string(#call) + ": " + ((R)->GetErrorString ? (R)->GetErrorString(r_) : "rccl error"); \
+            return QRGPU_ERR_COMM;                                                                    \
+        }                                                                                             \
+    } while (0)
+
+int ensure_comm_stream(qrgpu_ctx *c)
+{
+    if (c->comm_stream) return QRGPU_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_tick, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather[i], hipEventDisableTiming));
+    return QRGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrgpu_comm_unique_id(unsigned char id[QRGPU_COMM_ID_BYTES])
+{
+    static_assert(QRGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id blob size");
+    if (!id) return QRGPU_ERR_BAD_ARG;
+    Rccl *R = rccl();
+    if (!R->err.empty()) return QRGPU_ERR_COMM;
+    ncclUniqueId u;
+    if (R->GetUniqueId(&u) != ncclSuccess) return QRGPU_ERR_COMM;
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return QRGPU_OK;
+}
+
+int qrgpu_comm_init_rank(qrgpu_ctx *c, const unsigned char id[QRGPU_COMM_ID_BYTES], int nranks, int rank)
+{
+    if (!c || !id || nranks <= 0 || rank < 0 || rank >= nranks) return QRGPU_ERR_BAD_ARG;
+    if (c->comm) return QRGPU_ERR_BAD_ARG;            // one communicator per context
+    Rccl *R = rccl();
+    if (!R->err.empty()) { c->err = R->err; return QRGPU_ERR_COMM; }
+    int rc = ensure_comm_stream(c);
+    if (rc) return rc;
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, R, R->CommInitRank(&comm, nranks, u, rank));
+    c->comm = comm; c->comm_owned = true; c->comm_nranks = nranks; c->comm_rank = rank;
+    return QRGPU_OK;
+}
+
+int qrgpu_comm_destroy(qrgpu_ctx *c)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    if (c->comm && c->comm_owned) { Rccl *R = rccl(); if (R->CommDestroy) R->CommDestroy((ncclComm_t)c->comm); }
+    c->comm = nullptr; c->comm_owned = false; c->comm_nranks = 0; c->comm_rank = 0;
+    if (c->comm_stream) {
+        hipSetDevice(c->device);
+        hipEventDestroy(c->ev_tick);
+        for (int i = 0; i < 2; ++i) hipEventDestroy(c->ev_gather[i]);
+        hipStreamDestroy(c->comm_stream);
+        c->comm_stream = nullptr; c->ev_tick = nullptr; c->ev_gather[0] = c->ev_gather[1] = nullptr;
+        c->ev_gather_pending[0] = c->ev_gather_pending[1] = false;
+    }
+    return QRGPU_OK;
+}
+
+int qrgpu_comm_info(const qrgpu_ctx *c, int *nranks, int *rank)
+{
+    if (!c || !c->comm) return QRGPU_ERR_NOT_SETUP;
+    if (nranks) *nranks = c->comm_nranks;
+    if (rank) *rank = c->comm_rank;
+    return QRGPU_OK;
+}
+
+int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot)
+{
+    if (!c || !d_tau || !d_tau_all || n_local <= 0 || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
+    ncclComm_t comm = nccl_comm ? (ncclComm_t)nccl_comm : (ncclComm_t)c->comm;
+    if (!comm) return QRGPU_ERR_NOT_SETUP;
+    Rccl *R = rccl();
+    if (!R->err.empty()) { c->err = R->err; return QRGPU_ERR_COMM; }
+    int rc = ensure_comm_stream(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    // the gather starts when everything queued on the compute stream so far (this tick's torques) is complete ...
+    HIPCHK(c, hipEventRecord(c->ev_tick, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_tick, 0));
+    NCCLCHK(c, R, R->AllGather(d_tau, d_tau_all, (size_t)12 * (size_t)n_local, ncclFloat, comm, c->comm_stream));
+    // ... and whoever overwrites d_tau (buffer `slot`) later fences on this event
+    HIPCHK(c, hipEventRecord(c->ev_gather[slot], c->comm_stream));
+    c->ev_gather_pending[slot] = true;
+    return QRGPU_OK;
+}
+
+int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
+    if (!c->comm_stream || !c->ev_gather_pending[slot]) return QRGPU_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
+    c->ev_gather_pending[slot] = false;
+    return QRGPU_OK;
+}
+
+int qrgpu_comm_sync(qrgpu_ctx *c)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    return QRGPU_OK;
+}
+
+}  // extern "C"

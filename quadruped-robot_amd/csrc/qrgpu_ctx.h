@@ -1,0 +1,69 @@
+// Internal: the context behind the opaque qrgpu_ctx of include/qrgpu.h (shared by qrgpu_api.hip and qrgpu_comm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/qrgpu.h"
+#include "qr_device_types.h"
+
+using namespace qrgpu;
+
+struct qrgpu_ctx {
+    int device = 0;
+    int max_batch = 0;
+    int horizon_max = 0;
+    hipStream_t stream = nullptr;
+    MpcLaunch mpc{};
+    bool mpc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    bool wbc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    VmcLaunch vmc{};
+    bool vmc_ready[QR_MAX_TYPES] = {false, false, false, false};
+    WbcConst wbc_host[QR_MAX_TYPES];
+    WbcConst *d_wbc = nullptr;
+    bool wbc_dirty = true;
+    // scratch for the single-robot calls and the fused tick
+    float *d_in1 = nullptr;       // staging: single-robot inputs
+    float *d_out1 = nullptr;      // staging: single-robot outputs
+    int *d_st1 = nullptr;
+    int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
+    int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
+    int configured_lds[3] = {0, 0, 0};     // dynamic-LDS limit already set on this context's device, per kernel variant
+    int configured_rescue[2] = {0, 0};
+    double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
+    int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
+    int rescue_parity = 0;
+    int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
+    bool lpt = true;
+    bool rescue = true;
+    int epilogue = 0;             // QRGPU_EPILOGUE_* bits
+    float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
+    void *d_dbg_cycles_wbc = nullptr;
+    void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
+    int lds_per_cu = 0, num_cu = 0;
+    std::string name;
+    std::string err;
+    // multi-GPU: context-owned RCCL communicator and the stream its all-gathers run on (qrgpu_comm.hip)
+    void *comm = nullptr;         // ncclComm_t
+    bool comm_owned = false;
+    int comm_nranks = 0, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_tick = nullptr;          // compute stream -> comm stream: this tick's torques are complete
+    hipEvent_t ev_gather[2] = {nullptr, nullptr};   // comm stream -> compute stream: the gather that read buffer `slot` has landed
+    bool ev_gather_pending[2] = {false, false};
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    size_t ev_used[2] = {0, 0};
+};
+
+#define HIPCHK(ctx, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return QRGPU_ERR_LAUNCH;                                                         \
+        }                                                                                    \
+    } while (0)
+

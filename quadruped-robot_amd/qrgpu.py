@@ -20,7 +20,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ERRORS = {0: "OK", 1: "NO_DEVICE", 2: "BAD_ARG", 3: "NOT_SETUP", 4: "LAUNCH", 5: "ALLOC"}
+ERRORS = {0: "OK", 1: "NO_DEVICE", 2: "BAD_ARG", 3: "NOT_SETUP", 4: "LAUNCH", 5: "ALLOC", 6: "COMM"}
+ST_FLAG_MASK, ST_BAD_TYPE = 0xff0000ff, 0x01000000
 ST_MPC_MAXITER, ST_MPC_INFEAS, ST_MPC_OVERFLOW, ST_MPC_NOTSPD = 0x1, 0x2, 0x4, 0x8
 ST_WBC_MAXITER, ST_WBC_INFEAS = 0x10, 0x20
 FB_DEBUG_FLOATS = 324 + 18 + 18 + 216 + 12 + 12 + 12
@@ -63,6 +64,19 @@ class gait_desc_struct(C.Structure):
                 ("advanced_trot", C.c_int)]
 
 
+EPILOGUE_HIP_COMP, EPILOGUE_CLIP = 1, 2
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """A fresh ncclUniqueId blob (rank 0 makes it; the launcher hands it to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load_library().qrgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise QrgpuError("qrgpu_comm_unique_id failed: %s" % ERRORS.get(rc, rc))
+    return buf.raw
+
+
 def lib_path():
     return os.path.join(_HERE, "libqrgpu.so")
 
@@ -73,7 +87,9 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
-           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1"]
+           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
+           "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
+           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync"]
 
 
 def load_library():
@@ -98,7 +114,15 @@ def load_library():
     lib.qrgpu_wbc_setup.argtypes = [vp, ip, C.POINTER(model_desc_struct)]
     lib.qrgpu_mpc_solve_batch.argtypes = [vp, ip] + [vp] * 8
     lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
-    lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 10
+    lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 11
+    lib.qrgpu_set_torque_epilogue.argtypes = [vp, ip]
+    lib.qrgpu_comm_unique_id.argtypes = [C.c_char_p]
+    lib.qrgpu_comm_init_rank.argtypes = [vp, C.c_char_p, ip, ip]
+    lib.qrgpu_comm_info.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
+    lib.qrgpu_comm_destroy.argtypes = [vp]
+    lib.qrgpu_allgather_tau.argtypes = [vp, vp, vp, ip, vp, ip]
+    lib.qrgpu_allgather_fence.argtypes = [vp, ip]
+    lib.qrgpu_comm_sync.argtypes = [vp]
     lib.qrgpu_mpc_assemble_batch.argtypes = [vp, ip] + [vp] * 6
     lib.qrgpu_vmc_desc_default.argtypes = [C.POINTER(vmc_desc_struct)]; lib.qrgpu_vmc_desc_default.restype = None
     lib.qrgpu_vmc_setup.argtypes = [vp, ip, C.POINTER(vmc_desc_struct)]
@@ -246,9 +270,14 @@ class Context:
         self._chk(self._lib.qrgpu_wbc_run_batch(self._h, n, _dp(type_id), _dp(fb_state), _dp(wbc_cmd), _dp(prev_ori), _dp(tau),
                                                 _dp(qdes), _dp(status)))
 
-    def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None):
+    def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None, qdes=None):
+        """qdes [24][n]: desiredJPos / desiredJVel of the kinematic projection (K12); None skips that projection."""
         self._chk(self._lib.qrgpu_tick_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(fb_state),
-                                             _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(status)))
+                                             _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(qdes), _dp(status)))
+
+    def set_torque_epilogue(self, hip_comp=False, clip=False):
+        """K14 tail on the batched torques: +-0.9 N m abad compensation (qr_fsm_state_locomotion.cpp:141-151), +-23 N m clip (qr_safety_checker.cpp:48-66)."""
+        self._chk(self._lib.qrgpu_set_torque_epilogue(self._h, (EPILOGUE_HIP_COMP if hip_comp else 0) | (EPILOGUE_CLIP if clip else 0)))
 
     def vmc_setup_packed(self, type_id, cfg20, geom3):
         """cfg20 = workload.vmc_cfg(): mass, inertia[9], acc_weight[6], reg_weight, friction, fmin_ratio, fmax_ratio; geom3 = hip/upper/lower length."""
@@ -345,6 +374,23 @@ class Context:
 
     def sync(self):
         self._chk(self._lib.qrgpu_sync(self._h))
+
+    # -- multi-GPU: the all-gather of torques over RCCL (qrgpu_comm.hip) ---------------------------------------------
+    def comm_init_rank(self, id_blob, nranks, rank):
+        assert len(id_blob) == COMM_ID_BYTES
+        self._chk(self._lib.qrgpu_comm_init_rank(self._h, bytes(id_blob), int(nranks), int(rank)))
+
+    def comm_destroy(self):
+        self._chk(self._lib.qrgpu_comm_destroy(self._h))
+
+    def allgather_tau(self, tau, n_local, tau_all, slot=0, nccl_comm=None):
+        self._chk(self._lib.qrgpu_allgather_tau(self._h, _dp(nccl_comm), _dp(tau), int(n_local), _dp(tau_all), int(slot)))
+
+    def allgather_fence(self, slot=0):
+        self._chk(self._lib.qrgpu_allgather_fence(self._h, int(slot)))
+
+    def comm_sync(self):
+        self._chk(self._lib.qrgpu_comm_sync(self._h))
 
     def enable_timing(self, on=True):
         self._chk(self._lib.qrgpu_enable_timing(self._h, 1 if on else 0))

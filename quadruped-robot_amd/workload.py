@@ -87,58 +87,71 @@ def _foot_positions_base(r, q):
     return out
 
 
-def make_batch(n, horizon=10, robot="a1", seed=0xA1, frac_all_stance=0.05, frac_three_leg=0.05, excite=1.0):
-    """n robots of one type.  Returns a dict of float32 AoS arrays (see module docstring).
-
-    excite scales the tracking errors the MPC has to remove (roll/pitch, angular rate,
-    velocity mismatch, vertical velocity).  excite=1.0 is SURVEY.md 8d's full range, under
-    which a good share of the QPs need more than qpOASES' nWSR=100 working-set changes (the
-    reference then returns a non-optimal point); excite=0.3 keeps trot QPs
-    inside that cap and is the default of the bench workload."""
+def _draw_population(n, horizon, robot, seed, frac_all_stance, frac_three_leg, excite):
+    """Every random draw of one batch, in a fixed order (seeded batches are part of the tests' contract), as a dict of float64 arrays."""
     r = ROBOTS[robot]
     rng = np.random.default_rng(seed)
     U = rng.uniform
-    h = horizon
-    # base state
     e = float(excite)
-    rpy = np.stack([e * U(-0.15, 0.15, n), e * U(-0.15, 0.15, n), U(-np.pi, np.pi, n)], axis=1)
-    R = _rot_body_to_world(rpy)
-    quat = _quat_from_rpy(rpy)
-    pos = np.stack([U(-1, 1, n), U(-1, 1, n), 0.27 + U(-0.03, 0.03, n)], axis=1)
-    v_w = np.stack([U(-0.5, 0.5, n), U(-0.5, 0.5, n), e * U(-0.1, 0.1, n)], axis=1)
-    w_w = e * U(-0.5, 0.5, (n, 3))
+    v = dict(robot=robot, horizon=horizon, n=n, excite=e)
+    v["rpy"] = np.stack([e * U(-0.15, 0.15, n), e * U(-0.15, 0.15, n), U(-np.pi, np.pi, n)], axis=1)
+    v["pos"] = np.stack([U(-1, 1, n), U(-1, 1, n), 0.27 + U(-0.03, 0.03, n)], axis=1)
+    v["v_w"] = np.stack([U(-0.5, 0.5, n), U(-0.5, 0.5, n), e * U(-0.1, 0.1, n)], axis=1)
+    v["w_w"] = e * U(-0.5, 0.5, (n, 3))
     # joints: stand pose (0, 0.8+-0.2, -1.6+-0.3), abad U(-0.2,0.2)
-    q = np.empty((n, 12)); qd = U(-1, 1, (n, 12))
+    q = np.empty((n, 12)); v["qd"] = U(-1, 1, (n, 12))
     for leg in range(4):
         q[:, 3 * leg] = U(-0.2, 0.2, n)
         q[:, 3 * leg + 1] = 0.8 + U(-0.2, 0.2, n)
         q[:, 3 * leg + 2] = -1.6 + U(-0.3, 0.3, n)
+    v["q"] = q
+    v["phase0"] = U(0, 1, n)
+    kind = U(0, 1, n)
+    v["all_st"] = kind < frac_all_stance
+    v["three"] = (kind >= frac_all_stance) & (kind < frac_all_stance + frac_three_leg)
+    v["sw_leg"] = rng.integers(0, 4, n)
+    # command (UpdateMPC :361-376): at excite < 1 it is blended towards the current motion
+    R = _rot_body_to_world(v["rpy"])
+    vdes_b = np.stack([U(-0.5, 1.0, n), U(-0.3, 0.3, n), np.zeros(n)], axis=1)
+    v_b_now = np.einsum("nji,nj->ni", R, v["v_w"])
+    vdes_b[:, :2] = v_b_now[:, :2] + e * (vdes_b[:, :2] - v_b_now[:, :2])     # e=1: independent command
+    v["vdes_b"] = vdes_b
+    v["yaw_rate"] = v["w_w"][:, 2] + e * (U(-0.5, 0.5, n) - v["w_w"][:, 2])
+    v["d_yaw"] = U(-0.05, 0.05, n)
+    v["d_x0"] = U(-0.05, 0.05, n); v["d_y0"] = U(-0.05, 0.05, n)
+    v["d_height"] = U(-0.01, 0.01, n)
+    v["d_foot"] = U(-0.05, 0.05, (n, 4, 3))
+    v["v_foot"] = U(-0.5, 0.5, (n, 12))
+    v["a_foot"] = U(-2.0, 2.0, (n, 12))
+    v["_rng"] = rng
+    return v
+
+
+def _assemble(v):
+    """The tick's input arrays from a population's variables (deterministic)."""
+    r = ROBOTS[v["robot"]]
+    n, h = v["n"], v["horizon"]
+    rpy, pos, v_w, w_w, q, qd = v["rpy"], v["pos"], v["v_w"], v["w_w"], v["q"], v["qd"]
+    R = _rot_body_to_world(rpy)
+    quat = _quat_from_rpy(rpy)
     foot_b = _foot_positions_base(r, q)                                   # [n,4,3]
     r_w = np.einsum("nij,nlj->nli", R, foot_b - np.asarray(r["com_offset"]))   # R (foot - comOffset)
     # gait table: trot, duty 0.6, random phase; dPhase = 1/(numHorizonL*h), numHorizonL = 2  (:50,:284)
     duty = 0.6
-    phase0 = U(0, 1, n)
     offs = np.array([0.0, 0.5, 0.5, 0.0])
     dphase = 1.0 / (2 * h)
-    ph = (phase0[:, None, None] + offs[None, None, :] + dphase * np.arange(h)[None, :, None]) % 1.0
+    ph = (v["phase0"][:, None, None] + offs[None, None, :] + dphase * np.arange(h)[None, :, None]) % 1.0
     gait = (ph < duty).astype(np.float64)                                  # [n,h,4]
-    kind = U(0, 1, n)
-    all_st = kind < frac_all_stance
-    three = (kind >= frac_all_stance) & (kind < frac_all_stance + frac_three_leg)
-    gait[all_st] = 1.0
-    sw_leg = rng.integers(0, 4, n)
-    for i in np.nonzero(three)[0]:
+    gait[v["all_st"]] = 1.0
+    for i in np.nonzero(v["three"])[0]:
         gait[i] = 1.0
-        gait[i, :, sw_leg[i]] = 0.0
+        gait[i, :, v["sw_leg"][i]] = 0.0
     contact = gait[:, 0, :].copy()
     # reference trajectory (UpdateMPC :361-376)
-    vdes_b = np.stack([U(-0.5, 1.0, n), U(-0.3, 0.3, n), np.zeros(n)], axis=1)
-    v_b_now = np.einsum("nji,nj->ni", R, v_w)
-    vdes_b[:, :2] = v_b_now[:, :2] + e * (vdes_b[:, :2] - v_b_now[:, :2])     # e=1: independent command
-    vdes_w = np.einsum("nij,nj->ni", R, vdes_b)
-    yaw_rate = w_w[:, 2] + e * (U(-0.5, 0.5, n) - w_w[:, 2])
-    yaw_des = rpy[:, 2] + U(-0.05, 0.05, n)
-    x0 = pos[:, 0] + U(-0.05, 0.05, n); y0 = pos[:, 1] + U(-0.05, 0.05, n)
+    vdes_w = np.einsum("nij,nj->ni", R, v["vdes_b"])
+    yaw_rate = v["yaw_rate"]
+    yaw_des = rpy[:, 2] + v["d_yaw"]
+    x0 = pos[:, 0] + v["d_x0"]; y0 = pos[:, 1] + v["d_y0"]
     height = np.full(n, 0.27)
     traj = np.zeros((n, h, 12))
     traj[:, :, 5] = height[:, None]
@@ -155,22 +168,74 @@ def make_batch(n, horizon=10, robot="a1", seed=0xA1, frac_all_stance=0.05, frac_
     fb_state = np.concatenate([quat, pos, w_b, v_b, q, qd], axis=1)
     # WBC command
     foot_w = pos[:, None, :] + np.einsum("nij,nlj->nli", R, foot_b)
-    pBody = np.stack([x0, y0, height + U(-0.01, 0.01, n)], axis=1)
+    pBody = np.stack([x0, y0, height + v["d_height"]], axis=1)
     cmd = np.zeros((n, 67))
     cmd[:, 0:3] = pBody
     cmd[:, 3:6] = np.stack([vdes_w[:, 0], vdes_w[:, 1], np.zeros(n)], axis=1)
     cmd[:, 9:12] = np.stack([np.zeros(n), np.zeros(n), yaw_des], axis=1)
     cmd[:, 12:15] = np.stack([np.zeros(n), np.zeros(n), yaw_rate], axis=1)
-    cmd[:, 15:27] = (foot_w + U(-0.05, 0.05, (n, 4, 3))).reshape(n, 12)
-    cmd[:, 27:39] = U(-0.5, 0.5, (n, 12))
-    cmd[:, 39:51] = U(-2.0, 2.0, (n, 12))
+    cmd[:, 15:27] = (foot_w + v["d_foot"]).reshape(n, 12)
+    cmd[:, 27:39] = v["v_foot"]
+    cmd[:, 39:51] = v["a_foot"]
     nst = np.maximum(contact.sum(axis=1), 1.0)
     cmd[:, 51:63] = (contact[:, :, None] * np.array([0.0, 0.0, 1.0]) * (r["mass"] * 9.81 / nst)[:, None, None]).reshape(n, 12)
     cmd[:, 63:67] = contact
-    return dict(robot=robot, horizon=h, n=n,
+    return dict(robot=v["robot"], horizon=h, n=n,
                 mpc_state=mpc_state.astype(f32), traj=traj.reshape(n, 12 * h).astype(f32),
                 gait=gait.reshape(n, 4 * h).astype(f32), fb_state=fb_state.astype(f32), wbc_cmd=cmd.astype(f32),
                 prev_ori_vel=np.zeros((n, 3), f32))
+
+
+def make_batch(n, horizon=10, robot="a1", seed=0xA1, frac_all_stance=0.05, frac_three_leg=0.05, excite=1.0):
+    """n robots of one type.  Returns a dict of float32 AoS arrays (see module docstring).
+
+    excite scales the tracking errors the MPC has to remove (roll/pitch, angular rate,
+    velocity mismatch, vertical velocity).  excite=1.0 is SURVEY.md 8d's full range, under
+    which a good share of the QPs need more than qpOASES' nWSR=100 working-set changes (the
+    reference then returns a non-optimal point)."""
+    return _assemble(_draw_population(n, horizon, robot, seed, frac_all_stance, frac_three_leg, excite))
+
+
+def make_batch_sequence(n, horizon=10, robot="a1", seed=0xA1, steps=8, dt=0.03, frac_all_stance=0.05, frac_three_leg=0.05, excite=1.0):
+    """`steps` consecutive batches of the SAME n robots, dt seconds apart (0.03 s = the reference's MPC cadence of 15 control ticks,
+    qr_mpc_stance_leg_controller.cpp:342): batch 0 is make_batch(seed); after that every robot moves on -- position and attitude integrate
+    the velocities, joint angles their rates, velocities take a bounded random step (<= 0.6 m/s^2, 0.6 rad/s^2), everything is reflected
+    back into SURVEY.md 8d's ranges, the gait phase advances by dt / 0.8333 s (stance 0.5 s at duty 0.6) so that the contact table scrolls,
+    and the commands stay.  Temporally coherent, never the same batch twice.  Returns a list of batch dicts."""
+    v = _draw_population(n, horizon, robot, seed, frac_all_stance, frac_three_leg, excite)
+    rng = v.pop("_rng")
+    e = v["excite"]
+    out = [_assemble(v)]
+
+    def reflect(x, rate, lo, hi):
+        over, under = x > hi, x < lo
+        x = np.where(over, 2 * hi - x, np.where(under, 2 * lo - x, x))
+        if rate is not None:
+            rate = np.where(over | under, -rate, rate)
+        return x, rate
+
+    for _ in range(1, steps):
+        v = dict(v)
+        v["v_w"] = v["v_w"] + rng.uniform(-0.018, 0.018, (n, 3)) * np.array([1.0, 1.0, e * 0.2])
+        v["w_w"] = v["w_w"] + e * rng.uniform(-0.018, 0.018, (n, 3))
+        for c, lim in ((0, 0.5), (1, 0.5), (2, e * 0.1 + 1e-9)):
+            v["v_w"][:, c], _ = reflect(v["v_w"][:, c], None, -lim, lim)
+        v["w_w"], _ = reflect(v["w_w"], None, -e * 0.5 - 1e-9, e * 0.5 + 1e-9)
+        v["pos"] = v["pos"] + dt * v["v_w"]
+        v["pos"][:, 2], _ = reflect(v["pos"][:, 2], None, 0.24, 0.30)
+        rpy = v["rpy"] + dt * v["w_w"]
+        w = v["w_w"].copy()
+        for c in (0, 1):
+            rpy[:, c], w[:, c] = reflect(rpy[:, c], w[:, c], -e * 0.15 - 1e-9, e * 0.15 + 1e-9)
+        rpy[:, 2] = (rpy[:, 2] + np.pi) % (2 * np.pi) - np.pi
+        v["rpy"], v["w_w"] = rpy, w
+        q, qd = v["q"] + dt * v["qd"], v["qd"].copy()
+        for j, (mid, half) in enumerate(((0.0, 0.2), (0.8, 0.2), (-1.6, 0.3))):
+            q[:, j::3], qd[:, j::3] = reflect(q[:, j::3], qd[:, j::3], mid - half, mid + half)
+        v["q"], v["qd"] = q, qd
+        v["phase0"] = (v["phase0"] + dt / (0.5 / 0.6)) % 1.0
+        out.append(_assemble(v))
+    return out
 
 
 def to_soa(a):

@@ -72,18 +72,21 @@ def run_fb_debug(ctx, pkg, b, type_id=None):
                 Jcdqd=o[:, 576:588].reshape(n, 4, 3), pGC=o[:, 588:600].reshape(n, 4, 3), vGC=o[:, 600:612].reshape(n, 4, 3))
 
 
-def run_tick(ctx, pkg, b, type_id=None):
+def run_tick(ctx, pkg, b, type_id=None, want_qdes=False):
     n, h = b["n"], b["horizon"]
     S = pkg.to_soa
     d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])),
              gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), fb=ctx.alloc((37, n)).upload(S(b["fb_state"])),
              cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
-             force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
+             force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32), qdes=ctx.alloc((24, n)))
     tid = ctx.alloc((n,), np.int32).upload(type_id) if type_id is not None else None
-    ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"], tid)
+    ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"], tid,
+                   qdes=d["qdes"] if want_qdes else None)
     ctx.sync()
     out = dict(force=d["force"].download().T.copy(), tau=d["tau"].download().T.copy(), status=d["status"].download(),
                prev=d["prev"].download().T.copy())
+    if want_qdes:
+        out["qdes"] = d["qdes"].download().T.copy()
     for v in d.values():
         v.free()
     if tid is not None:

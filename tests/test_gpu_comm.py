@@ -1,0 +1,48 @@
+"""GPU: the native RCCL all-gather of the C ABI (qrgpu_comm_* / qrgpu_allgather_tau), single rank (the box has one GPU): communicator
+from an id blob, asynchronous gather on the context's own stream behind the tick, double-buffer fence.  N > 1 is the same code with
+nranks > 1; its host side (id exchange, shard arithmetic, padded split) runs as a world-size-2 gloo test in test_workload_shard.py."""
+import numpy as np
+import pytest
+
+import gpu_helpers as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allgather_tau_single_rank(pkg, oracle):
+    ctx = pkg.Context(device_id=0, max_batch=256, horizon_max=16)
+    try:
+        G.setup_a1(ctx, pkg, 10)
+        blob = pkg.qrgpu.comm_unique_id()
+        assert len(blob) == 128
+        ctx.comm_init_rank(blob, 1, 0)
+        with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
+            ctx.comm_init_rank(blob, 1, 0)                       # one communicator per context
+        n, h = 256, 10
+        b = pkg.make_batch(n, h, "a1", seed=31)
+        S = pkg.to_soa
+        d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])),
+                 gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), fb=ctx.alloc((37, n)).upload(S(b["fb_state"])),
+                 cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
+                 force=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
+        tau = [ctx.alloc((12, n)), ctx.alloc((12, n))]
+        tau_all = ctx.alloc((1, 12, n)).upload(np.full((1, 12, n), np.nan, np.float32))
+        # three ticks, gathers overlapped: tick i+1 is queued while gather i runs; a buffer is fenced before it is overwritten
+        for i in range(3):
+            slot = i & 1
+            ctx.allgather_fence(slot)
+            d["prev"].upload(S(b["prev_ori_vel"]))
+            ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], tau[slot], d["status"])
+            ctx.allgather_tau(tau[slot], n, tau_all, slot)
+        ctx.comm_sync()
+        ctx.sync()
+        got = tau_all.download()[0]
+        assert np.array_equal(got, tau[0].download())
+        _, tau_o, st, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"],
+                                               b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
+        assert np.all(np.abs(got.T - tau_o) <= G.tau_tol(tau_o, 1e-4))
+        ctx.comm_destroy()
+        with pytest.raises(pkg.QrgpuError, match="NOT_SETUP"):
+            ctx.allgather_tau(tau[0], n, tau_all, 0)
+    finally:
+        ctx.close()

@@ -171,3 +171,72 @@ def test_full_tick_h16_mixed_a1_lite3(gpu_ctx, pkg, oracle):
                 tau[3 * l:3 * l + 3] = w["tau"][3 * l:3 * l + 3]
         assert np.all(np.abs(out["tau"][i] - tau) <= G.tau_tol(tau, 1e-4))
     G.setup_a1(gpu_ctx, pkg, 10)
+
+
+def test_full_tick_1024_with_projection_and_motor_tail(gpu_ctx, pkg, oracle):
+    """BASELINE.json configs[2] at full size: 1024 A1 robots, h = 10, the whole tick of SURVEY 8(d) -- K12 (kinematic projection) on and
+    the K14 motor tail (abad +-0.9 N m, +-23 N m clip) applied -- every robot against the threaded oracle."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(1024, 10, "a1", seed=0xA1 + 2)
+    f, tau, st, sec, prev, qdes = oracle.tick_batch(1, pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
+                                                    b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=8,
+                                                    epilogue=3, want_qdes=True)
+    gpu_ctx.set_torque_epilogue(hip_comp=True, clip=True)
+    try:
+        out = G.run_tick(gpu_ctx, pkg, b, want_qdes=True)
+    finally:
+        gpu_ctx.set_torque_epilogue(False, False)
+    assert np.all((out["status"] & 0xff) == 0) and np.all(st == 0)
+    assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
+    assert np.abs(out["tau"]).max() <= 23.0
+    # the compensation shows exactly on the abad motors of swing legs (their MPC torque is J^T 0 = 0)
+    swing = b["wbc_cmd"][:, 63:67] == 0
+    comp = np.array([-0.9, 0.9, -0.9, 0.9], np.float32)
+    assert np.array_equal(out["tau"][:, 0::3][swing], np.broadcast_to(comp, swing.shape)[swing])
+    # K12 outputs: the fp32 oracle's pseudo-inverses against the kernel's fp64 ones
+    assert np.abs(out["qdes"] - qdes).max() <= 2e-3
+    assert np.array_equal(out["prev"], prev)
+
+
+def test_tick_without_tail_is_unchanged_by_projection(gpu_ctx, pkg):
+    """K12's outputs do not enter the torque: the tick with and without d_qdes returns the same bits."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(64, 10, "a1", seed=77)
+    a = G.run_tick(gpu_ctx, pkg, b, want_qdes=False)
+    c = G.run_tick(gpu_ctx, pkg, b, want_qdes=True)
+    assert np.array_equal(a["tau"], c["tau"]) and np.array_equal(a["force"], c["force"])
+
+
+def test_mpc_only_motor_tail(gpu_ctx, pkg, oracle):
+    """qrgpu_mpc_solve_batch with the K14 tail: +-0.9 on every abad motor (no WBC overwrite on an MPC tick), then the clip."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(64, 10, "a1", seed=78)
+    f, tau, st, sec, prev = oracle.tick_batch(0, pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
+                                              b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), epilogue=3)
+    gpu_ctx.set_torque_epilogue(True, True)
+    try:
+        out = G.run_mpc(gpu_ctx, pkg, b)
+    finally:
+        gpu_ctx.set_torque_epilogue(False, False)
+    assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
+    raw = G.run_mpc(gpu_ctx, pkg, b)["tau"]
+    assert np.abs((out["tau"] - raw)[:, 1::3]).max() == 0.0 or np.abs(raw).max() > 23.0
+
+
+def test_unknown_type_is_flagged(gpu_ctx, pkg):
+    """A type id outside the table or never set up must not read garbage constants: the robot carries QRGPU_ST_BAD_TYPE."""
+    G.setup_a1(gpu_ctx, pkg, 10)
+    b = pkg.make_batch(8, 10, "a1", seed=79)
+    tid = np.array([0, 3, 0, 7, -1, 0, 2, 0], np.int32)            # types 2, 3 were never set up on this context's horizon; 7, -1 do not exist
+    ctx2 = pkg.Context(device_id=0, max_batch=8, horizon_max=16)
+    try:
+        G.setup_a1(ctx2, pkg, 10)
+        out = G.run_tick(ctx2, pkg, b, type_id=tid)
+    finally:
+        ctx2.close()
+    bad = (out["status"] & 0x01000000) != 0
+    assert np.array_equal(bad, tid != 0)
+    ref = G.run_tick(gpu_ctx, pkg, b)
+    assert np.array_equal(out["tau"][~bad], ref["tau"][~bad])
+    assert np.all(np.isfinite(out["tau"]))

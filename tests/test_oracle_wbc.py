@@ -89,3 +89,22 @@ def test_golden_wbc(oracle):
             assert np.abs(fb[k] - r[k]).max() <= 1e-10
         active += int(r["n_active"][0]) > 0
     assert active >= 2        # the fixtures exercise binding friction rows
+
+
+def test_motor_tail_of_the_tick(oracle, pkg):
+    """K14 tail as the locomotion state applies it (qr_fsm_state_locomotion.cpp:131-156, qr_safety_checker.cpp:48-66): +-0.9 N m on every abad
+    motor before the WBC overwrites its stance legs, then the +-23 N m clip."""
+    b = pkg.make_batch(32, 10, "a1", seed=5)
+    args = (pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"])
+    _, tau0, st, _, _ = oracle.tick_batch(1, *args, b["prev_ori_vel"].copy())
+    _, tau3, _, _, _ = oracle.tick_batch(1, *args, b["prev_ori_vel"].copy(), epilogue=3)
+    _, tau1, _, _, _ = oracle.tick_batch(1, *args, b["prev_ori_vel"].copy(), epilogue=1)
+    stance = np.repeat(b["wbc_cmd"][:, 63:67] != 0, 3, axis=1)
+    comp = np.tile(np.array([-0.9, 0, 0, 0.9, 0, 0], np.float32), 2)
+    expect = np.where(stance, tau0, (tau0.astype(np.float64) + comp).astype(np.float32))
+    assert np.array_equal(tau1, expect)
+    assert np.array_equal(tau3, np.clip(expect, -23, 23))
+    # MPC-only tick: nothing overwrites, the compensation is on every leg
+    _, m0, _, _, _ = oracle.tick_batch(0, *args, b["prev_ori_vel"].copy())
+    _, m1, _, _, _ = oracle.tick_batch(0, *args, b["prev_ori_vel"].copy(), epilogue=1)
+    assert np.array_equal(m1, (m0.astype(np.float64) + comp).astype(np.float32))

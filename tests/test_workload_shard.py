@@ -56,6 +56,14 @@ def _gloo_worker(rank, world, port, n_total, q):
     full = pkg.shard.allgather_torques(tau_local, n_total)
     expect = torch.arange(12, dtype=torch.float32)[:, None] * 100 + torch.arange(n_total, dtype=torch.float32)[None, :]
     ok = bool(torch.equal(full, expect))
+    # the C-ABI path's host side: rank 0's communicator id reaches every rank, and the padded rank-major gather result splits back
+    blob = pkg.shard.exchange_comm_id(rank, lambda: bytes(range(128)))
+    ok = ok and blob == bytes(range(128))
+    nmax = max(pkg.shard.shard_sizes(n_total, world))
+    pad = torch.zeros((12, nmax)); pad[:, :hi - lo] = tau_local
+    parts = [torch.zeros((12, nmax)) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    ok = ok and bool(torch.equal(pkg.shard.split_gathered(torch.stack(parts), n_total, world), expect))
     t = torch.tensor([1.0 + rank]); dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the bench's max-over-ranks timing reduction
     q.put((rank, ok, float(t.item())))
     dist.barrier()
