@@ -26,8 +26,11 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 def mpc_cases():
     rows = []
+    # (the first five groups are round 1's 30 rows, unchanged; the h = 16 / full-range groups after them include rows on which the
+    # reference's qpOASES runs into its nWSR = 100 cap: qpoases_as_called_nwsr[0] == 100 or init_rc != 0 -- kept, and marked)
     for robot, h, n, seed, excite in (("a1", 10, 12, 1001, 1.0), ("a1", 10, 6, 1002, 0.3), ("a1", 5, 4, 1003, 1.0),
-                                      ("a1", 16, 4, 1004, 0.3), ("lite3", 10, 4, 1005, 1.0)):
+                                      ("a1", 16, 4, 1004, 0.3), ("lite3", 10, 4, 1005, 1.0),
+                                      ("a1", 16, 14, 1006, 1.0), ("lite3", 16, 6, 1007, 1.0), ("a1", 5, 4, 1008, 0.3), ("a1", 10, 8, 1009, 1.0)):
         b = W.make_batch(n, h, robot, seed=seed, excite=excite)
         cfg = W.mpc_cfg(robot)
         A = O.mpc_constraint_matrix(h)
@@ -40,7 +43,10 @@ def mpc_cases():
             x_avg, info_avg = O.ref_qpoases_mpc(0.5 * (Hd + Hd.T), gd, A, np.zeros(20 * h), ub, nWSR=2000)   # converged, symmetric data
             x_t, info_t = O.ref_qpoases_mpc(Hd.T.copy(), gd, A, np.zeros(20 * h), ub, nWSR=2000)
             assert info_avg["init_rc"] == 0
-            tau = O.mpc_force_to_torque(W.model_desc(robot)[:3], b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], u[:12])
+            geom = W.model_desc(robot)[:3]
+            tau = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], u[:12])
+            tau_called = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], x_ref[:12])
+            tau_t = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], x_t[:12])
             rows.append(dict(robot=robot, h=h, cfg=cfg, mpc_state=b["mpc_state"][i], traj=b["traj"][i], gait=b["gait"][i],
                              q=b["fb_state"][i, 13:25], quat=b["fb_state"][i, 0:4],
                              g=g, H_checksum=np.array([H.astype(np.float64).sum(), np.abs(H.astype(np.float64)).sum(), np.trace(Hd)]),
@@ -48,7 +54,8 @@ def mpc_cases():
                              f_oracle=u[:12].copy(), u_oracle_norm=np.array([np.linalg.norm(u)]),
                              f_qpoases_as_called=x_ref[:12].copy(), qpoases_as_called_nwsr=np.array([info["nWSR"], info["init_rc"]]),
                              f_qpoases_sym=x_avg[:12].copy(), u_qpoases_sym=x_avg.copy(), u_oracle=u.copy(),
-                             f_qpoases_transposed=x_t[:12].copy(), tau_oracle=tau, n_active=np.array([st["n_active"]])))
+                             f_qpoases_transposed=x_t[:12].copy(), tau_oracle=tau, n_active=np.array([st["n_active"]]),
+                             tau_qpoases_as_called=tau_called, tau_qpoases_transposed=tau_t, excite=np.array([excite])))
     return rows
 
 
@@ -157,9 +164,67 @@ def save(name, rows):
     print(name, len(rows), "cases", os.path.getsize(os.path.join(OUT, name)) // 1024, "KiB")
 
 
+def parity_table(rows):
+    """Worst deviation of the oracle (= the kernel to 2e-6) from the reference's solver exactly as the reference calls it, per horizon,
+    over the rows on which that call converged; beside it the reference's own H <-> H^T ambiguity on the same rows.  -> dict, also
+    written to parity_as_called.json (the table of DESIGN.md 2)."""
+    import json
+    tab = {}
+    for r in rows:
+        h = int(r["h"])
+        t = tab.setdefault(h, dict(rows=0, converged=0, nwsr_cap_or_failed=0, max_rel_force=0.0, max_rel_torque=0.0, ambiguity_rel_force=0.0,
+                                   ambiguity_rel_torque=0.0, rows_above_1e_4_torque=0))
+        t["rows"] += 1
+        nwsr, rc = int(r["qpoases_as_called_nwsr"][0]), int(r["qpoases_as_called_nwsr"][1])
+        if rc != 0 or nwsr >= 100:
+            t["nwsr_cap_or_failed"] += 1
+            continue
+        t["converged"] += 1
+        fs = max(1.0, np.abs(r["f_qpoases_as_called"]).max())
+        ef = np.abs(r["f_oracle"] - r["f_qpoases_as_called"]).max() / fs
+        et = (np.abs(r["tau_oracle"] - r["tau_qpoases_as_called"]) / np.maximum(1.0, np.abs(r["tau_qpoases_as_called"]))).max()
+        af = np.abs(r["f_qpoases_transposed"] - r["f_qpoases_as_called"]).max() / fs
+        at = (np.abs(r["tau_qpoases_transposed"] - r["tau_qpoases_as_called"]) / np.maximum(1.0, np.abs(r["tau_qpoases_as_called"]))).max()
+        t["max_rel_force"] = max(t["max_rel_force"], float(ef)); t["max_rel_torque"] = max(t["max_rel_torque"], float(et))
+        t["ambiguity_rel_force"] = max(t["ambiguity_rel_force"], float(af)); t["ambiguity_rel_torque"] = max(t["ambiguity_rel_torque"], float(at))
+        t["rows_above_1e_4_torque"] += int(et > 1e-4)
+    out = {"h%d" % h: tab[h] for h in sorted(tab)}
+    json.dump(out, open(os.path.join(OUT, "parity_as_called.json"), "w"), indent=1)
+    return out
+
+
+def nwsr_cap_census(n=40):
+    """How often the reference's solve runs into its own nWSR = 100 cap on SURVEY.md 8d's input ranges: n seeded A1 robots per
+    horizon, qpOASES called exactly as qr_mpc_interface.cpp:428-438 does.  Written to nwsr_cap_census.json."""
+    import json
+    out = {}
+    for h in (10, 16):
+        b = W.make_batch(n, h, "a1", seed=0xA1 + 2, excite=1.0)
+        cfg = W.mpc_cfg("a1")
+        A = O.mpc_constraint_matrix(h)
+        hits, fails, nws = 0, 0, []
+        for i in range(n):
+            H, g, ub = O.mpc_assemble(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+            x, info = O.ref_qpoases_mpc(H.astype(np.float64), g.astype(np.float64), A, np.zeros(20 * h), ub, nWSR=100)
+            nws.append(info["nWSR"]); hits += int(info["nWSR"] >= 100 or info["init_rc"] != 0); fails += int(info["init_rc"] != 0)
+        out["h%d" % h] = dict(robots=n, seed=0xA1 + 2, excite=1.0, hit_cap_or_failed=hits, init_returned_error=fails,
+                             nwsr_median=float(np.median(nws)), nwsr_max=int(max(nws)))
+    json.dump(out, open(os.path.join(OUT, "nwsr_cap_census.json"), "w"), indent=1)
+    return out
+
+
 if __name__ == "__main__":
     assert O.ref() is not None, "oracle/_ref is required to generate fixtures"
-    save("mpc_golden.npz", mpc_cases())
+    if len(sys.argv) > 1 and sys.argv[1] == "mpc":          # only the MPC fixture and the artefacts derived from it
+        rows = mpc_cases()
+        save("mpc_golden.npz", rows)
+        print(parity_table(rows))
+        print(nwsr_cap_census())
+        sys.exit(0)
+    rows = mpc_cases()
+    save("mpc_golden.npz", rows)
+    parity_table(rows)
+    nwsr_cap_census()
     save("wbc_golden.npz", wbc_cases())
     vmc_golden()
     vmc_world_golden()

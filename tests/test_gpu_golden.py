@@ -31,6 +31,57 @@ def test_mpc_golden(gpu_ctx, pkg):
             assert np.all(np.abs(out["tau"][i] - r["tau_oracle"]) <= G.tau_tol(r["tau_oracle"], 1e-5))
 
 
+def test_mpc_vs_reference_solver_as_called(gpu_ctx, pkg):
+    """The HIP path against the reference's own solver call: qpOASES 3.2.0 compiled from the reference tree, fed the asymmetric fp32 H with
+    nWSR = 100 exactly as qr_mpc_interface.cpp:418-438 does (tests/golden/make_golden.py; rows on which that call runs into its nWSR cap
+    or fails are recorded and skipped here).  The reference's answer moves when it is handed H^T instead of the (nominally symmetric) H;
+    the stated QP depends on H only through (H + H^T)/2, and the kernel's answer must be
+      * within that ambiguity of the as-called answer:  |f_gpu - f(H)| <= 0.55 |f(H^T) - f(H)| (+ 1e-5 of the force scale), same in torque;
+      * the MIDPOINT of the reference's two answers to 1e-5 relative force / 1.5e-4 relative torque;
+      * per horizon no further from the as-called answer than the committed table tests/golden/parity_as_called.json:
+        3.1e-4 (h = 10) and 1.2e-3 (h = 16) relative force."""
+    import json, os
+    rows = golden_io.load("mpc_golden.npz")
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_as_called.json")))
+    groups = {}
+    for r in rows:
+        groups.setdefault((str(r["robot"]), int(r["h"])), []).append(r)
+    worst = {}
+    n_checked = n_cap = 0
+    for (robot, h), rs in groups.items():
+        gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg(robot), h)
+        gpu_ctx.wbc_setup_packed(0, pkg.model_desc(robot))
+        n = len(rs)
+        fb = np.zeros((n, 37), np.float32)
+        fb[:, 0:4] = [r["quat"] for r in rs]; fb[:, 13:25] = [r["q"] for r in rs]
+        b = dict(n=n, horizon=h, mpc_state=np.stack([r["mpc_state"] for r in rs]), traj=np.stack([r["traj"] for r in rs]),
+                 gait=np.stack([r["gait"] for r in rs]), fb_state=fb)
+        out = G.run_mpc(gpu_ctx, pkg, b)
+        assert np.all((out["status"] & 0xff) == 0), (robot, h)
+        for i, r in enumerate(rs):
+            nwsr, rc = int(r["qpoases_as_called_nwsr"][0]), int(r["qpoases_as_called_nwsr"][1])
+            if rc != 0 or nwsr >= 100:
+                n_cap += 1                  # the reference returned a non-optimal point (SURVEY.md 5): nothing to be close to
+                continue
+            n_checked += 1
+            f, fc, ft = out["force"][i].astype(np.float64), r["f_qpoases_as_called"], r["f_qpoases_transposed"]
+            tau, tc, tt = out["tau"][i].astype(np.float64), r["tau_qpoases_as_called"].astype(np.float64), r["tau_qpoases_transposed"].astype(np.float64)
+            fs = max(1.0, np.abs(fc).max())
+            ts = np.maximum(1.0, np.abs(tc))
+            ef, af = np.abs(f - fc).max(), np.abs(ft - fc).max()
+            assert ef <= 0.55 * af + 1e-5 * fs, (robot, h, i, ef, af)
+            assert np.all(np.abs(tau - tc) <= 0.55 * np.abs(tt - tc).max() + 1.5e-4 * ts), (robot, h, i)
+            assert np.abs(f - 0.5 * (fc + ft)).max() <= 1e-5 * fs, (robot, h, i, np.abs(f - 0.5 * (fc + ft)).max() / fs)
+            assert np.all(np.abs(tau - 0.5 * (tc + tt)) <= 1.5e-4 * ts), (robot, h, i)
+            w = worst.setdefault(h, [0.0, 0.0])
+            w[0] = max(w[0], ef / fs); w[1] = max(w[1], (np.abs(tau - tc) / ts).max())
+    assert n_checked >= 50 and n_cap >= 1
+    for h, (wf, wt) in worst.items():
+        t = table["h%d" % h]
+        assert wf <= 1.02 * t["max_rel_force"] + 2e-6 and wt <= 1.02 * t["max_rel_torque"] + 2e-5, (h, wf, wt, t)
+    G.setup_a1(gpu_ctx, pkg, 10)
+
+
 def test_wbc_golden(gpu_ctx, pkg):
     rows = golden_io.load("wbc_golden.npz")
     for robot in ("a1", "lite3"):
