@@ -145,6 +145,13 @@ int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
  * depend on it; a batch whose robots were reshuffled between calls merely loses the speed-up.  Turning it on or off
  * forgets the history. */
 int  qrgpu_set_lpt_schedule(qrgpu_ctx *ctx, int on);
+/* Warm start of the batched MPC solve (default on): robot slot i's final working set in one call (by leg-step, realigned to the scrolling
+ * contact table) is where its solve starts in the next call with the same n -- the equality-constrained problem on that set is solved in
+ * one block instead of adding its rows one active-set iteration at a time; rows that no longer belong leave, missing ones are added.  The
+ * reference cold-starts qpOASES at every solve (QProblem::init, qr_mpc_interface.cpp:430); the QP has one optimum, so results agree
+ * with a cold start to the solver's tolerance (1e-9 relative) -- not bit for bit: switch it off where run-to-run bit identity across a
+ * changing history matters.  Turning it on or off forgets what is stored. */
+int  qrgpu_set_warm_start(qrgpu_ctx *ctx, int on);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
  * Hessian at h = 10 leaves room for 56 rows): they are re-solved by the same kernel with the whole CU's LDS in a second, normally

@@ -7,6 +7,7 @@ namespace qrgpu {
 
 #define QR_QH 96                  // hard cap on the MPC working-set size (rows of S^-1 held in LDS)
 #define QR_MAX_TYPES 4
+#define QR_WARM_STRIDE 80
 
 // status bits (mirror include/qrgpu.h)
 #define QRGPU_ST_MPC_MAXITER_D  0x1
@@ -63,6 +64,9 @@ struct MpcLaunch {
     // scratch instead ([robot][tri(QR_QH)] doubles, L2-resident), MAXB = 9 variants only
     double *sinv_spill;
     int no_wcache;              // diagnostic (QRGPU_NO_WCACHE=1): always take the z = w - M (N_A r) form
+    // warm start (speed only): [robot][QR_WARM_STRIDE] bytes: the 6-bit active-row mask of each of the <= 64 original leg-steps at the end of the
+    // slot's last solve, the contact-table bits it belonged to (8 bytes at offset 64), the horizon as a validity tag in the last byte; or null
+    unsigned char *warm;
     int type_ready;             // bit t: type t was set up (robots naming any other type are flagged QRGPU_ST_BAD_TYPE)
     int epilogue;               // QRGPU_EPILOGUE_* bits applied to g_tau (MPC-only batches; 0 inside the fused tick)
 };

@@ -283,40 +283,30 @@ __global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__r
     lpt_order_chunk(blockIdx.x, n, cost, order, hist);
 }
 
-// TAG only names the instance: the rescue launch runs <4, true, 1>, so that a kernel trace keeps it apart from the main launches <4, true, 0>
-template <int MAXB, bool MULTI, int TAG>
-__global__ __launch_bounds__(QR_MPC_THREADS, (MAXB <= 4 ? 2 : 1))
-void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__restrict__ g_state,
-                   const float *__restrict__ g_traj, const float *__restrict__ g_gait, const float *__restrict__ g_q,
-                   float *__restrict__ g_force, float *__restrict__ g_tau, int *__restrict__ g_status,
-                   float *__restrict__ dbgH, float *__restrict__ dbgG, float *__restrict__ g_force_wbc, int force_stride,
-                   long long *__restrict__ dbgT)
+// Global-memory arguments of one MPC launch (SoA, [field][robot]; see include/qrgpu.h)
+struct MpcIO {
+    const int *type_id;
+    const float *g_state, *g_traj, *g_gait, *g_q;
+    float *g_force, *g_tau;
+    int *g_status;
+    float *dbgH, *dbgG, *g_force_wbc;
+    int force_stride;
+    long long *dbgT;
+};
+
+// One robot's MPC tick by one 256-thread workgroup.  MAXB: 3x3 blocks a thread keeps in registers during the sweep (MAXB * 256 >= number of
+// stance leg-step pairs).  BIG: working-set positions 64 .. 95 live in a second set of per-lane registers.  Every wave returns from here
+// (the workers at their exit command, wave 0 after the outputs), so a workgroup may solve several robots in a row (list mode below).
+template <int MAXB, bool BIG>
+__device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO &io, const int rid, double *smem)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int n = P.n;
-    int rid;
-    if (P.rescue_mode) {
-        if (P.lpt_order_out && blockIdx.x < 8) {       // the histogram borrows the head of the dynamic LDS before the solve carves it
-            extern __shared__ double smem_head[];
-            lpt_order_chunk(blockIdx.x, n, P.lpt_cost_in, P.lpt_order_out, (int *)smem_head);
-            __syncthreads();
-        }
-        // rescue pass: workgroup b re-solves the b-th robot the main pass could not hold
-        int cnt = P.rescue_count[P.rescue_parity];
-        cnt = cnt < n ? cnt : n;
-        if ((int)blockIdx.x >= cnt) return;
-        rid = P.rescue_list[blockIdx.x];
-    } else {
-        const int slot = xcd_robot_index(blockIdx.x, n);
-        if (slot < 0) return;
-        rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
-        if (P.rescue_count && blockIdx.x == 0 && tid == 0) P.rescue_count[P.rescue_parity ^ 1] = 0;     // the next call's counter
-    }
     const long long t_begin = P.cost ? clock64() : 0;
     // a type id outside the table, or one that was never set up, would read garbage (mass 0 => 1/mass = inf): the robot is solved with the
     // first valid type's constants and carries QRGPU_ST_BAD_TYPE
-    int tyid = type_id ? type_id[rid] : 0;
+    int tyid = io.type_id ? io.type_id[rid] : 0;
     const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((P.type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
     if (bad_type) tyid = __builtin_ctz(P.type_ready | (1 << QR_MAX_TYPES));
     const MpcType &C = P.type[tyid & (QR_MAX_TYPES - 1)];
@@ -324,14 +314,10 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int NV = 12 * h, NL = 4 * h;
 
     // ---------------- LDS carve (must match mpc_lds_fixed_bytes) ----------------
-    extern __shared__ double smem[];
     double *gl = smem;                 // [NV] gradient (free variables, leg-step major)
-    double *wl = gl + NV;              // single-wave: [NV] staging of w          | four-wave: xz[4][NV] partial x / z exchange
-    double *yl = wl + NV;              // single-wave: [NV] staging of y = N r
-    double *rl = yl + NV;              // single-wave: [QH] staging of r
-    double *xz = gl + NV;
-    double *xr = xz + 4 * NV;          // four-wave: xr[4][64] partial r exchange
-    double *fmk = MULTI ? xr + 4 * 64 : rl + QR_QH;   // [NL] f_z upper bound per free leg-step
+    double *xz = gl + NV;              // xz[4][NV] partial x / z exchange (slot 0 carries d of the iteration)
+    double *xr = xz + 4 * NV;          // xr[4][64] partial r exchange
+    double *fmk = xr + 4 * 64;         // [NL] f_z upper bound per free leg-step
     float *sT = (float *)(fmk + NL);   // [4][3][3]
     float *sU = sT + 36;               // [4][3][3]
     float *sSt = sU + 36;              // [28]
@@ -340,22 +326,22 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     float *sV = sGait + NL;            // [13h]
     float *sJ = (MAXB <= 4) ? sV + 13 * h : nullptr;   // [12][3] columns of the leg Jacobians (the torque map of phase 6, computed while the data loads; h <= 11)
     int *sLs = (int *)(sV + 13 * h + (MAXB <= 4 ? 36 : 0));   // [NL] free leg-step -> original leg-step
-    int *sAct = sLs + NL;              // [QH] active constraint ids (6*k + t)
-    short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> position in sAct, or -1
+    int *sAct = sLs + NL;              // [QH] (unused since the single-wave loop went; keeps the carve of mpc_lds_fixed_bytes)
+    short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> working-set position, or -1
     int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [16]: [0] free leg-steps, [8..13] control block
     // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
-    double *Mb = smem + (int)(mpc_lds_fixed_bytes(h, MULTI) / 8);   // block-packed M; the sweep panels live here first
+    double *Mb = smem + (int)(mpc_lds_fixed_bytes(h, true) / 8);   // block-packed M; the sweep panels live here first
 
-#ifdef QR_TRACE
+#if defined(QR_TRACE) || defined(QR_DIAG_REFAC)
 #define QR_TS(i) do { } while (0)
 #else
-#define QR_TS(i) do { if (dbgT && tid == 0) dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
+#define QR_TS(i) do { if (io.dbgT && tid == 0) io.dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
 #endif
     QR_TS(0);
     // ---------------- phase 0: inputs ----------------
-    if (tid < 28) sSt[tid] = g_state[(size_t)tid * n + rid];
-    for (int i = tid; i < NV; i += QR_MPC_THREADS) sTraj[i] = g_traj[(size_t)i * n + rid];
-    for (int i = tid; i < NL; i += QR_MPC_THREADS) sGait[i] = g_gait[(size_t)i * n + rid];
+    if (tid < 28) sSt[tid] = io.g_state[(size_t)tid * n + rid];
+    for (int i = tid; i < NV; i += QR_MPC_THREADS) sTraj[i] = io.g_traj[(size_t)i * n + rid];
+    for (int i = tid; i < NL; i += QR_MPC_THREADS) sGait[i] = io.g_gait[(size_t)i * n + rid];
     __syncthreads();
 
     // ---------------- phase 1: SRBD terms (every thread keeps R in registers) ----------------
@@ -424,7 +410,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             sLs[pos] = tid;
             fmk[pos] = (double)(sGait[tid] * C.fmax);
         }
-        if (tid == 0) sMisc[0] = __popcll(mask);
+        if (tid == 0) { sMisc[0] = __popcll(mask); sMisc[2] = (int)(unsigned)mask; sMisc[3] = (int)(unsigned)(mask >> 32); }
     }
     // v = Aqp x0 - X_d, one horizon step per thread (wave 1 so it overlaps the above)
     if (tid >= 64 && tid < 64 + h) {
@@ -458,37 +444,35 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     const int ns = 3 * nls;
     const int npairs = tri(nls);
     double *Sinv = Mb + npairs * 9;
+    // BIG at a horizon whose phase 0-2 float arrays are too small for the second half of the r exchange (h < 14): 256 doubles at the very
+    // end of the workgroup's LDS
+    const bool xr2_in_floats = (100 + 29 * h) * 4 >= 2048;
+    const int tail_doubles = (BIG && !xr2_in_floats) ? 256 : 0;
+    constexpr int QMAX = BIG ? QR_QH : 64;          // working-set positions the per-lane registers hold
     int qcap;
     {   // rows of S^-1 that fit behind M
-        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9;
+        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - tail_doubles;
         int qc = 0;
         if (rem > 0) { qc = (int)((__builtin_sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5); while (tri(qc) > rem) --qc; }
-        qcap = qc < QR_QH ? qc : QR_QH;
+        qcap = qc < QMAX ? qc : QMAX;
         if (qcap > ns) qcap = ns;
     }
     bool spilled = false;
     if constexpr (MAXB > 4) {
         // (the pointer is then generic and the S^-1 accesses of these variants compile to flat_* instructions: a few per cent at
         // h = 16, nothing at h <= 11 whose variants never take this branch)
-        const int want = ns < QR_QH ? ns : QR_QH;
+        const int want = ns < QMAX ? ns : QMAX;
         if (P.sinv_spill && qcap < want && qcap < 64) { Sinv = P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH); qcap = want; spilled = true; }
     }
-    // Four-wave path: what is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the
-    // iteration that added it), so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to
-    // z = w - M (N_A r) for good once the working set outgrows them (all-stance robots at h = 10 never have room).
-    // h = 16 only: a four-wave solve whose working set reaches its 64 lanes hands over, in place, to the single-wave loop further down
-    // (positions 64..95 in a second register / the big-q path): the state is a consistent dual-feasible point there (see the hand-over)
-    bool handoff = false;
-    double h_x0 = 0.0, h_x1 = 0.0, h_x2 = 0.0, h_u0 = 0.0;
-    unsigned h_amask = 0;
-    int h_q = 0, h_iter = 0;
-    const int qcap_full = qcap;
+    // What is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the iteration that added it),
+    // so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to z = w - M (N_A r) for good once the
+    // working set outgrows them.
     int qW = 0;
     double *Wc = nullptr;
     const int nsp = ns | 1;             // row stride of the cache (odd number of doubles)
-    if constexpr (MULTI) {
-        const int qs = spilled ? 0 : (qcap < 64 ? qcap : 64);
-        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs);
+    {
+        const int qs = spilled ? 0 : qcap;
+        const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - (long long)tri(qs) - tail_doubles;
         Wc = Mb + npairs * 9 + tri(qs);
         if (rem > 0 && ns > 0) qW = (int)(rem / (ns | 1));
         if (qW > 64) qW = 64;
@@ -506,7 +490,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
 
     // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
     // (the torque map's Jacobian columns first, on twelve lanes of the last wave: it owns the fewest blocks, so this hides behind wave 0's)
-    if (MAXB <= 4 && g_tau && tid >= 192 && tid < 204) { const int e = tid - 192; mpc_jacobian_column(e / 3, e - 3 * (e / 3), rid, n, C, g_q, sJ + 3 * e); }
+    if (MAXB <= 4 && io.g_tau && tid >= 192 && tid < 204) { const int e = tid - 192; mpc_jacobian_column(e / 3, e - 3 * (e / 3), rid, n, C, io.g_q, sJ + 3 * e); }
     int ba[MAXB], bb[MAXB];
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
@@ -519,7 +503,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             const int b = pid - tri(a);                 // a >= b
             ba[sl] = a; bb[sl] = b;
             const Blk Hb = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
-                                      dbgH ? dbgH + (size_t)rid * NV * NV : nullptr, NV);
+                                      io.dbgH ? io.dbgH + (size_t)rid * NV * NV : nullptr, NV);
             // parked in its final M slot: keeps the 18 VGPRs per block out of the build's register budget
             double *dst = Mb + pid * 9;
 #pragma unroll
@@ -548,184 +532,11 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             acc = __builtin_fmaf(dw, vr[9 + j], acc);
         }
         gl[e] = (double)acc;
-        if (dbgG) dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
+        if (io.dbgG) io.dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
     for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
     QR_TS(2);
 
-// Two implementations of the sweep.  The default keeps the 3x3 blocks in VALU registers.  QR_SWEEP_MFMA=1 runs the same sweep on the
-// fp64 matrix cores (one v_mfma_f64_16x16x4_f64 per 16x16 tile and pivot); parity-green, but measured SLOWER on MI355X (1024 A1
-// robots, h = 10: 128 k cycles per robot against 84 k): the f64 matrix instruction holds its wave for 64 cycles and runs at 1.7x the
-// v_fma_f64 rate at best (scratch/ubench/mfma64b.hip), while copying the pivot columns out of the accumulator layout, the barrier and
-// P^-1 cost ~3 k cycles per pivot whatever the matrix size -- the sweep is a chain of 4h dependent rank-3 steps, not a GEMM.
-#ifndef QR_SWEEP_MFMA
-#define QR_SWEEP_MFMA 0
-#endif
-#if QR_SWEEP_MFMA
-    // ---------------- phase 3: symmetric sweep on the fp64 matrix cores,  A <- -H^-1 ----------------
-    // Pivot leg-step k, its three columns p:  P = A_pp,  C = A[:, p] (n x 3, the lower triangle mirrored),  D = C P^-1;
-    //   A <- A - D C'   everywhere,   then   A[:, p] <- D,  A[p, :] <- D',  A_pp <- -P^-1.
-    // The whole step is ONE rank-3 update: with V = C except V[p, :] = P - I,
-    //   A - (V P^-1) V'  =  A - D C' off the pivot,  D in the pivot columns / rows,  2I - P^-1 in the pivot block
-    // (the 2I is taken off the three diagonal entries when they are copied out).
-    // A lives in the accumulators of v_mfma_f64_16x16x4_f64 as 16x16 tiles of the lower triangle (diagonal tiles whole): five leg-steps
-    // per tile row / column (15 of 16 indices; no leg-step straddles a tile), tile p = tri(R) + C in slot p / 4 of wave p mod 4.  Lane l
-    // of a tile holds column l&15, rows (l>>4) + 4r, r = 0..3.  The update of a tile is one instruction: A operand -(V P^-1) rows of
-    // tile row R, B operand V rows of tile column C, the fourth k zero.  Only V goes through LDS (rows of 4 doubles, double-buffered, one
-    // barrier per pivot); the exact pivot diagonal goes to a side array for P^-1 (P_ii - 1 would lose the low bits of a small pivot
-    // there; as an operand it does not matter).
-    {
-        typedef double d4 __attribute__((ext_vector_type(4)));
-        constexpr int NTW = (MAXB <= 4) ? 12 : 24;         // tiles per wave: tri(9) = 45 (44 leg-steps), tri(13) = 91 (64 leg-steps)
-        const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int lc = lane & 15, lr = lane >> 4;
-        const int T = (nls + 4) / 5, ntile = tri(T);
-        const int nsl = (ntile - wvs + 3) >> 2;              // tiles of this wave
-        int tRC[NTW];                                        // R | C << 8 (scalar)
-        int offA[NTW], offB[NTW];                            // byte offsets of the lane's operands inside a panel
-        d4 acc[NTW];
-        __syncthreads();               // the Hessian blocks parked in the M slots are read by other threads now
-        const int lcb = lc / 3, lcj = lc - 3 * lcb;
-#pragma unroll
-        for (int sl = 0; sl < NTW; ++sl) {
-            const int pt = 4 * sl + wvs;
-            int R = 0, C = 0;
-            if (pt < ntile) { while (tri(R + 1) <= pt) ++R; C = pt - tri(R); }
-            tRC[sl] = R | (C << 8);
-            offA[sl] = (16 * R + lc) * 32; offB[sl] = ((16 * C + lc) * 4 + lr) * 8;
-            acc[sl] = (d4){0.0, 0.0, 0.0, 0.0};
-            if (pt < ntile) {
-                const int b = 5 * C + lcb;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ri = lr + 4 * r, a = 5 * R + ri / 3, i = ri - 3 * (ri / 3);
-                    if (ri < 15 && lc < 15 && a < nls && b < nls)
-                        acc[sl][r] = (a >= b) ? Mb[(tri(a) + b) * 9 + 3 * i + lcj] : Mb[(tri(b) + a) * 9 + 3 * lcj + i];
-                }
-            }
-        }
-        __syncthreads();               // every tile is in registers: the M region can now carry the panels
-        double *pan0 = Mb + ((int)(Mb - smem) & 1);          // 16-byte aligned rows of 4 doubles: V[row][0..2] and a zero (the fourth k)
-        const int pansz = 64 * T;
-        double *pd0 = pan0 + 2 * pansz;                      // [2][4] exact pivot diagonals
-        for (int e = tid; e < 32 * T; e += QR_MPC_THREADS) pan0[4 * e + 3] = 0.0;
-#ifdef QR_SWEEP_STAMPS
-        long long sw_t[6] = {0, 0, 0, 0, 0, 0}, sw_0 = clock64();
-#define SW_STAMP(i) do { const long long t_ = clock64(); sw_t[i] += t_ - sw_0; sw_0 = t_; } while (0)
-#else
-#define SW_STAMP(i) do { } while (0)
-#endif
-        unsigned colmask = 0, rowmask = 0;                   // slots holding a tile of the pivot's tile column / tile row
-        int J = -1;
-        for (int k = 0; k < nls; ++k) {
-            double *pan = pan0 + (k & 1) * pansz, *pd = pd0 + (k & 1) * 4;
-            SW_STAMP(3);
-            if (k == 5 * (J + 1)) {
-                ++J; colmask = 0; rowmask = 0;
-#pragma unroll
-                for (int sl = 0; sl < NTW; ++sl) {
-                    if (sl >= nsl) continue;
-                    if ((tRC[sl] >> 8) == J) colmask |= 1u << sl;
-                    if ((tRC[sl] & 255) == J) rowmask |= 1u << sl;
-                }
-            }
-            const int y = 3 * (k - 5 * J);                   // first pivot index inside its tile
-            SW_STAMP(4);
-            // ---- the pivot columns -> panel (from the lower triangle only, so that the panel is exactly symmetric data)
-            const int jj = lc - y;
-#pragma unroll
-            for (int sl = 0; sl < NTW; ++sl) {
-                if ((colmask >> sl) & 1u) {
-                    const int R = tRC[sl] & 255;
-                    if (jj >= 0 && jj < 3) {
-                        double *dst = pan + (16 * R + lr) * 4 + jj;
-                        if (R > J) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dst[16 * r] = acc[sl][r];
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                if (lr + 4 * r == lc) { pd[jj] = acc[sl][r]; dst[16 * r] = acc[sl][r] - 1.0; acc[sl][r] -= 2.0; }
-                                else if (lr + 4 * r > lc) dst[16 * r] = acc[sl][r];
-                            }
-                        }
-                    }
-                }
-                if ((rowmask >> sl) & 1u) {
-                    // row y + ii of this tile sits in register (y + ii - lr) / 4 of the lanes whose lr makes that an integer
-                    const int C = tRC[sl] >> 8, ii = (lr - y) & 3, x = y + ii - lr;
-                    const double v01 = (x >> 2) == 0 ? acc[sl][0] : acc[sl][1], v23 = (x >> 2) == 2 ? acc[sl][2] : acc[sl][3];
-                    const double v = (x >> 2) < 2 ? v01 : v23;
-                    if (ii < 3 && (C < J || lc < y + ii)) pan[(16 * C + lc) * 4 + ii] = v;
-                }
-            }
-            SW_STAMP(0);
-            __syncthreads();
-            SW_STAMP(1);
-            // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per lane
-            double Pi[9];
-            {
-                const double *Pk = pan + 4 * (16 * J + y);
-                const double p00 = pd[0], p01 = Pk[4], p02 = Pk[8], p11 = pd[1], p12 = Pk[9], p22 = pd[2];
-                const double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
-                const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
-                const double det = p00 * c00 + p01 * c01 + p02 * c02;
-                if (!(det > 0.0) || !(p00 > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
-                const double id = fast_rcp(det);
-                Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
-                Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
-                Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
-            }
-            // column lr of -P^-1 for the A operand (k index = lr; the fourth k is zero padding)
-            const double q0 = -(lr == 0 ? Pi[0] : (lr == 1 ? Pi[1] : (lr == 2 ? Pi[2] : 0.0)));
-            const double q1 = -(lr == 0 ? Pi[3] : (lr == 1 ? Pi[4] : (lr == 2 ? Pi[5] : 0.0)));
-            const double q2 = -(lr == 0 ? Pi[6] : (lr == 1 ? Pi[7] : (lr == 2 ? Pi[8] : 0.0)));
-#ifdef QR_SWEEP_STAMPS
-            asm volatile("" :: "v"(q0), "v"(q1), "v"(q2));
-#endif
-            SW_STAMP(2);
-            // three tiles at a time: the operand loads first, then the products and the matrix instructions
-            // (a group's slots past the wave's last tile work on tile (0, 0) data and are never stored)
-            const char *panb = (const char *)pan;
-#pragma unroll
-            for (int g = 0; g < NTW / 3; ++g) {
-                if (3 * g >= nsl) continue;
-                double c0[3], c1[3], c2[3], bo[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const double *cr = (const double *)(panb + offA[3 * g + u]);
-                    c0[u] = cr[0]; c1[u] = cr[1]; c2[u] = cr[2];
-                    bo[u] = *(const double *)(panb + offB[3 * g + u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const double aop = c0[u] * q0 + c1[u] * q1 + c2[u] * q2;
-                    acc[3 * g + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bo[u], acc[3 * g + u], 0, 0, 0);
-                }
-            }
-        }
-#ifdef QR_SWEEP_STAMPS
-        SW_STAMP(3);
-        if (dbgT && tid == 0) { dbgT[(size_t)rid * 16 + 8] = sw_t[0]; dbgT[(size_t)rid * 16 + 9] = sw_t[1]; dbgT[(size_t)rid * 16 + 10] = sw_t[2]; dbgT[(size_t)rid * 16 + 11] = sw_t[3]; dbgT[(size_t)rid * 16 + 12] = sw_t[4]; }
-#endif
-        __syncthreads();           // everybody is done with the panels before M overwrites them
-#pragma unroll
-        for (int sl = 0; sl < NTW; ++sl) {
-            if (sl >= nsl) continue;
-            const int R = tRC[sl] & 255, C = tRC[sl] >> 8, b = 5 * C + lcb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ri = lr + 4 * r, a = 5 * R + ri / 3, i = ri - 3 * (ri / 3);
-                if (ri < 15 && lc < 15 && a < nls && (R > C || lc <= ri)) {
-                    const double v = -acc[sl][r];                              // M = +H^-1
-                    Mb[(tri(a) + b) * 9 + 3 * i + lcj] = v;
-                    if (a == b && i != lcj) Mb[(tri(a) + a) * 9 + 3 * lcj + i] = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
-#else
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
     // Pivot leg-step k:  P = A_kk,  C_i = A_ik (i > k) or A_ki' (i < k);
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
@@ -836,7 +647,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
 #ifdef QR_SWEEP_STAMPS
         VS_STAMP(3);
-        if (dbgT && tid == 0) { dbgT[(size_t)rid * 16 + 8] = vs_t[0]; dbgT[(size_t)rid * 16 + 9] = vs_t[1]; dbgT[(size_t)rid * 16 + 10] = vs_t[2]; dbgT[(size_t)rid * 16 + 11] = vs_t[3]; dbgT[(size_t)rid * 16 + 12] = 0; }
+        if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 8] = vs_t[0]; io.dbgT[(size_t)rid * 16 + 9] = vs_t[1]; io.dbgT[(size_t)rid * 16 + 10] = vs_t[2]; io.dbgT[(size_t)rid * 16 + 11] = vs_t[3]; io.dbgT[(size_t)rid * 16 + 12] = 0; }
 #endif
         __syncthreads();           // everybody is done with the panels before M overwrites them
 #pragma unroll
@@ -849,21 +660,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         }
         __syncthreads();
     }
-#endif
     QR_TS(3);
     // =====================================================================================================
-    // Four-wave active set (h <= 11).  All four wavefronts run the SAME control flow on the SAME data, so every
-    // decision is identical without communication (same code, same inputs, deterministic reductions); only the
-    // three loops whose cost grows with the working set are split four ways and recombined through LDS:
-    //   r = S^-1 d        wave v takes columns j = v (mod 4)      -> partial r   -> xr[4][64]  -> barrier -> sum
-    //   z = w - M (N r)   wave v takes every 4th active leg-step  -> partial z   -> xz[4][NV]  -> barrier -> sum
-    //   S^-1 +/- update   wave v updates columns j = v (mod 4) of every row (disjoint), visible after the next barrier
-    // Bookkeeping lives in registers, replicated per wave: working-set position i belongs to lane i (q <= 64):
-    // constraint (ck, ct), multiplier u, and d, r during an iteration; lane k knows its leg-step's active rows (amask)
-    // and their positions (posk).  Per-lane gathers use ds_bpermute (__shfl), uniform ones v_readlane.
-    // =====================================================================================================
-    // =====================================================================================================
-    // Control / worker active set (QR_GI_CTRL, default).  Wave 0 alone takes the decisions -- row scan, w, delta, d, step lengths,
+    // Control / worker active set.  Wave 0 alone takes the decisions -- row scan, w, delta, d, step lengths,
     // bookkeeping in its registers -- and waves 1-3 are linear-algebra helpers, so that the S^-1 border of one iteration runs while
     // wave 0 already scans for the next row, and the z partials run while wave 0 reduces the step lengths:
     //     wave 0:   scan, w, delta, d  ->X1-> r partial ->B2-> r, dr, t1, t2, t ->B3-> z, x, u, bookkeeping -> scan ...
@@ -871,10 +670,7 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
     // Three workgroup barriers per working-set change (X1 also publishes the S^-1 update); the control block in LDS carries
     // {command, q, flags, dropped position, 1/z'c}, d travels through xz[0], the row positions of every leg-step through sPos.
     // =====================================================================================================
-#ifndef QR_GI_CTRL
-#define QR_GI_CTRL 1
-#endif
-    if constexpr (MULTI && QR_GI_CTRL) {
+    {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const bool own = lane < nls;
         const int kme = own ? lane : 0;
@@ -883,14 +679,12 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         const int tril = tri(lane);
         const double tol = 1e-9;
         const double INF = __builtin_inf();
-        // h = 16 variants: working-set positions 64 .. 95 live in a SECOND set of per-lane registers (position lane + 64), so a solve that
-        // outgrows the 64 lanes stays in this loop instead of handing over to the single-wave one (which costs ~40 k cycles per change at
-        // 86 rows).  The second half of the r exchange lives in the float arrays of phases 0-2, dead by now (2.2 KB at h = 16).
-        constexpr bool BIG = MAXB > 4;
-        const bool big2 = BIG && (100 + 29 * h) * 4 >= 2048 && qcap_full > 64;
-        double *xr2 = (double *)sT;
+        // BIG variants: working-set positions 64 .. 95 live in a SECOND set of per-lane registers (position lane + 64), so a solve that
+        // outgrows the 64 lanes stays in this loop.  The second half of the r exchange lives in the float arrays of phases 0-2, dead by
+        // now (2.2 KB at h = 16), or at the very end of the workgroup's LDS when those are too small (h < 14).
+        const bool big2 = BIG && qcap > 64;
+        double *xr2 = xr2_in_floats ? (double *)sT : smem + (P.lds_bytes / 8 - 256);
         const int tril2 = tri(lane + 64);
-        if (qcap > (big2 ? QR_QH : 64)) qcap = big2 ? QR_QH : 64;
         auto rd2 = [&](double v0, double v1, int j) { return j < 64 ? readlane_d(v0, j) : readlane_d(v1, j - 64); };       // j uniform
         int *sCtl = sMisc + 8;                            // [0] command (0 go, 1 exit), [1] q, [2] flags, [3] dropped position, [4,5] 1/z'c
         double *dd = xz;                                  // d of the iteration (wave 0 produces no z partial: its slot is free)
@@ -914,6 +708,9 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             if (own) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { x0 -= xz[v * NV + 3 * kme]; x1 -= xz[v * NV + 3 * kme + 1]; x2 -= xz[v * NV + 3 * kme + 2]; }
+                // the unconstrained optimum stays in LDS (g is dead: every wave read it in front of the barrier above): a re-factorisation or a
+                // warm start solves the equality-constrained problem on a whole working set from it
+                if (wv == 0) { gl[3 * kme] = x0; gl[3 * kme + 1] = x1; gl[3 * kme + 2] = x2; }
             }
             __syncthreads();
         }
@@ -949,13 +746,113 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
             for (; j < q; j += 4) pr += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(dq, j);
             xr[wv * 64 + lane] = pr;
         };
+        // ---- S^-1 (and the W_A cache) of a WHOLE working set at once: sAct[0..q) = 6 * leg-step + row per position.
+        //   S_ij = c_i' M[k_i, k_j] c_j (one block of M per pair), then an in-place symmetric sweep of the packed triangle (one barrier per
+        //   pivot: the next pivot's column is published by the owners of its elements while they update them), then W_A = M N_A while it fits.
+        // Used for a warm start (last tick's working set, instead of adding its rows one iteration at a time) and to re-factorise when the
+        // exit check finds that S^-1 -- otherwise kept by bordered updates / downdates only -- has drifted.  Every wave calls it (barriers
+        // inside); returns false, for everybody alike, when a pivot shows the rows to be dependent.
+        auto rebuild = [&](const int q) -> bool {
+            // thread t owns the packed elements e = t, t + 256, ... (NE at most) and keeps them in registers through the whole sweep; only the
+            // pivot column goes through LDS (colp, double buffered: the owners of the next pivot's column publish it while they update it)
+            constexpr int NE = (QMAX * (QMAX + 1) / 2 + QR_MPC_THREADS - 1) / QR_MPC_THREADS;        // 9 (64 rows), 19 (96 rows)
+            const int ne = tri(q);
+            double *colp = xr;                            // [2][QMAX] pivot columns (the r exchange is idle during a rebuild)
+            double *diag0 = xz + NV;                      // [q] the diagonal of S (q <= 3 nls <= NV)
+#if defined(QR_DIAG_REFAC)
+            const long long tb0 = clock64();
+#endif
+            double el[NE];
+            int eij[NE];
+#pragma unroll
+            for (int m = 0; m < NE; ++m) {
+                el[m] = 0.0; eij[m] = 0;
+                if (QR_MPC_THREADS * m < ne) {                                  // (uniform)
+                    const int e = tid + QR_MPC_THREADS * m;
+                    if (e < ne) {
+                        int i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+                        while (tri(i + 1) <= e) ++i;
+                        while (tri(i) > e) --i;
+                        const int j = e - tri(i);
+                        const int ci = sAct[i], cj = sAct[j];
+                        const int ki = (ci * 10923) >> 16, kj = (cj * 10923) >> 16;        // / 6 for ids < 6 * 64
+                        Blk B; load_block(Mb, ki, kj, B);
+                        double a0, a1, a2, b0, b1, b2;
+                        cons_vec(ci - 6 * ki, im, a0, a1, a2); cons_vec(cj - 6 * kj, im, b0, b1, b2);
+                        const double v = a0 * (B.m[0] * b0 + B.m[1] * b1 + B.m[2] * b2) + a1 * (B.m[3] * b0 + B.m[4] * b1 + B.m[5] * b2)
+                                       + a2 * (B.m[6] * b0 + B.m[7] * b1 + B.m[8] * b2);
+                        el[m] = v; eij[m] = (i << 8) | j;
+                        if (j == 0) colp[i] = v;
+                        if (i == j) diag0[i] = v;
+                    }
+                }
+            }
+            __syncthreads();
+#if defined(QR_DIAG_REFAC)
+            const long long tb1 = clock64();
+#endif
+            bool ok = true;
+            for (int p = 0; p < q; ++p) {
+                const double *cur = colp + (p & 1) * QMAX;
+                double *nxt = colp + ((p & 1) ^ 1) * QMAX;
+                const double d = cur[p];
+                if (!(d > 1e-11 * diag0[p])) { ok = false; break; }          // (the same value in every thread: a uniform exit)
+                const double ip = fast_rcp(d);
+#pragma unroll
+                for (int m = 0; m < NE; ++m) {
+                    if (QR_MPC_THREADS * m < ne) {                              // (uniform; threads past the last element work on a zero at (0, 0))
+                        const int i = eij[m] >> 8, j = eij[m] & 255;
+                        const double ci = cur[i], cj = cur[j];
+                        const bool ip_ = (i == p), jp_ = (j == p);
+                        const double sp_ = (ip_ && jp_) ? -ip : (ip_ ? cj : ci) * ip;
+                        const double v = (ip_ || jp_) ? sp_ : el[m] - ci * cj * ip;
+                        el[m] = v;
+                        const bool c1 = (j == p + 1);
+                        if (c1 || i == p + 1) nxt[c1 ? i : j] = v;
+                    }
+                }
+                __syncthreads();
+            }
+#if defined(QR_DIAG_REFAC)
+            const long long tb2 = clock64();
+            if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 2] = tb1 - tb0; io.dbgT[(size_t)rid * 16 + 3] = tb2 - tb1; }
+#endif
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < NE; ++m) { const int e = tid + QR_MPC_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
+                if (qW > 0 && q <= qW) {
+                    for (int i = wv; i < q; i += 4) {
+                        const int ci = sAct[i];
+                        const int ki = (ci * 10923) >> 16;
+                        double a0, a1, a2;
+                        cons_vec(ci - 6 * ki, im, a0, a1, a2);
+                        if (own) {
+                            Blk B; load_block(Mb, kme, ki, B);
+                            double *wq = Wc + i * nsp + 3 * kme;
+                            wq[0] = B.m[0] * a0 + B.m[1] * a1 + B.m[2] * a2;
+                            wq[1] = B.m[3] * a0 + B.m[4] * a1 + B.m[5] * a2;
+                            wq[2] = B.m[6] * a0 + B.m[7] * a1 + B.m[8] * a2;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            return ok;
+        };
+        enum { CMD_GO = 0, CMD_EXIT = 1, CMD_REBUILD = 2 };
         if (wv != 0) {
             // ================================ workers ================================
             const int g = wv - 1;                         // 0..2
             for (;;) {
                 __syncthreads();                          // X1
-                if (__builtin_amdgcn_readfirstlane(sCtl[0]) != 0) return;
+                const int cmd = __builtin_amdgcn_readfirstlane(sCtl[0]);
+                if (cmd == CMD_EXIT) return;
                 const int q = __builtin_amdgcn_readfirstlane(sCtl[1]);
+                if (cmd == CMD_REBUILD) {
+                    const bool ok = rebuild(q);
+                    fastz = ok ? (qW > 0 && q <= qW) : (qW > 0);      // as wave 0 decides (a failed rebuild falls back to a cold start)
+                    continue;
+                }
                 const bool hi = BIG && q > 64;
                 const double dq = (lane < q) ? dd[lane] : 0.0;
                 const double dq2 = (hi && lane + 64 < q) ? dd[lane + 64] : 0.0;
@@ -1076,7 +973,148 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
         double uq2 = 0.0;
         const int maxit = 40 * nls + 100;
         bool done = (nls == 0);
+        // ---- warm start: last tick's final working set of this robot slot (P.warm: per robot a 6-bit row mask per ORIGINAL leg-step, the
+        // contact table it belonged to and a validity tag).  The contact table scrolls as the gait phase advances, so the old masks are
+        // taken under the row shift (0, 1 or 2 horizon steps) that matches the old table to the new one best.  Speed only: the QP has
+        // one optimum, whatever set the solve starts from.
+        bool need_rebuild = false;
+        int refac = 0;                                    // re-factorisations spent on a failed exit check (at most two)
+        unsigned char *warm = (P.warm && nls > 0) ? P.warm + (size_t)rid * QR_WARM_STRIDE : nullptr;
+        if (warm && warm[QR_WARM_STRIDE - 1] == (unsigned char)h) {
+            const unsigned long long cur = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
+            const unsigned long long old = *(const unsigned long long *)(warm + 64);
+            int sh = 0, best = 1 << 30;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int keep = NL - 4 * k;                                   // table rows that exist under this shift
+                const unsigned long long m = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
+                const int miss = __popcll(((old >> (4 * k)) ^ cur) & m) * 4 + k;
+                if (miss < best) { best = miss; sh = k; }
+            }
+            const int src = own ? sLs[kme] + 4 * sh : NL;
+            unsigned gm = (src < NL) ? (unsigned)warm[src] & 0x3fu : 0u;
+            // positions row-type-major: rows t of every leg-step, then rows t + 1 ...
+            int base = 0;
+            unsigned long long pk = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const bool has = (gm >> t) & 1u;
+                const unsigned long long bal = __ballot(has);
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (has && pos < 256) pk |= (unsigned long long)(pos & 0xff) << (8 * t);
+                base += __popcll(bal);
+            }
+            const int qg = base;
+            if (qg > 0 && qg <= qcap) {
+                amask = gm; posk = pk; q = qg;
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    if ((gm >> t) & 1u) { const int pos = (int)((pk >> (8 * t)) & 0xffu); sAct[pos] = 6 * kme + t; sPos[6 * kme + t] = (short)pos; }
+                wave_sync();
+                if (lane < q) { const int c = sAct[lane]; ck = (c * 10923) >> 16; ct = c - 6 * ck; }
+                if (BIG && lane + 64 < q) { const int c = sAct[lane + 64]; ck2 = (c * 10923) >> 16; ct2 = c - 6 * ck2; }
+                need_rebuild = true;
+            }
+        }
+        // slack of the row at working-set position `lane` (+64) at the unconstrained optimum x_0 (kept in gl)
+        auto slack_at_x0 = [&](int k_, int t_) {
+            double a0, a1, a2;
+            cons_vec(t_, im, a0, a1, a2);
+            return a0 * gl[3 * k_] + a1 * gl[3 * k_ + 1] + a2 * gl[3 * k_ + 2] + ((t_ == 5) ? fmk[k_] : 0.0);
+        };
         while (!done) {
+            if (need_rebuild) {
+                // ---- solve the equality-constrained problem on the whole working set: S^-1 from scratch, u = -S^-1 s(x_0), x = x_0 + W_A u;
+                // rows whose multiplier comes out negative leave one by one (most negative first) until the point is dual feasible: then
+                // (x, u, working set, S^-1) is a state the loop below can carry on from.
+                need_rebuild = false;
+                xmask = 0;
+                if (lane < q) sAct[lane] = 6 * ck + ct;
+                if (BIG && lane + 64 < q) sAct[lane + 64] = 6 * ck2 + ct2;
+                if (lane == 0) { sCtl[0] = CMD_REBUILD; sCtl[1] = q; }
+                __syncthreads();                          // X1
+#if defined(QR_DIAG_REFAC)
+                const long long tr0 = clock64();
+#endif
+                const bool ok = rebuild(q);
+#if defined(QR_DIAG_REFAC)
+                if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 8] += ok ? 1 : 100; io.dbgT[(size_t)rid * 16 + 10] = clock64() - tr0; io.dbgT[(size_t)rid * 16 + 11] = q; }
+                const long long tr1 = clock64();
+#endif
+                if (!ok) {
+                    // dependent rows in the guess: cold start
+                    if (own) {
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) sPos[6 * kme + t] = (short)-1;
+                    }
+                    amask = 0; posk = 0; q = 0; uq = 0.0; uq2 = 0.0;
+                    x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2];
+                    fastz = qW > 0;
+                    refac = 2;
+                    continue;
+                }
+                fastz = qW > 0 && q <= qW;
+                for (;;) {
+                    if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
+                    q = __builtin_amdgcn_readfirstlane(q);
+                    const bool hi = BIG && q > 64;
+                    const double dq = (lane < q) ? slack_at_x0(ck, ct) : 0.0;
+                    double dq2 = 0.0;
+                    if (hi) { dq2 = (lane + 64 < q) ? slack_at_x0(ck2, ct2) : 0.0; if (lane + 64 < q) dd[lane + 64] = dq2; }
+                    if (lane < q) dd[lane] = dq;
+                    if (lane == 0) { sCtl[0] = CMD_GO; sCtl[1] = q; }
+                    __syncthreads();                      // X1
+                    r_partial(q, dq, dq2);
+                    __syncthreads();                      // B2
+                    double rq, rq2 = 0.0;
+                    { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
+                    if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
+                    // u = -r; the most negative multiplier beyond rounding leaves
+                    const double umax = -wave_min_d(hi ? (rq < rq2 ? rq : rq2) : rq);          // max u (>= 0 when any row is held properly)
+                    const double worst = -wave_min_d(hi ? (-rq < -rq2 ? -rq : -rq2) : -rq);    // max r = -min u
+                    const bool drop = worst > 1e-10 * (1.0 + (umax > 0.0 ? umax : 0.0));
+                    int lpos = -1;
+                    if (drop) { lpos = first_lane(lane < q && rq == worst); if (hi && lpos < 0) lpos = 64 + first_lane(lane + 64 < q && rq2 == worst); }
+                    if (lane == 0) { sCtl[2] = drop ? F_DROP : 0; sCtl[3] = lpos; }
+                    __syncthreads();                      // B3
+                    if (!drop) {
+                        x0 = gl[3 * kme] - ((xz[NV + 3 * kme] + xz[2 * NV + 3 * kme]) + xz[3 * NV + 3 * kme]);
+                        x1 = gl[3 * kme + 1] - ((xz[NV + 3 * kme + 1] + xz[2 * NV + 3 * kme + 1]) + xz[3 * NV + 3 * kme + 1]);
+                        x2 = gl[3 * kme + 2] - ((xz[NV + 3 * kme + 2] + xz[2 * NV + 3 * kme + 2]) + xz[3 * NV + 3 * kme + 2]);
+                        uq = (lane < q && rq < 0.0) ? -rq : 0.0;
+                        if (hi) uq2 = (lane + 64 < q && rq2 < 0.0) ? -rq2 : 0.0;
+                        break;
+                    }
+#if defined(QR_DIAG_REFAC)
+                    if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 13] += 1;
+#endif
+                    // position lpos leaves: the same bookkeeping as a drop of the loop below (the workers downdate S^-1 between D1 and D3)
+                    {
+                        const int l = lpos, last = q - 1;
+                        int clk, clt, cmk, cmt;
+                        if (BIG && l >= 64) { clk = __builtin_amdgcn_readlane(ck2, l - 64); clt = __builtin_amdgcn_readlane(ct2, l - 64); }
+                        else { clk = __builtin_amdgcn_readlane(ck, l); clt = __builtin_amdgcn_readlane(ct, l); }
+                        if (BIG && last >= 64) { cmk = __builtin_amdgcn_readlane(ck2, last - 64); cmt = __builtin_amdgcn_readlane(ct2, last - 64); }
+                        else { cmk = __builtin_amdgcn_readlane(ck, last); cmt = __builtin_amdgcn_readlane(ct, last); }
+                        __syncthreads();                  // D1
+                        if (fastz && l != last && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
+                        __syncthreads();                  // D2
+                        if (l != last) {
+                            if (lane == l) { ck = cmk; ct = cmt; }
+                            if (BIG && lane + 64 == l) { ck2 = cmk; ct2 = cmt; }
+                        }
+                        if (lane == clk) { amask &= ~(1u << clt); sPos[6 * clk + clt] = (short)-1; }
+                        if (l != last && lane == cmk) { posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt)); sPos[6 * cmk + cmt] = (short)l; }
+                        __syncthreads();                  // D3
+                        --q;
+                    }
+                    if (q == 0) { x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2]; uq = 0.0; uq2 = 0.0; break; }
+                }
+#if defined(QR_DIAG_REFAC)
+                if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 9] = clock64() - tr1;
+#endif
+                if (done) break;
+            }
             double bs = INF; int bt = 0;
             {
                 const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
@@ -1095,7 +1133,17 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                         if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
                     }
                 }
-                if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
+                const double bemin = wave_min_d(be);
+#if defined(QR_DIAG_REFAC)
+                if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 12] = __double_as_longlong(bemin); }
+#endif
+                if (bemin < -1e-4) {
+                    // S^-1 has drifted (hundreds of bordered updates / downdates) or a row was set aside wrongly: rebuild it from the working
+                    // set as it stands, re-solve on that set, restore dual feasibility and carry on; only a solve that fails the check
+                    // after two such repairs keeps the flag
+                    if (refac < 2 && q > 0) { ++refac; need_rebuild = true; continue; }
+                    st |= QRGPU_ST_MPC_INFEAS_D;
+                }
                 break;
             }
             const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
@@ -1152,26 +1200,31 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
                 if (hi && t1 < INF && lpos < 0) lpos = 64 + first_lane(tt2 == t1);
                 const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
+                // z'c / c'Mc = |z|^2 / |w|^2 in the Hessian norm: how independent of the working set the row is.  Measured over 6,000 solves
+                // (scratch/diag_ratio.py) the rows a solve adds sit at >= 9e-4; the only other values seen were ~1e-13 -- rows that are dependent
+                // but slipped through a looser test, after which 1 / z'c = 1e13 in S^-1 cost ten digits and the solve ended with active rows
+                // 2e-4 N off (the drift flags of round 1).  Below 1e-9 a row is treated as dependent: no full step, a blocking row leaves first.
                 const bool have_z = zc > 1e-13 * delta;
+                const bool indep = zc > 1e-9 * delta;
                 const double izc = fast_rcp(zc);
-                const double t2 = have_z ? -sp * izc : INF;
+                const double t2 = indep ? -sp * izc : INF;
                 const double t = t1 < t2 ? t1 : t2;
                 const bool degenerate = !(t < INF);
-                const bool full = !degenerate && have_z && t == t2;
+                const bool full = !degenerate && indep && t == t2;
+#if defined(QR_DIAG_REFAC)
+                if (io.dbgT && lane == 0 && full) { const double ratio = zc / delta; double *mr = (double *)&io.dbgT[(size_t)rid * 16 + 15]; if (iter <= 2 || ratio < *mr) *mr = ratio; }
+#endif
                 const bool over = full && q >= qcap;
                 const int flags = (degenerate || over) ? 0 : (full ? F_FULL : F_DROP);
 #ifdef QR_TRACE
-                if (dbgT && lane == 0 && iter <= 7) { dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
+                if (io.dbgT && lane == 0 && iter <= 7) { io.dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); io.dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
 #endif
                 if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
                 CS_STAMP(4);
                 __syncthreads();                          // B3
                 CS_STAMP(5);
                 if (degenerate) { if (lane == kp) xmask |= 1u << tp; break; }
-                if (over) {
-                    if (!big2 && q == 64 && qcap_full > 64) handoff = true; else st |= QRGPU_ST_MPC_OVERFLOW_D;
-                    done = true; break;
-                }
+                if (over) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }      // (main pass: the robot goes on the rescue list below)
                 if (have_z) {
                     const double z0 = w0 - ((xz[NV + 3 * kme] + xz[2 * NV + 3 * kme]) + xz[3 * NV + 3 * kme]);
                     const double z1 = w1 - ((xz[NV + 3 * kme + 1] + xz[2 * NV + 3 * kme + 1]) + xz[3 * NV + 3 * kme + 1]);
@@ -1217,634 +1270,72 @@ void qr_mpc_kernel(MpcLaunch P, const int *__restrict__ type_id, const float *__
                 }
             }
         }
-        if (lane == 0) sCtl[0] = 1;                       // workers leave at their next X1
+        if (lane == 0) sCtl[0] = CMD_EXIT;                // workers leave at their next X1
         __syncthreads();
         QR_TS(5);
-        if (handoff) {
-            if (lane < q) sAct[lane] = 6 * ck + ct;       // sPos has been kept all along
-            h_x0 = x0; h_x1 = x1; h_x2 = x2; h_u0 = (lane < q) ? uq : 0.0; h_amask = amask; h_q = q; h_iter = iter;
+        const bool to_rescue = (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode;
+        if (warm && !to_rescue) {                         // (a robot on its way to the list pass keeps last tick's guess for that pass)
+            // this tick's final working set, by original leg-step, for the next tick of this robot slot (only a converged solve is worth it)
+            const bool good = (st & 0xff) == 0;
+            warm[lane] = 0;
             wave_sync();
-        } else {
-            wave_sync();
-            if (lane < 12) xz[lane] = 0.0;
-            wave_sync();
-            if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
-            wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
-            if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
-            if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
-            QR_TS(6);
+            if (own && good) warm[sLs[kme]] = (unsigned char)amask;
+            if (lane == 0) {
+                *(unsigned long long *)(warm + 64) = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
+                warm[QR_WARM_STRIDE - 1] = good ? (unsigned char)h : 0;
+            }
+        }
+        wave_sync();
+        if (lane < 12) xz[lane] = 0.0;
+        wave_sync();
+        if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
+        wave_sync();
+        mpc_outputs(lane, rid, n, xz, R, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
+        if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
+        if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+        if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
+        QR_TS(6);
 #ifndef QR_TRACE
-            if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; dbgT[(size_t)rid * 16 + 14] = q; }
+        if (lane == 0 && io.dbgT) { io.dbgT[(size_t)rid * 16 + 7] = ns; io.dbgT[(size_t)rid * 16 + 14] = q; }
 #ifdef QR_GI_STAMPS
-            if (lane == 0 && dbgT) for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = cs_t[i];
+        if (lane == 0 && io.dbgT) for (int i = 0; i < 6; ++i) io.dbgT[(size_t)rid * 16 + 8 + i] = cs_t[i];
 #endif
 #endif
-            return;
-        }
-    } else
-    if constexpr (MULTI) {
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the partitioned loops below run on the SALU
-        const bool own = lane < nls;
-        const int kme = own ? lane : 0;
-        const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
-        const double fmaxk = own ? fmk[kme] : 0.0;
-        const int tril = tri(lane);
-        const double tol = 1e-9;
-        const double INF = __builtin_inf();
-        if (qcap > 64) qcap = 64;
-        // ---- phase 4: x = -M g, block columns kc = wv (mod 4) per wave
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-        {
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-            if (own) {
-                for (int kc = wv; kc < nls; kc += 4) {
-                    Blk B; load_block(Mb, kme, kc, B);
-                    const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
-                    p0 += B.m[0] * g0 + B.m[1] * g1 + B.m[2] * g2;
-                    p1 += B.m[3] * g0 + B.m[4] * g1 + B.m[5] * g2;
-                    p2 += B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
-                }
-                xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2;
-            }
-            __syncthreads();
-            if (own) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { x0 -= xz[v * NV + 3 * kme]; x1 -= xz[v * NV + 3 * kme + 1]; x2 -= xz[v * NV + 3 * kme + 2]; }
-            }
-            __syncthreads();
-        }
-        QR_TS(4);
-        // ---- phase 5
-        int q = 0, iter = 0;
-        unsigned amask = 0, xmask = 0;
-        unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
-        int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
-        double uq = 0.0;                                  // its multiplier
-        const int maxit = 40 * nls + 100;
-        bool done = (nls == 0);
-        bool after_drop = false;
-        bool fastz = qW > 0;
-        long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = dbgT ? clock64() : 0;
-#ifdef QR_GI_STAMPS      // sub-phase cycle accounting of the loop below (build.py: QRGPU_GI_STAMPS=1); costs ~15 % when compiled in
-#define QM_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
-#else
-#define QM_STAMP(i) do { } while (0)
-#endif
-        while (!done) {
-            // step 1: most violated inactive row (ties -> lowest id)
-            // (lanes without a leg-step run the same arithmetic on their zeros and are masked by one select: no divergent region)
-            double bs = INF; int bt = 0;
-            {
-                const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
-                const unsigned blocked = own ? (amask | xmask) : 0x3fu;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { const bool take = !((blocked >> t) & 1u) && s[t] < bs; bs = take ? s[t] : bs; bt = take ? t : bt; }
-            }
-            const double smin = wave_min_d(bs);
-            if (!(smin < -tol)) {
-                // Rows left out as dependent are combinations of active rows and hold with them -- unless the exclusion was a
-                // numerical accident (seen at twice SURVEY 8d's ranges after ~1000 iterations): then this point is not the optimum.
-                // Likewise an active row must be tight: the updates keep x = x0 + M N u whatever r was, but a drifted S^-1 lets
-                // active rows slip, and those are not scanned.  Either residual beyond 1e-4 N (a tenth of the force tolerance at 100 N) flags the robot.
-                double be = 0.0;
-                if (own && (xmask | amask)) {
-                    const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) {
-                        if (((xmask >> t) & 1u) && s[t] < be) be = s[t];
-                        if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
-                    }
-                }
-                if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
-                break;
-            }
-            const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
-            const int tp = __builtin_amdgcn_readlane(bt, kp);
-            double c0, c1, c2;
-            cons_vec(tp, im, c0, c1, c2);
-            const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
-            double up = 0.0;
-            QM_STAMP(0);
-            for (;;) {
-                q = __builtin_amdgcn_readfirstlane(q);
-                if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
-                // w_k = M_{k,kp} c_p
-                double w0, w1, w2_;
-                {
-                    Blk B; load_block(Mb, kme, kp, B);                // kme is a valid leg-step in every lane
-                    w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
-                    w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
-                    w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
-                }
-                const double delta = c0 * readlane_d(w0, kp) + c1 * readlane_d(w1, kp) + c2 * readlane_d(w2_, kp);
-                // d = N' w : position i needs w of leg-step ck(i)
-                double dq = 0.0;
-                {
-                    // (taking d from the W_A cache instead -- c_p' (W_A row i)(kp) -- is the same number in exact arithmetic but rounds
-                    // differently from delta; for a row that is dependent on active rows of its own leg-step the cancellation in
-                    // z'c = delta - d'r is then no longer exact, and one robot in 36 864 ended 8e-4 N off: scratch/diag_outlier.py)
-                    double a0, a1, a2;
-                    cons_vec(ct, im, a0, a1, a2);
-                    const double g0 = __shfl(w0, ck, 64), g1 = __shfl(w1, ck, 64), g2 = __shfl(w2_, ck, 64);
-                    dq = (lane < q) ? a0 * g0 + a1 * g1 + a2 * g2 : 0.0;
-                }
-                QM_STAMP(1);
-                // r = S^-1 d, columns j = wv (mod 4) here.  (i, j) at tri(i) + j for j <= i, else tri(j) + i.
-                if (after_drop) { __syncthreads(); after_drop = false; }   // B1: wave 0's row move of the last drop is visible
-                double rq = 0.0;
-                {
-                    const int i0 = (lane < q) ? lane : 0;
-                    double pr = 0.0;
-                    int j = wv;
-                    for (; j + 12 < q; j += 16) {
-                        double sv[4], dj[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int jj = j + 4 * u;
-                            sv[u] = Sinv[(jj <= i0) ? tril + jj : tri(jj) + i0];
-                            dj[u] = readlane_d(dq, jj);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) pr += sv[u] * dj[u];
-                    }
-                    for (; j < q; j += 4) pr += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(dq, j);
-                    xr[wv * 64 + lane] = pr;                      // every lane has its slot
-                    __syncthreads();                              // B2
-                    { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
-                }
-                QM_STAMP(2);
-                const double dr = wave_sum_d(rq * dq);
-                const double zc = delta - dr;                    // z'c_p
-                // dual step length: min u_j / r_j over r_j > 0
-                double tt = INF;
-                { const double tq_ = uq * fast_rcp(rq); tt = (lane < q && rq > 0.0) ? tq_ : INF; }
-                const double t1 = wave_min_d(tt);
-                const int lpos = (t1 < INF) ? first_lane(tt == t1) : -1;
-                const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
-                const bool have_z = zc > 1e-13 * delta;
-                const double izc = fast_rcp(zc);
-                const double t2 = have_z ? -sp * izc : INF;
-                const double t = t1 < t2 ? t1 : t2;
-                if (!(t < INF)) {
-                    // degenerate corner (see the single-wave path): leave the row out until the working set changes
-                    if (lane == kp) xmask |= 1u << tp;
-                    break;
-                }
-                const bool full = have_z && t == t2;
-                QM_STAMP(3);
-#ifdef QR_TRACE
-                if (dbgT && tid == 0 && iter <= 7) { dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
-#endif
-                if (full) {
-                    // bordered update of S^-1 (needs only r and 1/z'c): columns j = wv (mod 4); published by B3 below
-                    if (q >= qcap) {
-                        // Nothing of this inner iteration has been applied yet, and with q at its maximum no row was dropped in this
-                        // outer iteration either (up == 0): (x, u, working set, S^-1) is exactly the state the outer loop started from.
-                        if (q == 64 && qcap_full > 64) { handoff = true; done = true; break; }
-                        st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break;
-                    }
-                    const double isg = izc;
-                    const bool act0 = lane < q;
-                    const double ri = rq * isg;
-                    int j = wv;
-                    for (; j + 12 < q; j += 16) {
-                        double sv[4], rj[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; rj[u] = readlane_d(rq, jj); sv[u] = (act0 && jj <= lane) ? Sinv[tril + jj] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int jj = j + 4 * u; if (act0 && jj <= lane) Sinv[tril + jj] = sv[u] + ri * rj[u]; }
-                    }
-                    for (; j < q; j += 4) { const double rj = readlane_d(rq, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
-                    if (wv == 0) {
-                        if (act0) Sinv[tri(q) + lane] = -rq * isg;
-                        if (lane == 0) Sinv[tri(q) + q] = isg;
-                    }
-                }
-                QM_STAMP(4);
-                if (have_z) {
-                    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-                    if (fastz) {
-                        // partial W_A r over the positions i = wv (mod 4), two per trip
-                        const double *wk = Wc + 3 * kme;
-                        int i = wv;
-                        for (; i + 4 < q; i += 8) {
-                            const double ra = readlane_d(rq, i), rb = readlane_d(rq, i + 4);
-                            {
-                                const double *wa = wk + i * nsp, *wb = wk + (i + 4) * nsp;
-                                const double a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
-                                p0 += a0 * ra + b0 * rb; p1 += a1 * ra + b1 * rb; p2 += a2 * ra + b2 * rb;
-                            }
-                        }
-                        if (i < q) {
-                            const double ra = readlane_d(rq, i);
-                            { const double *wa = wk + i * nsp; p0 += wa[0] * ra; p1 += wa[1] * ra; p2 += wa[2] * ra; }
-                        }
-                    } else {
-                        // y_k = sum over the active rows of my leg-step of c_row * r(position)
-                        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-#pragma unroll
-                        for (int tq = 0; tq < 6; ++tq) {
-                            const int ps = (int)((posk >> (8 * tq)) & 0x3full);
-                            const double rr = __shfl(rq, ps, 64);
-                            if ((amask >> tq) & 1u) {
-                                double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
-                                y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
-                            }
-                        }
-                        // partial z over every 4th active leg-step (rank among the active ones = wv mod 4, found with mbcnt so that every
-                        // wave scans only its own bits), two block
-                        // columns per trip so that the second LDS load is in flight while the first is used
-                        const bool hasrow = own && amask != 0;
-                        const unsigned long long kall = __ballot(hasrow);
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(kall >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kall, 0u));
-                        unsigned long long km = __ballot(hasrow && (rank & 3) == wv);
-                        while (km) {
-                            const int kc = (int)__builtin_ctzll(km);
-                            km &= km - 1;
-                            int kc2 = -1;
-                            if (km) { kc2 = (int)__builtin_ctzll(km); km &= km - 1; }
-                            const int kr = kc2 >= 0 ? kc2 : kc;
-                            const double sc = kc2 >= 0 ? 1.0 : 0.0;
-                            Blk B, B2;
-                            if (own) { load_block(Mb, kme, kc, B); load_block(Mb, kme, kr, B2); }
-                            const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
-                            const double s0 = sc * readlane_d(y0, kr), s1 = sc * readlane_d(y1, kr), s2 = sc * readlane_d(y2, kr);
-                            if (own) {
-                                p0 += (B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2) + (B2.m[0] * s0 + B2.m[1] * s1 + B2.m[2] * s2);
-                                p1 += (B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2) + (B2.m[3] * s0 + B2.m[4] * s1 + B2.m[5] * s2);
-                                p2 += (B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2) + (B2.m[6] * s0 + B2.m[7] * s1 + B2.m[8] * s2);
-                            }
-                        }
-                    }
-                    if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
-                    __syncthreads();                              // B3
-                    {
-                        double z0 = w0, z1 = w1, z2 = w2_;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) { z0 -= xz[v * NV + 3 * kme]; z1 -= xz[v * NV + 3 * kme + 1]; z2 -= xz[v * NV + 3 * kme + 2]; }
-                        x0 += t * z0; x1 += t * z1; x2 += t * z2;      // (lanes without a leg-step shadow lane 0; their x is never read)
-                    }
-                }
-                uq -= t * rq;
-                up += t;
-                QM_STAMP(5);
-                if (full) {
-                    // full step: the row joined the working set at position q (S^-1 already updated above)
-                    if (fastz) {
-                        if (q < qW) { if (wv == 0 && own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
-                        else fastz = false;
-                    }
-                    if (lane == q) { uq = up; ck = kp; ct = tp; }
-                    if (lane == kp) { amask |= 1u << tp; posk = (posk & ~(0xffull << (8 * tp))) | ((unsigned long long)q << (8 * tp)); }
-                    xmask = 0;
-                    ++q;
-                    break;
-                }
-                // partial or dual-only step: the constraint at lpos leaves; downdate S^-1, move the last one into its slot
-                {
-                    const int l = lpos, last = q - 1;
-                    double sl = 0.0;                              // column l of S^-1
-                    if (lane < q) sl = Sinv[pidx(lane, l)];
-                    const double isl = fast_rcp(readlane_d(sl, l));
-                    __syncthreads();                              // everyone has column l before anyone changes S^-1
-                    for (int j = wv; j < q; j += 4) {
-                        if (j == l) continue;
-                        const double sj = readlane_d(sl, j) * isl;
-                        if (lane < q && lane != l && j <= lane) Sinv[tril + j] -= sl * sj;
-                    }
-                    __syncthreads();
-                    const int clk = __builtin_amdgcn_readlane(ck, l), clt = __builtin_amdgcn_readlane(ct, l);
-                    const int cmk = __builtin_amdgcn_readlane(ck, last), cmt = __builtin_amdgcn_readlane(ct, last);
-                    if (l != last) {
-                        double m0 = 0.0;
-                        if (wv == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
-                        __syncthreads();
-                        if (wv == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
-                        if (fastz && wv == 0 && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
-                        const double ulast = readlane_d(uq, last);
-                        if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
-                    }
-                    if (lane == clk) amask &= ~(1u << clt);
-                    if (l != last && lane == cmk) posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt));
-                    xmask = 0;
-                    --q;
-                    after_drop = true;
-                }
-            }
-        }
-        QR_TS(5);
-        if (wv != 0) return;
-        if (handoff) {
-            // wave 0 carries on alone: working-set tables of the single-wave loop from the per-lane registers
-            if (lane < q) sAct[lane] = 6 * ck + ct;
-            if (own) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) sPos[6 * lane + t] = ((amask >> t) & 1u) ? (short)((posk >> (8 * t)) & 0x3full) : (short)-1;
-            }
-            h_x0 = x0; h_x1 = x1; h_x2 = x2; h_u0 = (lane < q) ? uq : 0.0; h_amask = amask; h_q = q; h_iter = iter;
-            wave_sync();
-        } else {
-            // ---- phase 6 (wave 0): stage the first-step forces through LDS, then the shared output code below
-            wave_sync();
-            if (lane < 12) xz[lane] = 0.0;
-            wave_sync();
-            if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
-            wave_sync();
-            mpc_outputs(lane, rid, n, xz, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
-            if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
-            if (lane == 0 && (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
-            QR_TS(6);
-#ifndef QR_TRACE
-            if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
-#endif
-            return;
-        }
     }
-    if (tid >= 64) return;          // phases 4-6 are a single wavefront; no workgroup barrier below
-
-    // ---------------- phase 4: x = -M g  (lane k owns leg-step k) ----------------
-    const bool own = lane < nls;
-    const int kme = own ? lane : 0;
-    double x0 = h_x0, x1 = h_x1, x2 = h_x2;
-    if (own && !handoff) {
-        for (int kc = 0; kc < nls; ++kc) {
-            Blk B; load_block(Mb, kme, kc, B);
-            const double g0 = gl[3 * kc], g1 = gl[3 * kc + 1], g2 = gl[3 * kc + 2];
-            x0 -= B.m[0] * g0 + B.m[1] * g1 + B.m[2] * g2;
-            x1 -= B.m[3] * g0 + B.m[4] * g1 + B.m[5] * g2;
-            x2 -= B.m[6] * g0 + B.m[7] * g1 + B.m[8] * g2;
-        }
-    }
-    if (!handoff) QR_TS(4);
-    if (handoff) qcap = qcap_full;                    // the four-wave loop had clamped it to its 64 lanes
-
-    // ---------------- phase 5: dual active set (wave 0) ----------------
-    const double im = (double)(1.f / C.mu);          // mu_ (:230) as fmat holds it
-    const double fmaxk = own ? fmk[kme] : 0.0;
-    const int tril = tri(lane);
-    const double tol = 1e-9;
-    const double INF = __builtin_inf();
-    long long acc_t[6] = {0, 0, 0, 0, 0, 0}; long long tq0 = 0;
-#define QR_STAMP(i) do { if (dbgT) { const long long t_ = clock64(); acc_t[i] += t_ - tq0; tq0 = t_; } } while (0)
-    int q = h_q, iter = h_iter;
-    unsigned amask = h_amask;                         // active rows of my leg-step (6 bits)
-    unsigned xmask = 0;                               // rows found numerically dependent on the working set (skipped until the set changes)
-    double u0 = h_u0, u1 = 0.0;                       // multipliers of working-set positions lane, lane+64
-    const int maxit = 40 * nls + 100;
-    bool done = (nls == 0);
-    while (!done) {
-        if (dbgT) tq0 = clock64();
-        // step 1: most violated inactive row (ties -> lowest id)
-        double bs = INF; int bt = 0;
-        if (own) {
-            const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) if (!(((amask | xmask) >> t) & 1u) && s[t] < bs) { bs = s[t]; bt = t; }
-        }
-        const double smin = wave_min_d(bs);
-        if (!(smin < -tol)) {
-            double be = 0.0;                           // as in the four-wave path: excluded rows hold, active rows are tight
-            if (own && (xmask | amask)) {
-                const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    if (((xmask >> t) & 1u) && s[t] < be) be = s[t];
-                    if (((amask >> t) & 1u) && -__builtin_fabs(s[t]) < be) be = -__builtin_fabs(s[t]);
-                }
-            }
-            if (wave_min_d(be) < -1e-4) st |= QRGPU_ST_MPC_INFEAS_D;
-            break;
-        }
-        const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
-        const int tp = __builtin_amdgcn_readlane(bt, kp);
-        const int p = 6 * kp + tp;
-        double c0, c1, c2;
-        cons_vec(tp, im, c0, c1, c2);
-        const double ci0p = (tp == 5) ? readlane_d(fmaxk, kp) : 0.0;
-        double up = 0.0;
-        QR_STAMP(0);
-        for (;;) {
-            q = __builtin_amdgcn_readfirstlane(q);           // q is wave-uniform by construction; tell the compiler
-            if (++iter > maxit) { st |= QRGPU_ST_MPC_MAXITER_D; done = true; break; }
-            // w_k = M_{k,kp} c_p
-            double w0 = 0.0, w1 = 0.0, w2_ = 0.0;
-            if (own) {
-                Blk B; load_block(Mb, kme, kp, B);
-                w0 = B.m[0] * c0 + B.m[1] * c1 + B.m[2] * c2;
-                w1 = B.m[3] * c0 + B.m[4] * c1 + B.m[5] * c2;
-                w2_ = B.m[6] * c0 + B.m[7] * c1 + B.m[8] * c2;
-                wl[3 * kme] = w0; wl[3 * kme + 1] = w1; wl[3 * kme + 2] = w2_;
-            }
-            const double delta = c0 * readlane_d(w0, kp) + c1 * readlane_d(w1, kp) + c2 * readlane_d(w2_, kp);
-            wave_sync();
-            QR_STAMP(1);
-            // d = N' w  (position i lives in lane i & 63, slot i >> 6)
-            double d0 = 0.0, d1 = 0.0;
-            {
-                if (lane < q) { const int cj = sAct[lane]; const int kj = cj / 6; double a0, a1, a2; cons_vec(cj - 6 * kj, im, a0, a1, a2);
-                                d0 = a0 * wl[3 * kj] + a1 * wl[3 * kj + 1] + a2 * wl[3 * kj + 2]; }
-                if (q > 64 && lane + 64 < q) { const int cj = sAct[lane + 64]; const int kj = cj / 6; double a0, a1, a2; cons_vec(cj - 6 * kj, im, a0, a1, a2);
-                                     d1 = a0 * wl[3 * kj] + a1 * wl[3 * kj + 1] + a2 * wl[3 * kj + 2]; }
-            }
-            // r = S^-1 d.  Lane i owns position i (and i + 64 in the rare q > 64 case).  S^-1 is packed lower:
-            // (i, j) at tri(i) + j for j <= i, else tri(j) + i.  Four loads are issued before they are consumed.
-            double r0 = 0.0, r1 = 0.0;
-            {
-                const int q0 = q < 64 ? q : 64;
-                const int i0 = (lane < q) ? lane : 0;
-                int j = 0;
-                for (; j + 4 <= q0; j += 4) {
-                    double sv[4], dj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int jj = j + u;
-                        sv[u] = Sinv[(jj <= i0) ? tril + jj : tri(jj) + i0];
-                        dj[u] = readlane_d(d0, jj);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) r0 += sv[u] * dj[u];
-                }
-                for (; j < q0; ++j) r0 += Sinv[(j <= i0) ? tril + j : tri(j) + i0] * readlane_d(d0, j);
-                if (lane >= q) r0 = 0.0;
-                if (q > 64) {                     // cold path: positions 64..q-1
-                    const int i1 = lane + 64;
-                    for (int jj = 64; jj < q; ++jj) { const double dj = readlane_d(d1, jj - 64); if (lane < q) r0 += Sinv[pidx(lane, jj)] * dj; }
-                    for (int jj = 0; jj < q; ++jj) {
-                        const double dj = (jj < 64) ? readlane_d(d0, jj) : readlane_d(d1, jj - 64);
-                        if (i1 < q) r1 += Sinv[pidx(i1, jj)] * dj;
-                    }
-                }
-            }
-            QR_STAMP(2);
-            const double dr = wave_sum_d(r0 * d0 + r1 * d1);
-            const double zc = delta - dr;                    // z'c_p
-            // dual step length: min u_j / r_j over r_j > 0
-            double tt = INF;
-            if (lane < q && r0 > 0.0) tt = u0 * fast_rcp(r0);
-            double tt1 = INF;
-            if (q > 64 && lane + 64 < q && r1 > 0.0) tt1 = u1 * fast_rcp(r1);
-            const double t1 = wave_min_d(fmin(tt, tt1));
-            int lpos = -1;
-            if (t1 < INF) {
-                const int la = first_lane(tt == t1);
-                lpos = (la >= 0) ? la : 64 + first_lane(tt1 == t1);
-            }
-            const double sp = c0 * readlane_d(x0, kp) + c1 * readlane_d(x1, kp) + c2 * readlane_d(x2, kp) + ci0p;
-            const bool have_z = zc > 1e-13 * delta;
-            const double izc = fast_rcp(zc);
-            const double t2 = have_z ? -sp * izc : INF;
-            const double t = t1 < t2 ? t1 : t2;
-            if (!(t < INF)) {
-                // The row is (numerically) in the span of the working set and no multiplier blocks: u = 0 is always
-                // feasible, so this is a degenerate corner (e.g. f = 0 with five rows on three unknowns), its violation
-                // is rounding.  Leave it out until the working set changes (what QuadProg++ does, QuadProg++.cc "iaexcl").
-                if (lane == kp) xmask |= 1u << tp;
-                break;
-            }
-            QR_STAMP(3);
-            if (have_z) {
-                // y_k = sum of active rows of my leg-step times r;  z = w - M y;  x += t z
-                if (lane < q) rl[lane] = r0;
-                if (q > 64 && lane + 64 < q) rl[lane + 64] = r1;
-                wave_sync();
-                double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-                if (own && amask) {
-#pragma unroll
-                    for (int tq = 0; tq < 6; ++tq)
-                        if ((amask >> tq) & 1u) {
-                            const double rr = rl[sPos[6 * kme + tq]];
-                            double a0, a1, a2; cons_vec(tq, im, a0, a1, a2);
-                            y0 += a0 * rr; y1 += a1 * rr; y2 += a2 * rr;
-                        }
-                }
-                unsigned long long km = __ballot(own && amask != 0);
-                double z0 = w0, z1 = w1, z2 = w2_;
-                while (km) {
-                    const int kc = (int)__builtin_ctzll(km);
-                    km &= km - 1;
-                    int kc2 = -1;
-                    if (km) { kc2 = (int)__builtin_ctzll(km); km &= km - 1; }
-                    Blk B, B2;
-                    load_block(Mb, kme, kc, B);
-                    load_block(Mb, kme, kc2 >= 0 ? kc2 : kc, B2);
-                    const double q0 = readlane_d(y0, kc), q1 = readlane_d(y1, kc), q2 = readlane_d(y2, kc);
-                    const int kr = kc2 >= 0 ? kc2 : 0;
-                    const double sc = kc2 >= 0 ? 1.0 : 0.0;
-                    const double p0 = sc * readlane_d(y0, kr), p1 = sc * readlane_d(y1, kr), p2 = sc * readlane_d(y2, kr);
-                    z0 -= (B.m[0] * q0 + B.m[1] * q1 + B.m[2] * q2) + (B2.m[0] * p0 + B2.m[1] * p1 + B2.m[2] * p2);
-                    z1 -= (B.m[3] * q0 + B.m[4] * q1 + B.m[5] * q2) + (B2.m[3] * p0 + B2.m[4] * p1 + B2.m[5] * p2);
-                    z2 -= (B.m[6] * q0 + B.m[7] * q1 + B.m[8] * q2) + (B2.m[6] * p0 + B2.m[7] * p1 + B2.m[8] * p2);
-                }
-                x0 += t * z0; x1 += t * z1; x2 += t * z2;
-            }
-            QR_STAMP(4);
-            u0 -= t * r0; u1 -= t * r1;
-            up += t;
-            if (have_z && t == t2) {
-                // full step: p joins the working set; bordered update of S^-1
-                if (q >= qcap) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }
-                const double isg = izc;
-                {
-                    // row i of the lower triangle belongs to lane i: S^-1(i, j) += r_i r_j / sigma for j <= i
-                    const int q0 = q < 64 ? q : 64;
-                    const bool act0 = lane < q;
-                    const double ri = r0 * isg;
-                    int j = 0;
-                    for (; j + 4 <= q0; j += 4) {
-                        double sv[4], rj[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { rj[u] = readlane_d(r0, j + u); sv[u] = (act0 && j + u <= lane) ? Sinv[tril + j + u] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) if (act0 && j + u <= lane) Sinv[tril + j + u] = sv[u] + ri * rj[u];
-                    }
-                    for (; j < q0; ++j) { const double rj = readlane_d(r0, j); if (act0 && j <= lane) Sinv[tril + j] += ri * rj; }
-                    if (q > 64) {                 // cold path
-                        const int i1 = lane + 64;
-                        for (int jj = 0; jj < q; ++jj) {
-                            const double rj = ((jj < 64) ? readlane_d(r0, jj) : readlane_d(r1, jj - 64)) * isg;
-                            if (i1 < q && jj <= i1) Sinv[tri(i1) + jj] += r1 * rj;
-                        }
-                        if (i1 < q) Sinv[tri(q) + i1] = -r1 * isg;
-                    }
-                    if (act0) Sinv[tri(q) + lane] = -r0 * isg;
-                }
-                if (lane == 0) { Sinv[tri(q) + q] = isg; sAct[q] = p; sPos[p] = (short)q; }
-                if (lane == (q & 63)) { if (q < 64) u0 = up; else u1 = up; }
-                if (lane == kp) amask |= 1u << tp;
-                xmask = 0;
-                ++q;
-                wave_sync();
-                QR_STAMP(5);
-                break;
-            }
-            // partial or dual-only step: the constraint at lpos leaves; downdate S^-1, move the last one into its slot
-            {
-                const int l = lpos, last = q - 1;
-                double s0 = 0.0, s1 = 0.0;                    // column l of S^-1
-                if (lane < q) s0 = Sinv[pidx(lane, l)];
-                if (lane + 64 < q) s1 = Sinv[pidx(lane + 64, l)];
-                const double isl = fast_rcp((l < 64) ? readlane_d(s0, l) : readlane_d(s1, l - 64));
-                wave_sync();
-                {
-                    const int i0 = lane, i1 = lane + 64;
-                    for (int j = 0; j < q; ++j) {
-                        if (j == l) continue;
-                        const double sj = ((j < 64) ? readlane_d(s0, j) : readlane_d(s1, j - 64)) * isl;
-                        if (i0 < q && i0 != l && j <= i0) Sinv[tri(i0) + j] -= s0 * sj;
-                        if (i1 < q && i1 != l && j <= i1) Sinv[tri(i1) + j] -= s1 * sj;
-                    }
-                }
-                wave_sync();
-                const int cl = sAct[l], clast = sAct[last];
-                if (l != last) {
-                    double m0 = 0.0, m1 = 0.0;
-                    if (lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
-                    if (lane + 64 < last) m1 = (lane + 64 == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane + 64)];
-                    wave_sync();
-                    if (lane < last) Sinv[pidx(l, lane)] = m0;
-                    if (lane + 64 < last) Sinv[pidx(l, lane + 64)] = m1;
-                    const double ulast = (last < 64) ? readlane_d(u0, last) : readlane_d(u1, last - 64);
-                    if (lane == (l & 63)) { if (l < 64) u0 = ulast; else u1 = ulast; }
-                }
-                wave_sync();
-                if (lane == 0) {
-                    sPos[cl] = -1;
-                    if (l != last) { sAct[l] = clast; sPos[clast] = (short)l; }
-                }
-                if (lane == cl / 6) amask &= ~(1u << (cl - 6 * (cl / 6)));
-                xmask = 0;
-                --q;
-                wave_sync();
-            }
-        }
-    }
-    QR_TS(5);
-
-    // ---------------- phase 6: outputs ----------------
-    // f(axis,leg) = q_soln[3*leg+axis] for horizon step 0 (GetMPCSolution, :446-451); swing legs are 0.
-    if (lane < 12) yl[lane] = 0.0;
-    wave_sync();
-    if (own) { const int ls = sLs[kme]; if (ls < 4) { yl[3 * ls] = x0; yl[3 * ls + 1] = x1; yl[3 * ls + 2] = x2; } }
-    wave_sync();
-    mpc_outputs(lane, rid, n, yl, R, sJ, C, g_q, g_force, g_force_wbc, force_stride, g_tau, P.epilogue);
-    if (lane == 0 && g_status) g_status[rid] = st | ((iter & 0xffff) << 8);
-    if (tid == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
-    QR_TS(6);
-#ifndef QR_TRACE
-    if (lane == 0 && dbgT) { dbgT[(size_t)rid * 16 + 7] = ns; for (int i = 0; i < 6; ++i) dbgT[(size_t)rid * 16 + 8 + i] = acc_t[i]; dbgT[(size_t)rid * 16 + 14] = q; }
-#endif
 }
 
-#define QR_MPC_INST(MAXB, MULTI, TAG)                                                                                                 \
-    template __global__ void qr_mpc_kernel<MAXB, MULTI, TAG>(MpcLaunch, const int *, const float *, const float *, const float *, const float *, \
-                                                             float *, float *, int *, float *, float *, float *, int, long long *);
-QR_MPC_INST(4, true, 0)
-QR_MPC_INST(4, true, 1)
-QR_MPC_INST(9, true, 0)
-QR_MPC_INST(9, false, 0)
+// Launch wrappers (one inlined copy of the solve each).
+//   LIST = false, main pass: workgroup b solves the robot of slot xcd_robot_index(b) (through the longest-first order when there is one);
+//   LIST = true:  workgroups 0-7 first sort the next call's dispatch order, then workgroup b re-solves entries b, b + grid, b + 2 grid ...
+//                 of the rescue list (robots whose working set outgrew the main pass's registers or LDS) with this launch's larger LDS
+//                 allotment and the BIG register set.
+template <int MAXB, bool BIG, bool LIST>
+__global__ __launch_bounds__(QR_MPC_THREADS, ((MAXB <= 4 && !LIST) ? 2 : 1))
+void qr_mpc_kernel(MpcLaunch P, MpcIO io)
+{
+    extern __shared__ double smem[];
+    if constexpr (LIST) {
+        if (P.lpt_order_out && blockIdx.x < 8) {       // the histogram borrows the head of the dynamic LDS before a solve carves it
+            lpt_order_chunk(blockIdx.x, P.n, P.lpt_cost_in, P.lpt_order_out, (int *)smem);
+            __syncthreads();
+        }
+        int cnt = P.rescue_count[P.rescue_parity];
+        cnt = cnt < P.n ? cnt : P.n;
+        for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+            mpc_solve_robot<MAXB, BIG>(P, io, P.rescue_list[e], smem);
+            __syncthreads();                           // every wave is out of the solve before the LDS is carved again
+        }
+    } else {
+        const int slot = xcd_robot_index(blockIdx.x, P.n);
+        if (slot < 0) return;
+        if (P.rescue_count && blockIdx.x == 0 && threadIdx.x == 0) P.rescue_count[P.rescue_parity ^ 1] = 0;     // the next call's counter
+        mpc_solve_robot<MAXB, BIG>(P, io, P.order ? P.order[slot] : slot, smem);       // same XCD chunk either way (the order permutes inside a chunk)
+    }
+}
+
+template __global__ void qr_mpc_kernel<4, false, false>(MpcLaunch, MpcIO);     // h <= 11, main pass
+template __global__ void qr_mpc_kernel<4, true, true>(MpcLaunch, MpcIO);       // h <= 11, rescue list (whole CU's LDS, 96 rows)
+template __global__ void qr_mpc_kernel<9, true, false>(MpcLaunch, MpcIO);      // h <= 16
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

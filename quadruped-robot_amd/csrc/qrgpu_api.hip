@@ -13,17 +13,19 @@
 #include "qrgpu_ctx.h"
 
 namespace qrgpu {
-template <int MAXB, bool MULTI, int TAG>
-__global__ void qr_mpc_kernel(MpcLaunch P, const int *type_id, const float *g_state, const float *g_traj, const float *g_gait,
-                              const float *g_q, float *g_force, float *g_tau, int *g_status, float *dbgH, float *dbgG,
-                              float *g_force_wbc, int force_stride, long long *dbgT);
-#define QR_MPC_DECL(MAXB, MULTI, TAG)                                                                                                             \
-    extern template __global__ void qr_mpc_kernel<MAXB, MULTI, TAG>(MpcLaunch, const int *, const float *, const float *, const float *,         \
-                                                               const float *, float *, float *, int *, float *, float *, float *, int, long long *);
-QR_MPC_DECL(4, true, 0)
-QR_MPC_DECL(4, true, 1)
-QR_MPC_DECL(9, true, 0)
-QR_MPC_DECL(9, false, 0)
+struct MpcIO {
+    const int *type_id;
+    const float *g_state, *g_traj, *g_gait, *g_q;
+    float *g_force, *g_tau;
+    int *g_status;
+    float *dbgH, *dbgG, *g_force_wbc;
+    int force_stride;
+    long long *dbgT;
+};
+template <int MAXB, bool BIG, bool LIST> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
+extern template __global__ void qr_mpc_kernel<4, false, false>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<4, true, true>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<9, true, false>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -39,19 +41,11 @@ __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, 
                               const float *g_fr, int type_ready, int epilogue);
 }
 
-// h > 11: the four-wave active set is the default; a working set that reaches its 64 lanes is handed over in place to the single-wave
-// loop (up to 96 rows), so no rescue launch is needed there.  QRGPU_H16_SINGLE=1 selects the single-wave variant for the whole solve.
-static bool mpc_h16_single()
-{
-    static const bool v = [] { const char *e = getenv("QRGPU_H16_SINGLE"); return e && e[0] == '1'; }();
-    return v;
-}
-
 static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h)
 {
     // Packed inverse Hessian for the all-stance worst case plus room for S^-1; two workgroups
     // per CU when that fits in half the LDS, otherwise the whole CU.
-    const size_t fixed = mpc_lds_fixed_bytes(h, 4 * h <= 44 || !mpc_h16_single());
+    const size_t fixed = mpc_lds_fixed_bytes(h, true);
     const size_t nmax = 12 * (size_t)h;
     const size_t mp = 8 * (nmax * (nmax + 1) / 2);
     const size_t want = fixed + mp + 8 * (size_t)(24 * 25 / 2);     // at least a 24-row S^-1 in the worst case
@@ -195,7 +189,8 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_st1, 4 * sizeof(int)) != hipSuccess || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
         hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
@@ -219,6 +214,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_order) hipFree(c->d_order);
     if (c->d_cost) hipFree(c->d_cost);
     if (c->d_rescue) hipFree(c->d_rescue);
+    if (c->d_warm) hipFree(c->d_warm);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
 }
@@ -228,6 +224,13 @@ int qrgpu_set_lpt_schedule(qrgpu_ctx *c, int on)
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->lpt = on != 0;
     c->lpt_n = 0;
+    return QRGPU_OK;
+}
+int qrgpu_set_warm_start(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->warm = on != 0;
+    c->warm_n = 0;                 // forget what is stored
     return QRGPU_OK;
 }
 int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
@@ -298,6 +301,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.n = n;
     P.type_ready = ready_mask(c->mpc_ready);
     P.epilogue = epilogue;
+    // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
+    P.warm = (c->warm && !dH) ? c->d_warm : nullptr;
+    if (P.warm && c->warm_n != n) {
+        HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, c->stream));
+        c->warm_n = n;
+    }
     P.lds_bytes = mpc_lds_bytes(c, P.horizon);
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
@@ -311,59 +320,47 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         P.sinv_spill = c->d_sinv_spill;
     }
     // rescue pass for the four-wave variants (not for inspection launches or single-robot calls through the staging buffers)
-    const bool rescue = c->rescue && !dH && small;          // h > 11 hands over in place instead
+    const bool rescue = c->rescue && !dH && small;          // the h > 11 variant holds 96 rows itself
     P.rescue_mode = 0;
     P.rescue_count = rescue ? c->d_rescue : nullptr;
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
-    // kernel variant: 0 = <4, four-wave>, 1 = <9, four-wave with in-place hand-over>, 2 = <9, single-wave> (QRGPU_H16_SINGLE=1)
-    const int var = small ? 0 : (mpc_h16_single() ? 2 : 1);
-    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, true, 0> : var == 1 ? (const void *)qr_mpc_kernel<9, true, 0> : (const void *)qr_mpc_kernel<9, false, 0>;
+    // kernel variant: 0 = <4 blocks per thread> (h <= 11), 1 = <9, positions 64..95 in a second register set> (h <= 16)
+    const int var = small ? 0 : 1;
+    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, false, false> : (const void *)qr_mpc_kernel<9, true, false>;
     if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
         c->configured_lds[var] = P.lds_bytes;
     }
+    MpcIO io;
+    io.type_id = d_type; io.g_state = d_state; io.g_traj = d_traj; io.g_gait = d_gait; io.g_q = d_q; io.g_force = d_force; io.g_tau = d_tau;
+    io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
     {
         TimerScope ts(c, 0);
         const dim3 grid(8 * ((n + 7) / 8)), block(256);
-        long long *dbg = (long long *)c->d_dbg_cycles;
-        if (var == 0)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, true, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
-                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
-        else if (var == 1)
-            hipLaunchKernelGGL((qr_mpc_kernel<9, true, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
-                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
-        else
-            hipLaunchKernelGGL((qr_mpc_kernel<9, false, 0>), grid, block, (size_t)P.lds_bytes, c->stream, P, d_type, d_state, d_traj, d_gait, d_q, d_force,
-                               d_tau, d_status, dH, dG, d_force_wbc, 51, dbg);
+        if (var == 0) hipLaunchKernelGGL((qr_mpc_kernel<4, false, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, io);
+        else hipLaunchKernelGGL((qr_mpc_kernel<9, true, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, io);
     }
     HIPCHK(c, hipGetLastError());
     if (rescue) {
-        // re-solve the robots whose working set outgrew the four-wave path (normally none: the workgroups exit at once)
+        // list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's dispatch
+        // order and exit) are re-solved with the whole CU's LDS and 96 working-set positions; workgroup b takes entries b, b + 64, ...
         MpcLaunch R = P;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
-        // list capacity served per call: 64 robots.  (It used to grow to n / 16, but workgroups that ask for a whole CU's LDS are dispatched
-        // one every ~2 us: the empty pass cost 0.55 ms at 4096 robots, 1.3 ms at 16384.)
-        int rgrid = small ? 64 : c->num_cu;
-        if (rgrid > n) rgrid = n;
-        // h <= 11: the multi-wave variant again, now with the whole CU's LDS (64 rows and the W_A cache even for an all-stance robot; it
-        // hands over to its single-wave tail beyond 64 rows) -- three times faster than re-solving in the single-wave variant
-        const void *rfn = small ? (const void *)qr_mpc_kernel<4, true, 1> : (const void *)qr_mpc_kernel<9, false, 0>;
-        int &conf = c->configured_rescue[small ? 0 : 1];
-        if (conf < R.lds_bytes) {
-            HIPCHK(c, hipFuncSetAttribute(rfn, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
-            conf = R.lds_bytes;
+        // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
+        // empty pass at 4096 robots)
+        int rgrid = 64 < n ? 64 : n;
+        if (rgrid < 8 && lpt) rgrid = 8;
+        if (c->configured_rescue[0] < R.lds_bytes) {
+            HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
+            c->configured_rescue[0] = R.lds_bytes;
         }
-        if (small)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, true, 1>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
-                               d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
-        else
-            hipLaunchKernelGGL((qr_mpc_kernel<9, false, 0>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, d_type, d_state, d_traj, d_gait, d_q,
-                               d_force, d_tau, d_status, nullptr, nullptr, d_force_wbc, 51, nullptr);
+        io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
+        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
         HIPCHK(c, hipGetLastError());
         c->rescue_parity ^= 1;
     }

@@ -38,6 +38,9 @@ struct qrgpu_ctx {
     bool lpt = true;
     bool rescue = true;
     int epilogue = 0;             // QRGPU_EPILOGUE_* bits
+    bool warm = true;             // warm start of the MPC active set from the slot's previous solve
+    unsigned char *d_warm = nullptr;   // [max_batch][QR_WARM_STRIDE]
+    int warm_n = 0;               // batch size d_warm is valid for (0 = nothing yet)
     float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
     void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)

@@ -29,6 +29,7 @@ def replay(ctx, log, stateful=False, first=0, count=None, to_soa=None):
     worst_f = worst_t = 0.0
     flagged = rec_flagged = 0
     per_tick = []
+    ctx.set_warm_start(False)        # a log replays onto itself bit for bit only when no solve depends on the solves before it
     try:
         for k in range(first, last):
             t = log.tick(k)
@@ -49,6 +50,7 @@ def replay(ctx, log, stateful=False, first=0, count=None, to_soa=None):
             worst_f, worst_t = max(worst_f, f_k), max(worst_t, t_k)
             per_tick.append((f_k, t_k, int(bad.sum())))
     finally:
+        ctx.set_warm_start(True)
         for v in d.values():
             v.free()
     return dict(ticks=last - first, robot_ticks=(last - first) * n, worst_force=worst_f, worst_tau=worst_t, flagged=flagged,
@@ -63,6 +65,7 @@ def record(ctx, path, batches, mpc_cfg, model6, robot="", to_soa=None):
     n, h = b0["n"], b0["horizon"]
     d = dict(state=ctx.alloc((28, n)), traj=ctx.alloc((12 * h, n)), gait=ctx.alloc((4 * h, n)), fb=ctx.alloc((37, n)), cmd=ctx.alloc((67, n)),
              prev=ctx.alloc((3, n)), force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
+    ctx.set_warm_start(False)        # (see replay)
     try:
         d["prev"].upload(to_soa(b0["prev_ori_vel"]))
         with ticklog.TickLogWriter(path, n, h, mpc_cfg, ticklog.model15(model6), robot) as w:
@@ -74,5 +77,6 @@ def record(ctx, path, batches, mpc_cfg, model6, robot="", to_soa=None):
                 ctx.sync()
                 w.append(dict(b, prev_ori_vel=prev_before), d["force"].download().T, d["tau"].download().T, d["status"].download())
     finally:
+        ctx.set_warm_start(True)
         for v in d.values():
             v.free()

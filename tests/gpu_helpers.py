@@ -1,5 +1,18 @@
 """Shared helpers for the -m gpu parity tests: upload a workload batch, run the C-ABI, download."""
+import contextlib
+
 import numpy as np
+
+
+@contextlib.contextmanager
+def cold_start(ctx):
+    """Warm start off inside the block: every solve starts from the empty working set, so that two calls on the same inputs return the
+    same bits whatever was solved in between (with it on they agree to the solver's tolerance, and the iteration counts differ)."""
+    ctx.set_warm_start(False)
+    try:
+        yield ctx
+    finally:
+        ctx.set_warm_start(True)
 
 
 def run_mpc(ctx, pkg, b, with_tau=True, type_id=None):

@@ -203,8 +203,9 @@ def test_tick_without_tail_is_unchanged_by_projection(gpu_ctx, pkg):
     """K12's outputs do not enter the torque: the tick with and without d_qdes returns the same bits."""
     G.setup_a1(gpu_ctx, pkg, 10)
     b = pkg.make_batch(64, 10, "a1", seed=77)
-    a = G.run_tick(gpu_ctx, pkg, b, want_qdes=False)
-    c = G.run_tick(gpu_ctx, pkg, b, want_qdes=True)
+    with G.cold_start(gpu_ctx):
+        a = G.run_tick(gpu_ctx, pkg, b, want_qdes=False)
+        c = G.run_tick(gpu_ctx, pkg, b, want_qdes=True)
     assert np.array_equal(a["tau"], c["tau"]) and np.array_equal(a["force"], c["force"])
 
 
@@ -237,6 +238,7 @@ def test_unknown_type_is_flagged(gpu_ctx, pkg):
         ctx2.close()
     bad = (out["status"] & 0x01000000) != 0
     assert np.array_equal(bad, tid != 0)
-    ref = G.run_tick(gpu_ctx, pkg, b)
+    with G.cold_start(gpu_ctx):
+        ref = G.run_tick(gpu_ctx, pkg, b)
     assert np.array_equal(out["tau"][~bad], ref["tau"][~bad])
     assert np.all(np.isfinite(out["tau"]))
