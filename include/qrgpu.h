@@ -152,6 +152,12 @@ int  qrgpu_set_lpt_schedule(qrgpu_ctx *ctx, int on);
  * with a cold start to the solver's tolerance (1e-9 relative) -- not bit for bit: switch it off where run-to-run bit identity across a
  * changing history matters.  Turning it on or off forgets what is stored. */
 int  qrgpu_set_warm_start(qrgpu_ctx *ctx, int on);
+/* Planned list of the batched MPC solve (default on, big_nls = 0): a robot that needed the rescue pass in one call -- or ended within a few
+ * rows of the main pass's LDS allotment -- is solved in the NEXT call with the same n by a list launch of its own (whole CU's LDS, 96
+ * working-set positions), issued at the start of the call on a second stream of the context beside the main launch, which skips it: the
+ * batch no longer waits for a re-solve after the main launch.  big_nls > 0 additionally sends every robot with at least that many stance
+ * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling only: which launch solves a robot does not change its result. */
+int  qrgpu_set_planned_list(qrgpu_ctx *ctx, int on, int big_nls);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
  * Hessian at h = 10 leaves room for 56 rows): they are re-solved by the same kernel with the whole CU's LDS in a second, normally

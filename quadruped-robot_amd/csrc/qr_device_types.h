@@ -56,7 +56,16 @@ struct MpcLaunch {
     int *rescue_count;
     int *rescue_list;
     int rescue_parity;
-    int rescue_mode;
+    int rescue_mode;            // 0 main pass, 1 trailing list launch (rescue list + planning), 2 planned list launch
+    // Planned list (DESIGN.md "tail"): robots that needed the list pass in the last call (or came within a few rows of the main pass's LDS
+    // allotment, or belong to the big class nls >= big_nls) are solved by a list launch of their own, issued on a second stream AT THE
+    // START of the next call, beside the main launch (which skips them), instead of after it.  pre_list / pre_count[parity] / skip[robot] are
+    // written by the trailing list launch's planning workgroups from the `big` bit each solve leaves in cost[robot] (bit 8).
+    int *pre_count;
+    int *pre_list;
+    unsigned char *skip;
+    int big_nls;                // 0 = no class rule
+    int lds_main;               // the main pass's LDS allotment (bytes), for the `big` decision of a solve that runs in a list launch
     // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
     const int *lpt_cost_in;
     int *lpt_order_out;

@@ -1293,7 +1293,20 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         mpc_outputs(lane, rid, n, xz, R, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
         if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
         if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-        if (lane == 0 && P.cost) { const long long c = (clock64() - t_begin) >> 12; P.cost[rid] = c > 255 ? 255 : (int)c; }
+        if (lane == 0 && P.cost) {
+            const long long c = (clock64() - t_begin) >> 12;
+            int big = 0;
+            if (P.pre_list) {
+                // does this robot belong in the planned list next time?  It overflowed, or ended within six rows of what the main pass's LDS
+                // holds for its size, or is of the big class
+                const long long remm = (long long)(P.lds_main / 8) - (long long)(Mb - smem) - (long long)npairs * 9;
+                int qcm = 0;
+                if (remm > 0) { qcm = (int)((__builtin_sqrt(8.0 * (double)remm + 1.0) - 1.0) * 0.5); while (tri(qcm) > remm) --qcm; }
+                if (qcm > 64) qcm = 64;
+                big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + 6 >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
+            }
+            P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8);
+        }
         QR_TS(6);
 #ifndef QR_TRACE
         if (lane == 0 && io.dbgT) { io.dbgT[(size_t)rid * 16 + 7] = ns; io.dbgT[(size_t)rid * 16 + 14] = q; }
@@ -1315,21 +1328,40 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
     if constexpr (LIST) {
-        if (P.lpt_order_out && blockIdx.x < 8) {       // the histogram borrows the head of the dynamic LDS before a solve carves it
-            lpt_order_chunk(blockIdx.x, P.n, P.lpt_cost_in, P.lpt_order_out, (int *)smem);
-            __syncthreads();
+        const bool planned = P.rescue_mode == 2;
+        if (!planned && blockIdx.x < 8) {
+            if (P.lpt_order_out) {                     // the histogram borrows the head of the dynamic LDS before a solve carves it
+                lpt_order_chunk(blockIdx.x, P.n, P.lpt_cost_in, P.lpt_order_out, (int *)smem);
+                __syncthreads();
+            }
+            if (P.pre_list && P.skip && P.lpt_cost_in) {
+                // plan the next call: robots whose solve left the `big` bit go on the planned list and are skipped by the main pass
+                const int chunk = (P.n + 7) >> 3, lo = blockIdx.x * chunk, hi = (lo + chunk < P.n) ? lo + chunk : P.n;
+                for (int i = lo + threadIdx.x; i < hi; i += QR_MPC_THREADS) {
+                    const int big = (P.lpt_cost_in[i] >> 8) & 1;
+                    P.skip[i] = (unsigned char)big;
+                    if (big) P.pre_list[atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 1)] = i;
+                }
+                __syncthreads();
+            }
         }
-        int cnt = P.rescue_count[P.rescue_parity];
+        const int *list = planned ? P.pre_list : P.rescue_list;
+        int cnt = planned ? P.pre_count[P.rescue_parity] : P.rescue_count[P.rescue_parity];
         cnt = cnt < P.n ? cnt : P.n;
         for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-            mpc_solve_robot<MAXB, BIG>(P, io, P.rescue_list[e], smem);
+            mpc_solve_robot<MAXB, BIG>(P, io, list[e], smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
     } else {
         const int slot = xcd_robot_index(blockIdx.x, P.n);
         if (slot < 0) return;
-        if (P.rescue_count && blockIdx.x == 0 && threadIdx.x == 0) P.rescue_count[P.rescue_parity ^ 1] = 0;     // the next call's counter
-        mpc_solve_robot<MAXB, BIG>(P, io, P.order ? P.order[slot] : slot, smem);       // same XCD chunk either way (the order permutes inside a chunk)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
+            if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
+            if (P.pre_count) P.pre_count[P.rescue_parity ^ 1] = 0;
+        }
+        const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+        if (P.skip && P.skip[rid]) return;             // solved by the planned list launch, beside this one
+        mpc_solve_robot<MAXB, BIG>(P, io, rid, smem);
     }
 }
 

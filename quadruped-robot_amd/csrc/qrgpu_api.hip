@@ -190,7 +190,10 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess) {
+        hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
@@ -215,6 +218,11 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_cost) hipFree(c->d_cost);
     if (c->d_rescue) hipFree(c->d_rescue);
     if (c->d_warm) hipFree(c->d_warm);
+    if (c->d_pre) hipFree(c->d_pre);
+    if (c->d_skip) hipFree(c->d_skip);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
 }
@@ -224,6 +232,7 @@ int qrgpu_set_lpt_schedule(qrgpu_ctx *c, int on)
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->lpt = on != 0;
     c->lpt_n = 0;
+    c->plan_n = 0;
     return QRGPU_OK;
 }
 int qrgpu_set_warm_start(qrgpu_ctx *c, int on)
@@ -233,10 +242,19 @@ int qrgpu_set_warm_start(qrgpu_ctx *c, int on)
     c->warm_n = 0;                 // forget what is stored
     return QRGPU_OK;
 }
+int qrgpu_set_planned_list(qrgpu_ctx *c, int on, int big_nls)
+{
+    if (!c || big_nls < 0) return QRGPU_ERR_BAD_ARG;
+    c->planned = on != 0;
+    c->big_nls = big_nls;
+    c->plan_n = 0;
+    return QRGPU_OK;
+}
 int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->rescue = on != 0;
+    c->plan_n = 0;
     return QRGPU_OK;
 }
 int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; return QRGPU_OK; }
@@ -327,6 +345,17 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
+    // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
+    const bool planned = c->planned && rescue && lpt;
+    P.pre_count = planned ? c->d_pre : nullptr;
+    P.pre_list = planned ? c->d_pre + 2 : nullptr;
+    P.skip = nullptr;
+    P.big_nls = c->big_nls;
+    P.lds_main = P.lds_bytes;
+    if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
+        HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 2 * sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
+    }
     // kernel variant: 0 = <4 blocks per thread> (h <= 11), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     const int var = small ? 0 : 1;
     const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, false, false> : (const void *)qr_mpc_kernel<9, true, false>;
@@ -334,9 +363,28 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
         c->configured_lds[var] = P.lds_bytes;
     }
+    if (rescue && c->configured_rescue[0] < c->lds_per_cu) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
+        c->configured_rescue[0] = c->lds_per_cu;
+    }
     MpcIO io;
     io.type_id = d_type; io.g_state = d_state; io.g_traj = d_traj; io.g_gait = d_gait; io.g_q = d_q; io.g_force = d_force; io.g_tau = d_tau;
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
+    const bool have_plan = planned && c->plan_n == n;
+    if (have_plan) {
+        // the planned list launch goes first, on the side stream, beside the main pass: whole CU's LDS, 96 positions, workgroup b takes
+        // entries b, b + grid, ... of the list the last call's planning left
+        P.skip = c->d_skip;
+        MpcLaunch L = P;
+        L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
+        L.lds_bytes = c->lds_per_cu;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        const int pgrid = c->big_nls > 0 ? 64 : 16;
+        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, c->side_stream, L, io);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+    }
     {
         TimerScope ts(c, 0);
         const dim3 grid(8 * ((n + 7) / 8)), block(256);
@@ -344,25 +392,24 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         else hipLaunchKernelGGL((qr_mpc_kernel<9, true, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, io);
     }
     HIPCHK(c, hipGetLastError());
+    if (have_plan) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (rescue) {
-        // list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's dispatch
-        // order and exit) are re-solved with the whole CU's LDS and 96 working-set positions; workgroup b takes entries b, b + 64, ...
+        // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
+        // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
+        R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
         // empty pass at 4096 robots)
         int rgrid = 64 < n ? 64 : n;
         if (rgrid < 8 && lpt) rgrid = 8;
-        if (c->configured_rescue[0] < R.lds_bytes) {
-            HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R.lds_bytes));
-            c->configured_rescue[0] = R.lds_bytes;
-        }
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         hipLaunchKernelGGL((qr_mpc_kernel<4, true, true>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
         HIPCHK(c, hipGetLastError());
         c->rescue_parity ^= 1;
+        if (planned) c->plan_n = n;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {

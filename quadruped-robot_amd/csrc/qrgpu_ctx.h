@@ -34,6 +34,14 @@ struct qrgpu_ctx {
     double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
     int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
     int rescue_parity = 0;
+    // planned list (launched beside the main pass on side_stream): [2] counters + [max_batch] robot ids; skip flags; batch size the plan is for
+    int *d_pre = nullptr;
+    unsigned char *d_skip = nullptr;
+    int plan_n = 0;
+    bool planned = true;
+    int big_nls = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
     bool lpt = true;
     bool rescue = true;

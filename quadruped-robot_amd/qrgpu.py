@@ -89,7 +89,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
-           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start"]
+           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list"]
 
 
 def load_library():
@@ -108,6 +108,7 @@ def load_library():
     lib.qrgpu_set_lpt_schedule.argtypes = [vp, ip]
     lib.qrgpu_set_rescue_pass.argtypes = [vp, ip]
     lib.qrgpu_set_warm_start.argtypes = [vp, ip]
+    lib.qrgpu_set_planned_list.argtypes = [vp, ip, ip]
     lib.qrgpu_last_error.argtypes = [vp]; lib.qrgpu_last_error.restype = C.c_char_p
     lib.qrgpu_device_info.argtypes = [vp, C.c_char_p, ip, C.POINTER(ip)]
     lib.qrgpu_model_desc_default.argtypes = [C.POINTER(model_desc_struct)]; lib.qrgpu_model_desc_default.restype = None
@@ -373,6 +374,10 @@ class Context:
     def set_warm_start(self, on=True):
         """Start each robot slot's active set from its previous solve (speed only; results agree with a cold start to solver tolerance)."""
         self._chk(self._lib.qrgpu_set_warm_start(self._h, 1 if on else 0))
+
+    def set_planned_list(self, on=True, big_nls=0):
+        """Robots that needed the rescue pass last call are solved beside the main launch this call (scheduling only)."""
+        self._chk(self._lib.qrgpu_set_planned_list(self._h, 1 if on else 0, int(big_nls)))
 
     def set_rescue_pass(self, on=True):
         self._chk(self._lib.qrgpu_set_rescue_pass(self._h, 1 if on else 0))

@@ -20,7 +20,10 @@ for seed in (21, 22):
         b = {k: (il(ba[k], bl[k]) if isinstance(ba[k], np.ndarray) else ba[k]) for k in ba}
         b["n"] = n
         tid = np.tile(np.array([0, 1], np.int32), n // 2)
-        o = G.run_tick(ctx, pkg, b, type_id=tid)
+        with G.cold_start(ctx):
+            o = G.run_tick(ctx, pkg, b, type_id=tid)
+        ow = G.run_tick(ctx, pkg, b, type_id=tid)      # warm start from the previous batch's slots (stale), then from its own
+        ow = G.run_tick(ctx, pkg, b, type_id=tid)
         f = np.zeros((n, 12), np.float32); tau = np.zeros((n, 12), np.float32); st = np.zeros(n, np.int32)
         for r, t in (("a1", 0), ("lite3", 1)):
             m = tid == t
@@ -31,6 +34,11 @@ for seed in (21, 22):
         ok = ~flags & (st == 0)
         ef = (np.abs(o["force"] - f).max(1) / np.maximum(1.0, np.abs(f).max(1)))[ok]; et = (np.abs(o["tau"] - tau) / np.maximum(1.0, np.abs(tau))).max(1)[ok]
         bad = int((ef > 1e-5).sum() + (et > 1e-4).sum()); tot_flag += int(flags.sum()); tot_bad += bad
-        print("h=16 seed %d excite %.1f: flagged %d %s (oracle nonzero %d), max rel force err %.2e, torque %.2e, over tol %d, iters max %d"
-              % (seed, ex, flags.sum(), np.unique(o["status"][flags] & 0xff), (st != 0).sum(), ef.max(), et.max(), bad, (o["status"] >> 8).max()), flush=True)
+        fw = (ow["status"] & 0xff) != 0
+        okw = ~fw & (st == 0)
+        efw = (np.abs(ow["force"] - f).max(1) / np.maximum(1.0, np.abs(f).max(1)))[okw]; etw = (np.abs(ow["tau"] - tau) / np.maximum(1.0, np.abs(tau))).max(1)[okw]
+        badw = int((efw > 1e-5).sum() + (etw > 1e-4).sum()); tot_flag += int(fw.sum()); tot_bad += badw
+        print("h=16 seed %d excite %.1f: cold flagged %d %s (oracle nonzero %d), max rel force err %.2e, torque %.2e, over tol %d, iters max %d | warm flagged %d, force %.2e, torque %.2e, over tol %d, iters mean %.1f (cold %.1f)"
+              % (seed, ex, flags.sum(), np.unique(o["status"][flags] & 0xff), (st != 0).sum(), ef.max(), et.max(), bad, ((o["status"] >> 8) & 0xffff).max(),
+                 fw.sum(), efw.max(), etw.max(), badw, ((ow["status"] >> 8) & 0xffff).mean(), ((o["status"] >> 8) & 0xffff).mean()), flush=True)
 print("TOTAL flagged %d over tolerance %d" % (tot_flag, tot_bad))

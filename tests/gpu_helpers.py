@@ -7,12 +7,15 @@ import numpy as np
 @contextlib.contextmanager
 def cold_start(ctx):
     """Warm start off inside the block: every solve starts from the empty working set, so that two calls on the same inputs return the
-    same bits whatever was solved in between (with it on they agree to the solver's tolerance, and the iteration counts differ)."""
+    same bits whatever was solved in between (with it on they agree to the solver's tolerance, and the iteration counts differ).  The
+    planned list is switched off too: it moves robots between launches from one call to the next."""
     ctx.set_warm_start(False)
+    ctx.set_planned_list(False)          # (which launch solves a robot changes its LDS allotment, hence the form of its z update, hence the last bits)
     try:
         yield ctx
     finally:
         ctx.set_warm_start(True)
+        ctx.set_planned_list(True)
 
 
 def run_mpc(ctx, pkg, b, with_tau=True, type_id=None):

@@ -256,6 +256,7 @@ def test_dispatch_order_does_not_change_results(gpu_ctx, pkg):
     G.setup_a1(gpu_ctx, pkg, h)
     b = pkg.make_batch(n, h, "a1", seed=0x51)
     gpu_ctx.set_warm_start(False)          # (the history that must not matter here is the dispatch order's)
+    gpu_ctx.set_planned_list(False)
     gpu_ctx.set_lpt_schedule(False)
     try:
         ref = G.run_mpc(gpu_ctx, pkg, b)
@@ -271,6 +272,7 @@ def test_dispatch_order_does_not_change_results(gpu_ctx, pkg):
     finally:
         gpu_ctx.set_lpt_schedule(True)
     gpu_ctx.set_warm_start(True)
+    gpu_ctx.set_planned_list(True)
     for o in (first, second):
         assert np.array_equal(o["force"], ref["force"]) and np.array_equal(o["tau"], ref["tau"]) and np.array_equal(o["status"], ref["status"])
     assert np.array_equal(third["force"], ref2["force"]) and np.array_equal(third["status"], ref2["status"])
@@ -307,3 +309,31 @@ def test_warm_start_over_a_coherent_sequence(gpu_ctx, pkg, oracle):
         fresh = G.run_mpc(gpu_ctx, pkg, other)
     assert np.all((stale["status"] & 0xff) == 0)
     assert (np.abs(stale["force"] - fresh["force"]).max(1) / np.maximum(1.0, np.abs(fresh["force"]).max(1))).max() <= 1e-7
+
+
+def test_planned_list_takes_over_from_the_rescue_pass(gpu_ctx, pkg, oracle):
+    """A robot that needed the rescue pass in one call is on the planned list of the next call with the same n: solved beside the main
+    launch (which skips it), not after it.  Results are those of the oracle either way; with every robot of the batch all-stance and
+    excited, the second call must not leave anything for the trailing rescue pass that the first one had to re-solve."""
+    h, n = 10, 256
+    G.setup_a1(gpu_ctx, pkg, h)
+    b = pkg.make_batch(n, h, "a1", seed=0xBEE7, excite=1.5, frac_all_stance=1.0, frac_three_leg=0.0)
+    gpu_ctx.set_warm_start(False); gpu_ctx.set_planned_list(True)
+    try:
+        gpu_ctx.set_rescue_pass(False)
+        flagged = (G.run_mpc(gpu_ctx, pkg, b)["status"] & 0x4) != 0          # who overflows the main pass
+        gpu_ctx.set_rescue_pass(True)
+        first = G.run_mpc(gpu_ctx, pkg, b)        # no plan yet: main pass + rescue
+        second = G.run_mpc(gpu_ctx, pkg, b)       # planned list beside the main pass
+        third = G.run_mpc(gpu_ctx, pkg, b)
+    finally:
+        gpu_ctx.set_warm_start(True)
+    assert flagged.sum() >= 8
+    cfg = pkg.mpc_cfg("a1")
+    for o in (first, second, third):
+        assert np.all((o["status"] & 0xff) == 0)
+        assert (np.abs(o["force"] - first["force"]).max(1) / np.maximum(1.0, np.abs(first["force"]).max(1))).max() <= 1e-7
+    assert np.array_equal(second["force"], third["force"])
+    for i in np.where(flagged)[0][:12]:
+        u, st, rc = oracle.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        assert np.abs(second["force"][i] - u[:12]).max() <= 1e-5 * max(1.0, np.abs(u[:12]).max()), i
