@@ -40,6 +40,8 @@ FLOP_K6_PER_ITER = 4 * 120 ** 2                  # 57.6 kFLOP per working-set ch
 FLOP_WBC = 0.35e6
 BYTES_PER_TICK = 1216                            # algorithmic HBM bytes per full tick at h = 10
 PEAK_F32_MATRIX_TFLOPS = 157.3                   # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+PEAK_F64_VECTOR_TFLOPS = 78.6                    # MI355X FP64 vector peak (spec: half the FP32 vector rate); scratch/ubench/lat.hip measures 59 TFLOP/s of
+                                                 # v_fma_f64 at two waves per SIMD
 PEAK_HBM_GBS = 8000.0
 EST_IN_ROWS, EST_OUT_ROWS = 54, 42                # QRGPU_EST_IN_ROWS / QRGPU_EST_OUT_ROWS (include/qrgpu.h)
 
@@ -379,6 +381,20 @@ def main():
     rates = [world * n * share[d] / draw_s[d] for d in range(D)]
     value = float(np.median(rates))
 
+    # executed arithmetic of the MPC kernel (qrgpu_enable_flop_count): four more, untimed, steps on draw 0 with the counters on
+    flop = None
+    if args.mode != "wbc":
+        timed(2, args.warmup, 0)
+        ctx.enable_flop_count(True)
+        acc = {}
+        for _ in range(4):
+            step()
+            for k, v in ctx.mpc_flop_counts().items():
+                acc[k] = acc.get(k, 0.0) + v / 4.0
+        ctx.enable_flop_count(False)
+        fence()
+        flop = acc
+
     side = {}
     if world == 1 and not args.no_side and args.mode == "tick":
         ks = max(10, args.steps // 4)
@@ -431,12 +447,35 @@ def main():
         flags = status.astype(np.int64) & 0xff0000ff
         ms_per_step = 1e3 * world * n / value
         it_mean = float(iters.mean()) if args.mode != "wbc" else 0.0
-        flop_mpc = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + it_mean * FLOP_K6_PER_ITER
+        flop_dense = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + 20.3 * FLOP_K6_PER_ITER      # SURVEY 8(d)'s dense count (cold start: 20.3 changes)
         if args.mode == "wbc":
-            dom_ms, dom_flop, dom_name = wbc_ms, FLOP_WBC, "qr_wbc_kernel"
+            dom_ms, dom_name = wbc_ms, "qr_wbc_kernel"
+            roof = {"bound": "latency", "kernel": dom_name, "achieved": FLOP_WBC * n / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                    "frac": FLOP_WBC * n / (dom_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS, "traffic": None, "kernel_ms": dom_ms, "kernel_launches": wbc_cnt,
+                    "note": "SURVEY 8(d)'s estimate of 0.35 MFLOP per robot (fp64); one wavefront per robot, dependent small-matrix chains"}
         else:
-            dom_ms, dom_flop, dom_name = mpc_ms, flop_mpc, "qr_mpc_kernel"
-        achieved = (dom_flop * n) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            dom_ms, dom_name = mpc_ms, "qr_mpc_kernel"
+            sec = dom_ms * 1e-3
+            f64 = (flop["fp64_sweep"] + flop["fp64_active_set"]) / sec / 1e12
+            m32 = flop["fp32_matrix"] / sec / 1e12
+            v32 = flop["fp32_vector"] / sec / 1e12
+            roof = {
+                # what bounds the kernel: dependent chains (a barrier + LDS round trip + 3x3 inverse per sweep pivot, ~4 k cycles of wave 0 per
+                # working-set change), not a throughput roof -- DESIGN.md 5 holds the counter evidence (SQ_INSTS_VALU per SIMD-cycle, SQ_WAIT_*,
+                # SQ_VALU_MFMA_BUSY_CYCLES) from profiles/; every figure here is EXECUTED arithmetic counted by the kernel itself
+                "bound": "latency", "kernel": dom_name,
+                "achieved": f64, "peak": PEAK_F64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": f64 / PEAK_F64_VECTOR_TFLOPS,
+                "achieved_is": "executed fp64 flops (block sweep, x0, active set) / kernel time; fp64 is >= 85 % of the kernel's cycles",
+                "fp32_matrix": {"achieved": m32, "peak": PEAK_F32_MATRIX_TFLOPS, "frac": m32 / PEAK_F32_MATRIX_TFLOPS,
+                                "what": "v_mfma_f32_16x16x4_f32 flops issued by K4 (2*16*16*4 each, zero padding of the tiles included) = MFMA utilisation over the whole kernel"},
+                "fp32_vector": {"achieved": v32, "peak": PEAK_F32_MATRIX_TFLOPS, "frac": v32 / PEAK_F32_MATRIX_TFLOPS},
+                "executed_flop_per_robot": {k: v / n for k, v in flop.items()},
+                "dense_yardstick": {"flop_per_robot": flop_dense, "achieved": flop_dense * n / sec / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                                    "frac": flop_dense * n / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                                    "what": "SURVEY.md 8(d)'s dense count (12h x 13h x 12h GEMM, n^3/3 factorisation, 4 n^2 per change) over the same kernel time: "
+                                            "a yardstick against that accounting, not work the kernel does (swing variables are eliminated, zero terms skipped)"},
+                "traffic": None, "kernel_ms": dom_ms, "kernel_launches": mpc_cnt, "other_kernel_ms": wbc_ms,
+                "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         what = "full MPC+WBC tick (K1-K14: kinematic projection on, motor tail on)"
         out = {
             "metric": "MPC+WBC control ticks/s (batched robots)" if args.mode == "tick" else "%s-only control ticks/s (batched robots)" % args.mode.upper(),
@@ -456,11 +495,7 @@ def main():
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "dispatch": "longest-first from the previous step's per-robot solve time (a prediction: consecutive steps see different batches)",
                        **side},
-            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                         "kernel_ms": dom_ms, "kernel_launches": mpc_cnt if dom_name == "qr_mpc_kernel" else wbc_cnt,
-                         "algorithmic_flop_per_robot": dom_flop, "other_kernel_ms": wbc_ms if dom_name == "qr_mpc_kernel" else mpc_ms,
-                         "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline and not args.mixed and args.mode != "wbc":
             b0 = host0[0]

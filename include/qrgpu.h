@@ -342,6 +342,14 @@ int qrgpu_mpc_assemble_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const 
 #define QRGPU_FB_DEBUG_FLOATS (324 + 18 + 18 + 216 + 12 + 12 + 12)
 int qrgpu_fb_debug_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_fb_state, float *d_out);
 
+/* ---- executed arithmetic of the batched MPC solve (measurement; off by default) ---------------------------------------------------
+ * With counting on, every solve leaves what it actually computed, by formula from the sizes it saw (stance leg-steps, tile count,
+ * working-set size of every change, rebuilds): out[0] fp32 vector flops, out[1] fp32 matrix flops issued (v_mfma_f32_16x16x4_f32),
+ * out[2] fp64 flops of the block sweep and x0, out[3] fp64 flops of the active set.  qrgpu_mpc_flop_counts sums them over the robots of
+ * the last counted call (mul and add count 1, fma 2).  bench.py's roofline block is built from these, not from a dense yardstick. */
+int qrgpu_enable_flop_count(qrgpu_ctx *ctx, int on);
+int qrgpu_mpc_flop_counts(qrgpu_ctx *ctx, double out[4]);
+
 /* ---- plumbing ------------------------------------------------------------------ */
 int  qrgpu_sync(qrgpu_ctx *ctx);                       /* hipStreamSynchronize on the context stream */
 /* Mean device time (ms) of the kernels launched by the last `calls` batched calls,

@@ -76,6 +76,7 @@ struct MpcLaunch {
     // warm start (speed only): [robot][QR_WARM_STRIDE] bytes: the 6-bit active-row mask of each of the <= 64 original leg-steps at the end of the
     // slot's last solve, the contact-table bits it belonged to (8 bytes at offset 64), the horizon as a validity tag in the last byte; or null
     unsigned char *warm;
+    double *flops;              // [robot][4] executed-arithmetic counts of the solve (qrgpu_mpc_flop_counts), or null
     int type_ready;             // bit t: type t was set up (robots naming any other type are flagged QRGPU_ST_BAD_TYPE)
     int epilogue;               // QRGPU_EPILOGUE_* bits applied to g_tau (MPC-only batches; 0 inside the fused tick)
 };

@@ -37,6 +37,9 @@
 namespace qrgpu {
 
 #define QR_MPC_THREADS 256
+#ifndef QR_HESS_VALU
+#define QR_HESS_VALU 0           // 1: K4 as hand-written fmaf chains on the VALU (round 1), kept for A/B runs; 0: v_mfma_f32_16x16x4_f32
+#endif
 
 __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
 {
@@ -488,6 +491,11 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     const float dtm = dt * minv;
     const float two_alpha = 2.f * C.alpha;
 
+    // Executed-arithmetic accounting (P.flops, off unless asked for): what the workgroup actually computes, by formula from the sizes the
+    // solve sees -- [0] fp32 vector flops (operand generation, gradient), [1] fp32 matrix flops issued (2 * 16 * 16 * 4 per
+    // v_mfma_f32_16x16x4_f32), [2] fp64 flops of the sweep and x0, [3] fp64 flops of the active set (rebuilds included).  mul and add count 1
+    // each, fma 2.  Wave 0 keeps the sums (uniform) and stores them at the end.
+    double fl_v32 = 0.0, fl_m32 = 0.0, fl_sw = 0.0, fl_as = 0.0;
     // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
     // (the torque map's Jacobian columns first, on twelve lanes of the last wave: it owns the fewest blocks, so this hides behind wave 0's)
     if (MAXB <= 4 && io.g_tau && tid >= 192 && tid < 204) { const int e = tid - 192; mpc_jacobian_column(e / 3, e - 3 * (e / 3), rid, n, C, io.g_q, sJ + 3 * e); }
@@ -502,15 +510,118 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             while (tri(a) > pid) --a;
             const int b = pid - tri(a);                 // a >= b
             ba[sl] = a; bb[sl] = b;
+#if QR_HESS_VALU
             const Blk Hb = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
                                       io.dbgH ? io.dbgH + (size_t)rid * NV * NV : nullptr, NV);
             // parked in its final M slot: keeps the 18 VGPRs per block out of the build's register budget
             double *dst = Mb + pid * 9;
 #pragma unroll
             for (int i = 0; i < 9; ++i) dst[i] = Hb.m[i];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the blocks' temporaries from overlapping (register pressure)
     }
+#if !QR_HESS_VALU
+    // K4 on the matrix cores:  qH = temp * Bqp (:411) restricted to the stance columns, as 16 x 16 tiles of v_mfma_f32_16x16x4_f32.
+    // That instruction IS the k-ordered fp32 fmaf chain (MI355X_MICROARCH.md: "exact f32, == fmaf chain, bitwise"), so the result is bit
+    // for bit the oracle's dense GEMM (tests/test_gpu_mpc.py::test_assembly_bit_exact); the terms it adds beyond the hand-written chain
+    // are exact zeros.  k runs over (horizon step r, state row s): per step three instructions cover s = 0..11 (s = 12 has weight 0),
+    // lane group g = lane >> 4 supplying s = 4 q + g of instruction q.  Operands are generated in registers from the closed form of
+    // Adt^a Bdt (no Bqp in memory): G[(r, s)][(a, i)] = c * T_p[s][i] | c / m | dt U_p[s - 6][i] | dt / m, c = (r - i_a + 1/2) dt^2, zero for r < i_a.
+    // Only tiles on or below the diagonal are visited, each with TWO accumulators: H[e_r][e_c] = sum temp[e_r][k] G[k][e_c] and
+    // H[e_c][e_r] = sum G[k][e_r] temp[e_c][k] (the same products, a * b = b * a) land in the same lane and register, so the fp64 average
+    // (H + H') / 2 needs no transpose and goes straight to the block-packed slot the sweep loads from.
+    {
+#pragma clang fp contract(off)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int wvb = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int NT = (ns + 15) >> 4, NTL = tri(NT);
+        const int g = lane >> 4, lc = lane & 15;
+        const float w2q0 = 2.f * C.weights[g], w2q1 = 2.f * C.weights[4 + g], w2q2 = 2.f * C.weights[8 + g];
+        float *Hd = io.dbgH ? io.dbgH + (size_t)rid * NV * NV : nullptr;
+        // lane constants of one side (row tile or column tile): the leg-step behind index e = 16 * tile + lc and its operand recipe
+        auto side = [&](int tile, int &ia, float &al0, float &al1, float &k1, float &k2) {
+            const int e = 16 * tile + lc;
+            const bool valid = e < ns;
+            const int a = (e * 21846) >> 16;                       // e / 3
+            const int ls = valid ? sLs[a] : 0;
+            const int p = ls & 3, i = e - 3 * a;
+            ia = valid ? (ls >> 2) : h;                            // (rows / columns past the matrix never switch on)
+            al0 = (g < 3) ? sT[9 * p + 3 * g + i] : ((i == 0) ? minv : 0.f);
+            al1 = (i == g + 1) ? minv : 0.f;                       // used by lane groups 0, 1 only (s = 4, 5)
+            k1 = dt * sU[9 * p + 3 * ((g >= 2) ? g - 2 : 0) + i];  // s = 6, 7 for lane groups 2, 3
+            k2 = (g == 0) ? dt * sU[9 * p + 6 + i] : ((i == g - 1) ? dtm : 0.f);      // s = 8 | 9, 10, 11
+        };
+#if defined(QR_DIAG_REFAC)
+        const long long th0 = clock64();
+        long long th_loop = 0;
+#endif
+        for (int t = wvb; t < NTL; t += 4) {
+            int R = (int)((__builtin_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+            while (tri(R + 1) <= t) ++R;
+            while (tri(R) > t) --R;
+            const int Cc = t - tri(R);                                  // R >= Cc
+            int iaR, iaC;
+            float a0R, a1R, k1R, k2R, a0C, a1C, k1C, k2C;
+            side(R, iaR, a0R, a1R, k1R, k2R);
+            side(Cc, iaC, a0C, a1C, k1C, k2C);
+            const float t1R = k1R * w2q1, t2R = k2R * w2q2, t1C = k1C * w2q1, t2C = k2C * w2q2;
+            const int r0 = sLs[(16 * R * 21846) >> 16] >> 2;            // first step at which any entry of the tile switches on
+            f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#if defined(QR_DIAG_REFAC)
+            const long long tl0 = clock64();
+#endif
+            for (int r = r0; r < h; ++r) {
+                const bool onR = r >= iaR, onC = r >= iaC;
+                const float cR = ((float)(r - iaR) + 0.5f) * dt2, cC = ((float)(r - iaC) + 0.5f) * dt2;
+                // s = 0..3
+                float gR = cR * a0R, gC = cC * a0C;
+                float tR = gR * w2q0, tC = gC * w2q0;
+                gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+                // s = 4..7
+                const float hR = cR * a1R, hC = cC * a1C;
+                gR = (g < 2) ? hR : k1R; tR = (g < 2) ? hR * w2q1 : t1R;
+                gC = (g < 2) ? hC : k1C; tC = (g < 2) ? hC * w2q1 : t1C;
+                gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+                // s = 8..11
+                gR = onR ? k2R : 0.f; tR = onR ? t2R : 0.f; gC = onC ? k2C : 0.f; tC = onC ? t2C : 0.f;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+            }
+#if defined(QR_DIAG_REFAC)
+            asm volatile("" :: "v"(acc1), "v"(acc2));
+            th_loop += clock64() - tl0;
+#endif
+            // D[row = 4 g + reg][col = lc] of both accumulators -> (H + H') / 2 in fp64, block-packed
+            const int ec = 16 * Cc + lc;
+            const int bq = (ec * 21846) >> 16, j = ec - 3 * bq;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int er = 16 * R + 4 * g + reg;
+                if (er < ns && ec <= er) {
+                    const int aq = (er * 21846) >> 16, i = er - 3 * aq;
+                    float v1 = acc1[reg], v2 = acc2[reg];                 // H[er][ec], H[ec][er]
+                    if (er == ec) { v1 = v1 + two_alpha; v2 = v2 + two_alpha; }      // + 2 alpha I (:411)
+                    const double o = 0.5 * ((double)v1 + (double)v2);
+                    Mb[(tri(aq) + bq) * 9 + 3 * i + j] = o;
+                    if (aq == bq && i != j) Mb[(tri(aq) + aq) * 9 + 3 * j + i] = o;
+                    if (Hd) {
+                        const int la = sLs[aq], lb = sLs[bq];
+                        Hd[(size_t)(3 * la + i) * NV + 3 * lb + j] = v1;
+                        Hd[(size_t)(3 * lb + j) * NV + 3 * la + i] = v2;
+                    }
+                }
+            }
+        }
+#if defined(QR_DIAG_REFAC)
+        if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 4] = clock64() - th0; io.dbgT[(size_t)rid * 16 + 5] = th_loop; io.dbgT[(size_t)rid * 16 + 6] = NTL; }
+#endif
+    }
+#endif
     // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread
     for (int e = tid; e < ns; e += QR_MPC_THREADS) {
 #pragma clang fp contract(off)
@@ -542,10 +653,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
     // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
     Blk A[MAXB];
+#if !QR_HESS_VALU
+    __syncthreads();               // the Hessian blocks were written by the waves that ran their tiles
+#endif
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
         if (ba[sl] >= 0) {
-            const double *src = Mb + (tid + QR_MPC_THREADS * sl) * 9;        // own slot: no barrier needed
+            const double *src = Mb + (tid + QR_MPC_THREADS * sl) * 9;
 #pragma unroll
             for (int i = 0; i < 9; ++i) A[sl].m[i] = src[i];
         }
@@ -661,6 +775,17 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         __syncthreads();
     }
     QR_TS(3);
+    if (P.flops) {
+        const int NTf = (ns + 15) >> 4;
+        double steps = 0.0;                              // tile x horizon-step pairs of the lower tile triangle
+        for (int Rf = 0; Rf < NTf; ++Rf) steps += (double)(Rf + 1) * (double)(h - (sLs[(16 * Rf * 21846) >> 16] >> 2));
+        fl_m32 = steps * 6.0 * 2048.0;                   // 2 accumulators x 3 instructions, 2 * 16 * 16 * 4 flops each
+        fl_v32 = steps * 64.0 * 12.0;                    // operand generation: 12 mul / add per lane and step
+        double gsteps = 0.0;
+        for (int kf = 0; kf < nls; ++kf) gsteps += (double)(h - (sLs[kf] >> 2));
+        fl_v32 += gsteps * 3.0 * 24.0;                   // gradient: 8 fma + 8 mul per variable and step
+        fl_sw = (double)nls * ((double)npairs * 99.0 + 40.0) + (double)nls * (double)nls * 15.0;     // block sweep (D = C P^-1: 45, update: 54), P^-1 once per pivot; x0 = -M g
+    }
     // =====================================================================================================
     // Control / worker active set.  Wave 0 alone takes the decisions -- row scan, w, delta, d, step lengths,
     // bookkeeping in its registers -- and waves 1-3 are linear-algebra helpers, so that the S^-1 border of one iteration runs while
@@ -1037,6 +1162,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const long long tr0 = clock64();
 #endif
                 const bool ok = rebuild(q);
+                if (P.flops) fl_as += 17.5 * (double)q * (double)q + 1.5 * (double)q * (double)q * (double)q + 15.0 * (double)q * (double)nls;   // S, sweep of S, W_A
 #if defined(QR_DIAG_REFAC)
                 if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 8] += ok ? 1 : 100; io.dbgT[(size_t)rid * 16 + 10] = clock64() - tr0; io.dbgT[(size_t)rid * 16 + 11] = q; }
                 const long long tr1 = clock64();
@@ -1069,6 +1195,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     double rq, rq2 = 0.0;
                     { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                     if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
+                    if (P.flops) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 8.0 * (double)q;
                     // u = -r; the most negative multiplier beyond rounding leaves
                     const double umax = -wave_min_d(hi ? (rq < rq2 ? rq : rq2) : rq);          // max u (>= 0 when any row is held properly)
                     const double worst = -wave_min_d(hi ? (-rq < -rq2 ? -rq : -rq2) : -rq);    // max r = -min u
@@ -1234,6 +1361,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 uq -= t * rq;
                 if (hi) uq2 -= t * rq2;
                 up += t;
+                if (P.flops) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 21.0 * (double)nls + 12.0 * (double)q;
                 if (full) {
                     if (fastz) {
                         if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
@@ -1293,6 +1421,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         mpc_outputs(lane, rid, n, xz, R, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
         if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
         if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+        if (lane == 0 && P.flops) { double *fo = P.flops + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
         if (lane == 0 && P.cost) {
             const long long c = (clock64() - t_begin) >> 12;
             int big = 0;

@@ -218,6 +218,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_cost) hipFree(c->d_cost);
     if (c->d_rescue) hipFree(c->d_rescue);
     if (c->d_warm) hipFree(c->d_warm);
+    if (c->d_flops) hipFree(c->d_flops);
     if (c->d_pre) hipFree(c->d_pre);
     if (c->d_skip) hipFree(c->d_skip);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -319,6 +320,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.n = n;
     P.type_ready = ready_mask(c->mpc_ready);
     P.epilogue = epilogue;
+    P.flops = (c->flops_on && !dH) ? c->d_flops : nullptr;
+    if (P.flops) c->flops_n = n;
     // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
     P.warm = (c->warm && !dH) ? c->d_warm : nullptr;
     if (P.warm && c->warm_n != n) {
@@ -790,6 +793,27 @@ int qrgpu_selftest(qrgpu_ctx *c, double *host_out256)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(host_out256, d, 256 * sizeof(double), hipMemcpyDeviceToHost));
     hipFree(d);
+    return QRGPU_OK;
+}
+
+int qrgpu_enable_flop_count(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    if (on && !c->d_flops) HIPCHK(c, hipMalloc(&c->d_flops, sizeof(double) * 4 * (size_t)c->max_batch));
+    c->flops_on = on != 0;
+    c->flops_n = 0;
+    return QRGPU_OK;
+}
+
+int qrgpu_mpc_flop_counts(qrgpu_ctx *c, double out[4])
+{
+    if (!c || !out) return QRGPU_ERR_BAD_ARG;
+    if (!c->d_flops || c->flops_n <= 0) return QRGPU_ERR_NOT_SETUP;
+    std::vector<double> h(4 * (size_t)c->flops_n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h.data(), c->d_flops, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (int i = 0; i < c->flops_n; ++i) for (int k = 0; k < 4; ++k) out[k] += h[4 * (size_t)i + k];
     return QRGPU_OK;
 }
 

@@ -46,6 +46,9 @@ struct qrgpu_ctx {
     bool lpt = true;
     bool rescue = true;
     int epilogue = 0;             // QRGPU_EPILOGUE_* bits
+    double *d_flops = nullptr;    // [max_batch][4], allocated by qrgpu_enable_flop_count
+    bool flops_on = false;
+    int flops_n = 0;              // robots of the last counted launch
     bool warm = true;             // warm start of the MPC active set from the slot's previous solve
     unsigned char *d_warm = nullptr;   // [max_batch][QR_WARM_STRIDE]
     int warm_n = 0;               // batch size d_warm is valid for (0 = nothing yet)

@@ -89,7 +89,8 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
-           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list"]
+           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
+           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts"]
 
 
 def load_library():
@@ -109,6 +110,8 @@ def load_library():
     lib.qrgpu_set_rescue_pass.argtypes = [vp, ip]
     lib.qrgpu_set_warm_start.argtypes = [vp, ip]
     lib.qrgpu_set_planned_list.argtypes = [vp, ip, ip]
+    lib.qrgpu_enable_flop_count.argtypes = [vp, ip]
+    lib.qrgpu_mpc_flop_counts.argtypes = [vp, C.POINTER(C.c_double)]
     lib.qrgpu_last_error.argtypes = [vp]; lib.qrgpu_last_error.restype = C.c_char_p
     lib.qrgpu_device_info.argtypes = [vp, C.c_char_p, ip, C.POINTER(ip)]
     lib.qrgpu_model_desc_default.argtypes = [C.POINTER(model_desc_struct)]; lib.qrgpu_model_desc_default.restype = None
@@ -384,6 +387,15 @@ class Context:
 
     def sync(self):
         self._chk(self._lib.qrgpu_sync(self._h))
+
+    def enable_flop_count(self, on=True):
+        self._chk(self._lib.qrgpu_enable_flop_count(self._h, 1 if on else 0))
+
+    def mpc_flop_counts(self):
+        """Executed arithmetic of the last counted MPC call, summed over its robots: dict(fp32_vector, fp32_matrix, fp64_sweep, fp64_active_set)."""
+        out = (C.c_double * 4)()
+        self._chk(self._lib.qrgpu_mpc_flop_counts(self._h, out))
+        return dict(fp32_vector=out[0], fp32_matrix=out[1], fp64_sweep=out[2], fp64_active_set=out[3])
 
     # -- multi-GPU: the all-gather of torques over RCCL (qrgpu_comm.hip) ---------------------------------------------
     def comm_init_rank(self, id_blob, nranks, rank):
