@@ -36,7 +36,10 @@
 
 namespace qrgpu {
 
-#define QR_MPC_THREADS 256
+#define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
+#ifndef QR_MAIN_WAVES_PER_SIMD
+#define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
+#endif
 #ifndef QR_HESS_VALU
 #define QR_HESS_VALU 0           // 1: K4 as hand-written fmaf chains on the VALU (round 1), kept for A/B runs; 0: v_mfma_f32_16x16x4_f32
 #endif
@@ -259,9 +262,9 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
         // broadcast), no atomics -- the counting sort below spends ~0.5 ms at 512 robots per chunk on atomics to a few hot bins -- and the
         // order is stable, i.e. the same for the same costs.
         const int m = hi - lo;
-        for (int i = threadIdx.x; i < m; i += 256) hist[i] = cost[lo + i] & 255;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) hist[i] = cost[lo + i] & 255;
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += 256) {
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const int ci = hist[i];
             int rank = 0;
             for (int j = 0; j < m; ++j) { const int cj = hist[j]; rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0; }
@@ -269,16 +272,16 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
         }
         return;
     }
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&hist[255 - (cost[i] & 255)], 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int b = 0; b < 256; ++b) { const int c = hist[b]; hist[b] = acc; acc += c; }
     }
     __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 256) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
 }
 __global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
 {
@@ -297,10 +300,10 @@ struct MpcIO {
     long long *dbgT;
 };
 
-// One robot's MPC tick by one 256-thread workgroup.  MAXB: 3x3 blocks a thread keeps in registers during the sweep (MAXB * 256 >= number of
+// One robot's MPC tick by one workgroup of NTHR threads.  MAXB: 3x3 blocks a thread keeps in registers during the sweep (MAXB * NTHR >= number of
 // stance leg-step pairs).  BIG: working-set positions 64 .. 95 live in a second set of per-lane registers.  Every wave returns from here
 // (the workers at their exit command, wave 0 after the outputs), so a workgroup may solve several robots in a row (list mode below).
-template <int MAXB, bool BIG>
+template <int MAXB, bool BIG, int NTHR>
 __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO &io, const int rid, double *smem)
 {
     const int tid = threadIdx.x;
@@ -341,10 +344,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #define QR_TS(i) do { if (io.dbgT && tid == 0) io.dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
 #endif
     QR_TS(0);
+#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
+    if (io.dbgT && tid == 0) io.dbgT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
+#endif
     // ---------------- phase 0: inputs ----------------
     if (tid < 28) sSt[tid] = io.g_state[(size_t)tid * n + rid];
-    for (int i = tid; i < NV; i += QR_MPC_THREADS) sTraj[i] = io.g_traj[(size_t)i * n + rid];
-    for (int i = tid; i < NL; i += QR_MPC_THREADS) sGait[i] = io.g_gait[(size_t)i * n + rid];
+    for (int i = tid; i < NV; i += NTHR) sTraj[i] = io.g_traj[(size_t)i * n + rid];
+    for (int i = tid; i < NL; i += NTHR) sGait[i] = io.g_gait[(size_t)i * n + rid];
     __syncthreads();
 
     // ---------------- phase 1: SRBD terms (every thread keeps R in registers) ----------------
@@ -482,7 +488,18 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (P.no_wcache == 1) qW = 0;
     }
     int st = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
-    if (npairs > MAXB * QR_MPC_THREADS) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
+    if (npairs > MAXB * NTHR) { st |= QRGPU_ST_MPC_OVERFLOW_D; }      // cannot happen: the host picks MAXB from the horizon
+    if (!spilled && qcap < (ns < 24 ? ns : 24)) {
+        // this launch's LDS allotment cannot hold the inverse Hessian of this robot plus a 24-row S^-1 (the main pass at three workgroups
+        // per CU and an all-stance robot): nothing is computed here, the robot goes to the list pass at once -- and, through the `big`
+        // bit, onto the planned list of the next call
+        if (tid == 0) {
+            if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
+            if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+        }
+        return;
+    }
 
     float w2[13];
 #pragma unroll
@@ -502,7 +519,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     int ba[MAXB], bb[MAXB];
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
-        const int pid = tid + QR_MPC_THREADS * sl;
+        const int pid = tid + NTHR * sl;
         ba[sl] = -1; bb[sl] = -1;
         if (pid < npairs) {
             int a = (int)((__builtin_sqrtf(8.f * (float)pid + 1.f) - 1.f) * 0.5f);
@@ -556,7 +573,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         const long long th0 = clock64();
         long long th_loop = 0;
 #endif
-        for (int t = wvb; t < NTL; t += 4) {
+        for (int t = wvb; t < NTL; t += NTHR / 64) {
             int R = (int)((__builtin_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
             while (tri(R + 1) <= t) ++R;
             while (tri(R) > t) --R;
@@ -623,7 +640,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     }
 #endif
     // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread
-    for (int e = tid; e < ns; e += QR_MPC_THREADS) {
+    for (int e = tid; e < ns; e += NTHR) {
 #pragma clang fp contract(off)
         const int ls = sLs[e / 3], j = e % 3, ia = ls >> 2, p = ls & 3;
         const float t0 = sT[9 * p + j], t1 = sT[9 * p + 3 + j], t2 = sT[9 * p + 6 + j];
@@ -645,7 +662,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         gl[e] = (double)acc;
         if (io.dbgG) io.dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
-    for (int c = tid; c < 6 * nls; c += QR_MPC_THREADS) sPos[c] = -1;
+    for (int c = tid; c < 6 * nls; c += NTHR) sPos[c] = -1;
     QR_TS(2);
 
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
@@ -659,7 +676,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
         if (ba[sl] >= 0) {
-            const double *src = Mb + (tid + QR_MPC_THREADS * sl) * 9;
+            const double *src = Mb + (tid + NTHR * sl) * 9;
 #pragma unroll
             for (int i = 0; i < 9; ++i) A[sl].m[i] = src[i];
         }
@@ -774,6 +791,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
         __syncthreads();
     }
+    // phases 0-3 may run on more than four waves (NTHR / 64: one block of a trotting robot's Hessian per thread); the active set is a
+    // four-wave protocol, so the others are done here (a wave that has ended no longer counts at the workgroup's barriers)
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) return;
     QR_TS(3);
     if (P.flops) {
         const int NTf = (ns + 15) >> 4;
@@ -880,7 +900,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         auto rebuild = [&](const int q) -> bool {
             // thread t owns the packed elements e = t, t + 256, ... (NE at most) and keeps them in registers through the whole sweep; only the
             // pivot column goes through LDS (colp, double buffered: the owners of the next pivot's column publish it while they update it)
-            constexpr int NE = (QMAX * (QMAX + 1) / 2 + QR_MPC_THREADS - 1) / QR_MPC_THREADS;        // 9 (64 rows), 19 (96 rows)
+            constexpr int NE = (QMAX * (QMAX + 1) / 2 + QR_AS_THREADS - 1) / QR_AS_THREADS;        // 9 (64 rows), 19 (96 rows)
             const int ne = tri(q);
             double *colp = xr;                            // [2][QMAX] pivot columns (the r exchange is idle during a rebuild)
             double *diag0 = xz + NV;                      // [q] the diagonal of S (q <= 3 nls <= NV)
@@ -892,8 +912,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
             for (int m = 0; m < NE; ++m) {
                 el[m] = 0.0; eij[m] = 0;
-                if (QR_MPC_THREADS * m < ne) {                                  // (uniform)
-                    const int e = tid + QR_MPC_THREADS * m;
+                if (QR_AS_THREADS * m < ne) {                                  // (uniform)
+                    const int e = tid + QR_AS_THREADS * m;
                     if (e < ne) {
                         int i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
                         while (tri(i + 1) <= e) ++i;
@@ -925,7 +945,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const double ip = fast_rcp(d);
 #pragma unroll
                 for (int m = 0; m < NE; ++m) {
-                    if (QR_MPC_THREADS * m < ne) {                              // (uniform; threads past the last element work on a zero at (0, 0))
+                    if (QR_AS_THREADS * m < ne) {                              // (uniform; threads past the last element work on a zero at (0, 0))
                         const int i = eij[m] >> 8, j = eij[m] & 255;
                         const double ci = cur[i], cj = cur[j];
                         const bool ip_ = (i == p), jp_ = (j == p);
@@ -944,7 +964,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #endif
             if (ok) {
 #pragma unroll
-                for (int m = 0; m < NE; ++m) { const int e = tid + QR_MPC_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
+                for (int m = 0; m < NE; ++m) { const int e = tid + QR_AS_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
                 if (qW > 0 && q <= qW) {
                     for (int i = wv; i < q; i += 4) {
                         const int ci = sAct[i];
@@ -1437,6 +1457,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8);
         }
         QR_TS(6);
+#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
+        if (lane == 0 && io.dbgT) io.dbgT[(size_t)rid * 16 + 13] = wall_clock64();
+#endif
 #ifndef QR_TRACE
         if (lane == 0 && io.dbgT) { io.dbgT[(size_t)rid * 16 + 7] = ns; io.dbgT[(size_t)rid * 16 + 14] = q; }
 #ifdef QR_GI_STAMPS
@@ -1451,8 +1474,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 //   LIST = true:  workgroups 0-7 first sort the next call's dispatch order, then workgroup b re-solves entries b, b + grid, b + 2 grid ...
 //                 of the rescue list (robots whose working set outgrew the main pass's registers or LDS) with this launch's larger LDS
 //                 allotment and the BIG register set.
-template <int MAXB, bool BIG, bool LIST>
-__global__ __launch_bounds__(QR_MPC_THREADS, ((MAXB <= 4 && !LIST) ? 2 : 1))
+template <int MAXB, bool BIG, bool LIST, int NTHR>
+__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : 1))
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
@@ -1466,7 +1489,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             if (P.pre_list && P.skip && P.lpt_cost_in) {
                 // plan the next call: robots whose solve left the `big` bit go on the planned list and are skipped by the main pass
                 const int chunk = (P.n + 7) >> 3, lo = blockIdx.x * chunk, hi = (lo + chunk < P.n) ? lo + chunk : P.n;
-                for (int i = lo + threadIdx.x; i < hi; i += QR_MPC_THREADS) {
+                for (int i = lo + threadIdx.x; i < hi; i += NTHR) {
                     const int big = (P.lpt_cost_in[i] >> 8) & 1;
                     P.skip[i] = (unsigned char)big;
                     if (big) P.pre_list[atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 1)] = i;
@@ -1478,7 +1501,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         int cnt = planned ? P.pre_count[P.rescue_parity] : P.rescue_count[P.rescue_parity];
         cnt = cnt < P.n ? cnt : P.n;
         for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-            mpc_solve_robot<MAXB, BIG>(P, io, list[e], smem);
+            mpc_solve_robot<MAXB, BIG, NTHR>(P, io, list[e], smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
     } else {
@@ -1490,13 +1513,15 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         }
         const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
         if (P.skip && P.skip[rid]) return;             // solved by the planned list launch, beside this one
-        mpc_solve_robot<MAXB, BIG>(P, io, rid, smem);
+        mpc_solve_robot<MAXB, BIG, NTHR>(P, io, rid, smem);
     }
 }
 
-template __global__ void qr_mpc_kernel<4, false, false>(MpcLaunch, MpcIO);     // h <= 11, main pass
-template __global__ void qr_mpc_kernel<4, true, true>(MpcLaunch, MpcIO);       // h <= 11, rescue list (whole CU's LDS, 96 rows)
-template __global__ void qr_mpc_kernel<9, true, false>(MpcLaunch, MpcIO);      // h <= 16
+template __global__ void qr_mpc_kernel<3, false, false, 384>(MpcLaunch, MpcIO);     // h <= 11, main pass: six waves build and sweep, four solve
+template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
+template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
+template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
+template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

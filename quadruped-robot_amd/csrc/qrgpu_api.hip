@@ -22,10 +22,12 @@ struct MpcIO {
     int force_stride;
     long long *dbgT;
 };
-template <int MAXB, bool BIG, bool LIST> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
-extern template __global__ void qr_mpc_kernel<4, false, false>(MpcLaunch, MpcIO);
-extern template __global__ void qr_mpc_kernel<4, true, true>(MpcLaunch, MpcIO);
-extern template __global__ void qr_mpc_kernel<9, true, false>(MpcLaunch, MpcIO);
+template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
+extern template __global__ void qr_mpc_kernel<3, false, false, 384>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -41,16 +43,22 @@ __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, 
                               const float *g_fr, int type_ready, int epilogue);
 }
 
-static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h)
+static int mpc_main_wgs()
+{   // workgroups of the h <= 11 main pass per CU: 2 (80 KB each: every robot fits) or 3 (53 KB: robots above ~32 stance leg-steps go to the list launches)
+    static const int v = [] { const char *e = getenv("QRGPU_MAIN_WGS"); const int k = e ? atoi(e) : 2; return (k == 3) ? 3 : 2; }();
+    return v;
+}
+
+static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h, bool inspection = false)
 {
-    // Packed inverse Hessian for the all-stance worst case plus room for S^-1; two workgroups
-    // per CU when that fits in half the LDS, otherwise the whole CU.
+    // Packed inverse Hessian for the all-stance worst case plus room for S^-1; two (or three) workgroups
+    // per CU when that fits, otherwise the whole CU.
     const size_t fixed = mpc_lds_fixed_bytes(h, true);
     const size_t nmax = 12 * (size_t)h;
     const size_t mp = 8 * (nmax * (nmax + 1) / 2);
     const size_t want = fixed + mp + 8 * (size_t)(24 * 25 / 2);     // at least a 24-row S^-1 in the worst case
     const size_t cu = (size_t)ctx->lds_per_cu;
-    if (want <= cu / 2) return (int)(cu / 2);
+    if (want <= cu / 2) return (4 * h <= 44 && mpc_main_wgs() == 3 && !inspection) ? (int)((cu / 3) & ~(size_t)15) : (int)(cu / 2);
     return (int)cu;
 }
 
@@ -328,7 +336,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, c->stream));
         c->warm_n = n;
     }
-    P.lds_bytes = mpc_lds_bytes(c, P.horizon);
+    P.lds_bytes = mpc_lds_bytes(c, P.horizon, dH != nullptr);      // (inspection launches have no list pass behind them)
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
     P.order = (lpt && c->lpt_n == n) ? c->d_order : nullptr;
@@ -359,15 +367,18 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 2 * sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
     }
-    // kernel variant: 0 = <4 blocks per thread> (h <= 11), 1 = <9, positions 64..95 in a second register set> (h <= 16)
-    const int var = small ? 0 : 1;
-    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<4, false, false> : (const void *)qr_mpc_kernel<9, true, false>;
+    // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 0 / 2 = the same on six / four
+    // waves (QRGPU_MAIN_THREADS=384 / 256, for A/B runs), 1 = <9, positions 64..95 in a second register set> (h <= 16)
+    static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
+    const int var = small ? (main_threads == 256 ? 2 : main_threads == 384 ? 0 : 3) : 1;
+    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<3, false, false, 384> : var == 2 ? (const void *)qr_mpc_kernel<4, false, false, 256>
+                   : var == 3 ? (const void *)qr_mpc_kernel<2, false, false, 512> : (const void *)qr_mpc_kernel<9, true, false, 256>;
     if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
         c->configured_lds[var] = P.lds_bytes;
     }
     if (rescue && c->configured_rescue[0] < c->lds_per_cu) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
+        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
         c->configured_rescue[0] = c->lds_per_cu;
     }
     MpcIO io;
@@ -383,16 +394,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         L.lds_bytes = c->lds_per_cu;
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        const int pgrid = c->big_nls > 0 ? 64 : 16;
-        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, c->side_stream, L, io);
+        int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
+        pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
+        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, c->side_stream, L, io);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
     }
     {
         TimerScope ts(c, 0);
-        const dim3 grid(8 * ((n + 7) / 8)), block(256);
-        if (var == 0) hipLaunchKernelGGL((qr_mpc_kernel<4, false, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, io);
-        else hipLaunchKernelGGL((qr_mpc_kernel<9, true, false>), grid, block, (size_t)P.lds_bytes, c->stream, P, io);
+        const dim3 grid(8 * ((n + 7) / 8));
+        if (var == 0) hipLaunchKernelGGL((qr_mpc_kernel<3, false, false, 384>), grid, dim3(384), (size_t)P.lds_bytes, c->stream, P, io);
+        else if (var == 2) hipLaunchKernelGGL((qr_mpc_kernel<4, false, false, 256>), grid, dim3(256), (size_t)P.lds_bytes, c->stream, P, io);
+        else if (var == 3) hipLaunchKernelGGL((qr_mpc_kernel<2, false, false, 512>), grid, dim3(512), (size_t)P.lds_bytes, c->stream, P, io);
+        else hipLaunchKernelGGL((qr_mpc_kernel<9, true, false, 256>), grid, dim3(256), (size_t)P.lds_bytes, c->stream, P, io);
     }
     HIPCHK(c, hipGetLastError());
     if (have_plan) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -409,7 +423,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         int rgrid = 64 < n ? 64 : n;
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
-        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
+        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
         HIPCHK(c, hipGetLastError());
         c->rescue_parity ^= 1;
         if (planned) c->plan_n = n;

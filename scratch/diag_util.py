@@ -1,4 +1,5 @@
-"""Slot utilisation of the main MPC launch: sum of per-robot solve times / (resident slots x launch span), from the kernel's own stamps."""
+"""Concurrency of the main MPC launch from the kernel's own stamps: per XCD (the clock is read per XCD), how many robots are in flight
+over time, the launch span, and sum(solve time) / (slots x span)."""
 import sys, os, ctypes as C
 sys.path.insert(0, '/root/repo/tests')
 import numpy as np
@@ -12,23 +13,29 @@ G.setup_a1(ctx, pkg, h)
 lib = ctx._lib
 lib.qrgpu_debug_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.qrgpu_debug_cycles(ctx._h, None, 0)
-ctx.set_planned_list(False)
-names = ["load+srbd", "H/g build", "sweep inv", "x0", "active set", "out"]
-for seed in (0xA1 + 2, 0xA1 + 2 + 1000):
-    seq = pkg.make_batch_sequence(n, h, "a1", seed=seed, steps=6)
-    for warm, lpt in ((True, True), (True, False), (False, True)):
-        ctx.set_warm_start(warm); ctx.set_lpt_schedule(lpt)
-        for b in seq:
-            out = G.run_mpc(ctx, pkg, b)
-        buf = np.zeros((n, 16), np.int64)
-        lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, n)
-        ok = (out["status"] & 0x4) == 0
-        t0, t6 = buf[ok, 0], buf[ok, 6]
-        tot = (t6 - t0).astype(np.float64)
-        span = t6.max() - t0.min()
-        d = np.diff(buf[ok, :7], axis=1).astype(np.float64)
-        print("seed %x warm %s lpt %s: robots %d, per-robot total mean %.0f max %.0f, span %.0f, slots*span/sum = %.2f (1 = perfect packing on 512 slots), phases mean %s" % (
-            seed, warm, lpt, ok.sum(), tot.mean(), tot.max(), span, 512.0 * span / tot.sum(), dict(zip(names, d.mean(0).round(0)))))
-        # start-time histogram: how many robots start in the first 5% of the span
-        st = (t0 - t0.min()) / span
-        print("   robots started in the first 2%% of the span: %d; last start at %.2f of the span; longest robot started at %.2f" % ((st < 0.02).sum(), st.max(), st[np.argmax(tot)]))
+planned = len(sys.argv) > 2 and sys.argv[2] == 'planned'
+ctx.set_planned_list(planned)
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0xA1 + 2
+seq = pkg.make_batch_sequence(n, h, "a1", seed=seed, steps=6)
+for lpt in (True, False):
+    ctx.set_lpt_schedule(lpt)
+    for b in seq:
+        out = G.run_mpc(ctx, pkg, b)
+    buf = np.zeros((n, 16), np.int64)
+    lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, n)
+    t0, t6 = buf[:, 12], buf[:, 13]                 # 100 MHz wall clock, shared by every CU
+    good = t6 > t0
+    t0, t6 = t0[good].astype(np.float64), t6[good].astype(np.float64)
+    span = t6.max() - t0.min()
+    tot = (t6 - t0).sum()
+    ts = t0.min() + (np.arange(24) + 0.5) / 24 * span
+    inflight = [(int(((t0 <= t) & (t6 > t)).sum())) for t in ts]
+    print("lpt %s: robots %d, span %.1f us, mean solve %.1f us, max solve %.1f us, average robots in flight %.0f (512 slots), in flight over time: %s" % (
+        lpt, good.sum(), span / 100, (t6 - t0).mean() / 100, (t6 - t0).max() / 100, tot / span, inflight))
+    order = np.argsort(t0)
+    print("   start times (us) of robots 0, 256, 511, 512, 600, 768, 1023 in start order:", [round((t0[order[k]] - t0.min()) / 100, 1) for k in (0, 256, 511, 512, 600, 768, min(1023, len(order) - 1))])
+    nls_all = (buf[:, 7] // 3)[good]
+    big = np.where((t6 - t0) > 0)[0][np.argsort(-(t6 - t0))[:4]]
+    print("   longest solves: (start us, length us, nls, final q)", [(round((t0[k] - t0.min()) / 100, 1), round((t6[k] - t0[k]) / 100, 1), int(nls_all[k]), int(buf[good][k, 14])) for k in big])
+    late = np.argsort(-t6)[:5]
+    print("   last finishers: (start us, length us)", [(round((t0[k] - t0.min()) / 100, 1), round((t6[k] - t0[k]) / 100, 1)) for k in late])
