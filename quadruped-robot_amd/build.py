@@ -12,8 +12,15 @@ SOURCES = ["qr_mpc_kernel.hip", "qr_wbc_kernel.hip", "qr_frontend_kernel.hip", "
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast-honor-pragmas", "-fPIC", "-Wno-unused-value", "-I/opt/rocm/include"]
 
 
+def _flags():
+    return FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else []) + os.environ.get("QRGPU_EXTRA_FLAGS", "").split()
+
+
 def _stale():
     if not os.path.exists(SO):
+        return True
+    stamp = SO + ".flags"                       # a build with other flags (diagnostic -D switches) is another build
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(_flags()):
         return True
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
@@ -39,7 +46,7 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(verbose):
-    flags = FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else []) + os.environ.get("QRGPU_EXTRA_FLAGS", "").split()
+    flags = _flags()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -56,6 +63,8 @@ def _build_locked(verbose):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
     subprocess.check_call(cmd)
+    with open(SO + ".flags", "w") as f:
+        f.write(" ".join(flags))
     return SO
 
 

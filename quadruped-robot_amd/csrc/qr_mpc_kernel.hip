@@ -1517,7 +1517,6 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
     }
 }
 
-template __global__ void qr_mpc_kernel<3, false, false, 384>(MpcLaunch, MpcIO);     // h <= 11, main pass: six waves build and sweep, four solve
 template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
 template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)

@@ -3,6 +3,7 @@
 // No torch, no CPU compute path: every solve is a kernel launch on gfx950.
 // ============================================================================
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +24,6 @@ struct MpcIO {
     long long *dbgT;
 };
 template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
-extern template __global__ void qr_mpc_kernel<3, false, false, 384>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
@@ -200,6 +200,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
@@ -229,6 +230,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_flops) hipFree(c->d_flops);
     if (c->d_pre) hipFree(c->d_pre);
     if (c->d_skip) hipFree(c->d_skip);
+    if (c->h_pre_count) hipHostFree(c->h_pre_count);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
@@ -367,11 +369,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 2 * sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
     }
-    // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 0 / 2 = the same on six / four
-    // waves (QRGPU_MAIN_THREADS=384 / 256, for A/B runs), 1 = <9, positions 64..95 in a second register set> (h <= 16)
+    // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 2 = the same on four waves
+    // (QRGPU_MAIN_THREADS=256, for A/B runs; six waves were measured too: the second workgroup of a CU then often cannot be placed until
+    // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = small ? (main_threads == 256 ? 2 : main_threads == 384 ? 0 : 3) : 1;
-    const void *fn = var == 0 ? (const void *)qr_mpc_kernel<3, false, false, 384> : var == 2 ? (const void *)qr_mpc_kernel<4, false, false, 256>
+    const int var = small ? (main_threads == 256 ? 2 : 3) : 1;
+    const void *fn = var == 2 ? (const void *)qr_mpc_kernel<4, false, false, 256>
                    : var == 3 ? (const void *)qr_mpc_kernel<2, false, false, 512> : (const void *)qr_mpc_kernel<9, true, false, 256>;
     if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
@@ -384,32 +387,41 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     MpcIO io;
     io.type_id = d_type; io.g_state = d_state; io.g_traj = d_traj; io.g_gait = d_gait; io.g_q = d_q; io.g_force = d_force; io.g_tau = d_tau;
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
-    const bool have_plan = planned && c->plan_n == n;
+    // the planned launch (and its two stream events) is only worth issuing when the last plan listed somebody: the list's length comes back
+    // through pinned memory without a sync.  A stale zero just means the main pass solves everybody (P.skip stays null): consistent either way.
+    if (planned && c->plan_n != n) { c->h_pre_count[0] = c->h_pre_count[1] = 0; }
+    const bool have_plan = planned && c->plan_n == n && c->h_pre_count[c->rescue_parity] > 0;
+    // QRGPU_PLANNED_MODE: 0 = planned list on the context's side stream (fork / join events), 1 = planned list and main pass on the SAME
+    // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
+    // workgroups (each needs a whole CU's LDS) are dispatched first, the main pass's fill the rest of the machine
+    static const int planned_mode = [] { const char *e = getenv("QRGPU_PLANNED_MODE"); return e ? atoi(e) : 0; }();
     if (have_plan) {
-        // the planned list launch goes first, on the side stream, beside the main pass: whole CU's LDS, 96 positions, workgroup b takes
-        // entries b, b + grid, ... of the list the last call's planning left
+        // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
         P.skip = c->d_skip;
         MpcLaunch L = P;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = c->lds_per_cu;
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
-        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, c->side_stream, L, io);
+        hipStream_t ls = planned_mode == 1 ? c->stream : c->side_stream;
+        if (planned_mode != 1) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        }
+        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, ls, L, io);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
     }
     {
         TimerScope ts(c, 0);
         const dim3 grid(8 * ((n + 7) / 8));
-        if (var == 0) hipLaunchKernelGGL((qr_mpc_kernel<3, false, false, 384>), grid, dim3(384), (size_t)P.lds_bytes, c->stream, P, io);
-        else if (var == 2) hipLaunchKernelGGL((qr_mpc_kernel<4, false, false, 256>), grid, dim3(256), (size_t)P.lds_bytes, c->stream, P, io);
-        else if (var == 3) hipLaunchKernelGGL((qr_mpc_kernel<2, false, false, 512>), grid, dim3(512), (size_t)P.lds_bytes, c->stream, P, io);
-        else hipLaunchKernelGGL((qr_mpc_kernel<9, true, false, 256>), grid, dim3(256), (size_t)P.lds_bytes, c->stream, P, io);
+        void *kargs[2] = {(void *)&P, (void *)&io};
+        const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
+        const int threads = var == 3 ? 512 : 256;
+        HIPCHK(c, hipExtLaunchKernel(fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
-    if (have_plan) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (have_plan && planned_mode != 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (rescue) {
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
@@ -425,8 +437,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
         HIPCHK(c, hipGetLastError());
+        if (planned) {
+            // the list just planned (parity ^ 1) is what the next call reads
+            HIPCHK(c, hipMemcpyAsync(c->h_pre_count + (c->rescue_parity ^ 1), c->d_pre + (c->rescue_parity ^ 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            c->plan_n = n;
+        }
         c->rescue_parity ^= 1;
-        if (planned) c->plan_n = n;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {

@@ -37,5 +37,9 @@ for lpt in (True, False):
     nls_all = (buf[:, 7] // 3)[good]
     big = np.where((t6 - t0) > 0)[0][np.argsort(-(t6 - t0))[:4]]
     print("   longest solves: (start us, length us, nls, final q)", [(round((t0[k] - t0.min()) / 100, 1), round((t6[k] - t0[k]) / 100, 1), int(nls_all[k]), int(buf[good][k, 14])) for k in big])
+    kbig = big[0]
+    ph = np.diff(buf[good][kbig, :7]).astype(np.float64)
+    itb = ((out["status"][good][kbig] >> 8) & 0xffff)
+    print("   longest robot: phase cycles load %d, H %d, sweep %d, x0 %d, active set %d, out %d | iterations %d | status %d" % (*ph, itb, out["status"][good][kbig] & 0xff))
     late = np.argsort(-t6)[:5]
     print("   last finishers: (start us, length us)", [(round((t0[k] - t0.min()) / 100, 1), round((t6[k] - t0[k]) / 100, 1)) for k in late])
