@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements (slot-order dispatch, K12 off, replayed batch, PCIe, 8f kernels)")
     ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
+    ap.add_argument("--hessian", default="f32", choices=["f32", "bf16x3"],
+                    help="K4 arithmetic: f32 = exact fp32 matrix instruction (default); bf16x3 = three-limb bf16 on the bf16 matrix cores (BASELINE.json configs[4])")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE.json configs[4] per GPU: A1 and Lite3 interleaved (type_id per robot), usually with --horizon 16; mode tick only")
     args = ap.parse_args()
@@ -267,6 +269,7 @@ def main():
     if world > 1 and not rehearsal:
         ctx.comm_init_rank(pkg.shard.exchange_comm_id(rank, pkg.qrgpu.comm_unique_id), world, rank)     # RCCL communicator owned by the context
     ctx.set_torque_epilogue(hip_comp=True, clip=True)          # K14 tail is part of the tick SURVEY 8(d) defines
+    ctx.set_hessian_mode(args.hessian)
 
     # ---- populations: D draws x a coherent sequence each, all resident in HBM before anything is timed -----------------------
     D = max(1, min(args.draws, args.steps))
@@ -481,8 +484,8 @@ def main():
             "metric": "MPC+WBC control ticks/s (batched robots)" if args.mode == "tick" else "%s-only control ticks/s (batched robots)" % args.mode.upper(),
             "value": value, "unit": "ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, %s (fp32 assembly, fp64 QP)" % (n // 2, n // 2, h, what)) if args.mixed
+            "dtype": ("bf16x3 Hessian (fp32 accumulate) / f32 assembly / f64 QP+WBC" if args.hessian == "bf16x3" else "f32 assembly / f64 QP+WBC"), "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, %s (%s, fp64 QP)" % (n // 2, n // 2, h, what, "bf16x3 Hessian MFMA" if args.hessian == "bf16x3" else "fp32 assembly")) if args.mixed
                        else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, %s" % (n, h, what)
                        if args.mode == "tick" else "%d A1 robots per GPU, horizon %d, %s only" % (n, h, args.mode),
                        "robots_per_gpu": n, "horizon": h, "excite": args.excite,
@@ -497,6 +500,43 @@ def main():
                        **side},
             "roofline": roof,
         }
+        if world == 1 and not args.no_cpu_baseline and args.mixed and args.mode == "tick":
+            # configs[4] per GPU: the CPU restatement type by type (it has one parameter set per call), and the error of this run's
+            # arithmetic against the exact fp32 path on the same batch
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as O
+            O.build()
+            cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+            b0 = host0[0]
+            tid_h = pkg.shard.interleave_types(n, 2)
+            f_cpu = np.zeros((n, 12), np.float32); tau_cpu = np.zeros((n, 12), np.float32); st_cpu = np.zeros(n, np.int32)
+            wall = 0.0
+            for robot, t in (("a1", 0), ("lite3", 1)):
+                m = tid_h == t
+                t0 = time.perf_counter()
+                fr, tr, sr, _, _ = O.tick_batch(1, pkg.mpc_cfg(robot), h, pkg.model_desc(robot)[:3], pkg.model_desc(robot), b0["mpc_state"][m], b0["traj"][m], b0["gait"][m],
+                                                b0["fb_state"][m], b0["wbc_cmd"][m], b0["prev_ori_vel"][m].copy(), nthreads=cores, epilogue=3)
+                wall += time.perf_counter() - t0
+                f_cpu[m], tau_cpu[m], st_cpu[m] = fr, tr, sr
+            out["cpu_baseline"] = dict(value=n / wall, unit="ticks/s", cores=cores, kind="port",
+                                       sample="one pass over the %d-robot mixed batch (draw 0, first batch), A1 and Lite3 halves in turn, %d threads" % (n, cores))
+            ds, dt_, dg, dfb, dcmd = dev_seq[0][0]
+            res = {}
+            for mode in ("f32", args.hessian):
+                ctx.set_hessian_mode(mode); ctx.set_warm_start(False)
+                d_prev.zero_()
+                d_f1, d_t1, d_s1 = torch.zeros_like(d_force), torch.zeros_like(d_tau2[0]), torch.zeros_like(d_status)
+                ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_f1, d_t1, d_s1, d_type, qdes=d_qdes)
+                torch.cuda.synchronize()
+                res[mode] = (d_f1.cpu().numpy().T, d_t1.cpu().numpy().T, d_s1.cpu().numpy())
+            ctx.set_warm_start(True)
+            fg, tg, sg = res[args.hessian]
+            ok = ((sg.astype(np.int64) & 0xff0000ff) == 0) & (st_cpu == 0)
+            cfgo = out["config"]
+            cfgo["max_rel_torque_err_vs_cpu"] = float((np.abs(tg - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
+            cfgo["max_rel_force_err_vs_cpu"] = float((np.abs(fg - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
+            cfgo["max_rel_torque_err_vs_fp32_path"] = float((np.abs(tg - res["f32"][1]) / np.maximum(1.0, np.abs(res["f32"][1]))).max())
+            cfgo["robots_compared_with_cpu"] = int(ok.sum())
         if world == 1 and not args.no_cpu_baseline and not args.mixed and args.mode != "wbc":
             b0 = host0[0]
             out["cpu_baseline"] = cpu_baseline(pkg, b0, h, mode=0 if args.mode == "mpc" else 1)

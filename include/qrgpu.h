@@ -175,6 +175,19 @@ int qrgpu_mpc_setup(qrgpu_ctx *ctx, int type_id, float dt, int horizon, float mu
                     const float inertia[3], const float weights[12], float alpha);
 int qrgpu_wbc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_model_desc *desc);
 
+/* Arithmetic of the Hessian contraction qH = temp * Bqp (K4, qr_mpc_interface.cpp:396-412) of every MPC solve of this context:
+ *   QRGPU_HESSIAN_F32     (default) v_mfma_f32_16x16x4_f32: bit for bit the k-ordered fp32 fmaf chain of the reference's dense GEMM;
+ *   QRGPU_HESSIAN_BF16X3  BASELINE.json configs[4] ("fp32 QP + bf16 Hessian MFMA"): every fp32 operand cut into three bf16 limbs, the six
+ *                         leading cross products per term summed in fp32 by v_mfma_f32_16x16x32_bf16.  H comes out within an ulp or two of the
+ *                         exact fp32 assembly (measured 7.5e-9 absolute: the size of the exact H's own asymmetry) but not bit-identical, and on
+ *                         this QP an ulp of H is amplified by 1 / (2 alpha): forces move as they do between the reference's own answers for H
+ *                         and H^T.  Stated tolerance against the default mode (tests/test_gpu_mpc.py::test_bf16x3_hessian): median force
+ *                         deviation <= 1e-4 of the force scale; worst robot <= 2e-3 (forces) / 5e-2 max(1, |tau|) at h = 10 and 3e-2 / 0.3 at h = 16.
+ *                         Slower than the default here (the limb cuts dominate); it exists because that configuration names it. */
+#define QRGPU_HESSIAN_F32    0
+#define QRGPU_HESSIAN_BF16X3 1
+int qrgpu_mpc_set_hessian_mode(qrgpu_ctx *ctx, int mode);
+
 /* ---- batched device-pointer API (the measured path) -------------------------- */
 /* d_type_id may be NULL (all robots type 0).  d_q: joint angles [12][n] (needed by the
  * J^T f torque map; pass fb_state + 13*n to reuse the WBC state).  d_status may be NULL. */

@@ -79,6 +79,7 @@ struct MpcLaunch {
     double *flops;              // [robot][4] executed-arithmetic counts of the solve (qrgpu_mpc_flop_counts), or null
     int type_ready;             // bit t: type t was set up (robots naming any other type are flagged QRGPU_ST_BAD_TYPE)
     int epilogue;               // QRGPU_EPILOGUE_* bits applied to g_tau (MPC-only batches; 0 inside the fused tick)
+    int hess_mode;              // K4 arithmetic: 0 = fp32 matrix instruction (exact fmaf chain), 1 = three-limb bf16 on the bf16 matrix instruction
 };
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.

@@ -588,6 +588,49 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #if defined(QR_DIAG_REFAC)
             const long long tl0 = clock64();
 #endif
+            if (P.hess_mode == 1) {
+                // BASELINE.json configs[4]'s arithmetic: the same contraction on the bf16 matrix cores.  Every fp32 operand is cut into three
+                // bf16 limbs (8 + 8 + 8 significant bits: x = hi + mid + lo exactly up to the last limb's rounding) and the product a * b is taken as
+                // the six cross terms hh + hm + mh + hl + mm + lh (what is left out is below 2^-24 of it), summed in fp32 by
+                // v_mfma_f32_16x16x32_bf16: one instruction covers the same four state rows s = 4 q + g as the fp32 instruction it replaces, its
+                // K = 32 being 4 lane groups x (6 terms + 2 zeros).  NOT bit-identical to the fp32 chain (another summation order and tree):
+                // tolerance in tests/test_gpu_mpc.py::test_bf16x3_hessian.  Operand generation (the limb cuts) dominates here, so this mode is
+                // slower than the exact one on this problem; it exists because that configuration names it.
+                typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+                union PK { unsigned u[4]; bf8 v; };
+                auto limbs = [](float x, unsigned &hi, unsigned &mid, unsigned &lo) {
+                    const __bf16 bh = (__bf16)x;
+                    const float r1 = x - (float)bh;
+                    const __bf16 bm = (__bf16)r1;
+                    const float r2 = r1 - (float)bm;
+                    const __bf16 bl = (__bf16)r2;
+                    hi = (unsigned)__builtin_bit_cast(unsigned short, bh); mid = (unsigned)__builtin_bit_cast(unsigned short, bm); lo = (unsigned)__builtin_bit_cast(unsigned short, bl);
+                };
+                auto packA = [&](float x) { unsigned a, b, c; limbs(x, a, b, c); PK p; p.u[0] = a | (a << 16); p.u[1] = b | (a << 16); p.u[2] = b | (c << 16); p.u[3] = 0u; return p.v; };   // hi hi mid hi mid lo 0 0
+                auto packB = [&](float x) { unsigned a, b, c; limbs(x, a, b, c); PK p; p.u[0] = a | (b << 16); p.u[1] = a | (c << 16); p.u[2] = b | (a << 16); p.u[3] = 0u; return p.v; };   // hi mid hi lo mid hi 0 0
+                // the operands that do not change with the horizon step are cut once per tile
+                const bf8 Ak2g = packA(k2R), Ak2t = packA(t2R), Bk2g = packB(k2C), Bk2t = packB(t2C);
+                const bf8 Ak1g = packA(k1R), Ak1t = packA(t1R), Bk1g = packB(k1C), Bk1t = packB(t1C);
+                const bf8 zero8 = packA(0.f);
+                for (int r = r0; r < h; ++r) {
+                    const bool onR = r >= iaR, onC = r >= iaC;
+                    const float cR = ((float)(r - iaR) + 0.5f) * dt2, cC = ((float)(r - iaC) + 0.5f) * dt2;
+                    float gR = cR * a0R, gC = cC * a0C;
+                    float tR = gR * w2q0, tC = gC * w2q0;
+                    gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(packA(tR), packB(gC), acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(packA(gR), packB(tC), acc2, 0, 0, 0);
+                    const float hR = cR * a1R, hC = cC * a1C;
+                    const bf8 a1t = (g < 2) ? packA(onR ? hR * w2q1 : 0.f) : (onR ? Ak1t : zero8);
+                    const bf8 a1g = (g < 2) ? packA(onR ? hR : 0.f) : (onR ? Ak1g : zero8);
+                    const bf8 b1g = (g < 2) ? packB(onC ? hC : 0.f) : (onC ? Bk1g : zero8);
+                    const bf8 b1t = (g < 2) ? packB(onC ? hC * w2q1 : 0.f) : (onC ? Bk1t : zero8);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1t, b1g, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1g, b1t, acc2, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onR ? Ak2t : zero8, onC ? Bk2g : zero8, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onR ? Ak2g : zero8, onC ? Bk2t : zero8, acc2, 0, 0, 0);
+                }
+            } else
             for (int r = r0; r < h; ++r) {
                 const bool onR = r >= iaR, onC = r >= iaC;
                 const float cR = ((float)(r - iaR) + 0.5f) * dt2, cC = ((float)(r - iaC) + 0.5f) * dt2;

@@ -253,6 +253,12 @@ int qrgpu_set_warm_start(qrgpu_ctx *c, int on)
     c->warm_n = 0;                 // forget what is stored
     return QRGPU_OK;
 }
+int qrgpu_mpc_set_hessian_mode(qrgpu_ctx *c, int mode)
+{
+    if (!c || (mode != QRGPU_HESSIAN_F32 && mode != QRGPU_HESSIAN_BF16X3)) return QRGPU_ERR_BAD_ARG;
+    c->mpc.hess_mode = mode;
+    return QRGPU_OK;
+}
 int qrgpu_set_planned_list(qrgpu_ctx *c, int on, int big_nls)
 {
     if (!c || big_nls < 0) return QRGPU_ERR_BAD_ARG;

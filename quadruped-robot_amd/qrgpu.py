@@ -90,7 +90,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
-           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts"]
+           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode"]
 
 
 def load_library():
@@ -111,6 +111,7 @@ def load_library():
     lib.qrgpu_set_warm_start.argtypes = [vp, ip]
     lib.qrgpu_set_planned_list.argtypes = [vp, ip, ip]
     lib.qrgpu_enable_flop_count.argtypes = [vp, ip]
+    lib.qrgpu_mpc_set_hessian_mode.argtypes = [vp, ip]
     lib.qrgpu_mpc_flop_counts.argtypes = [vp, C.POINTER(C.c_double)]
     lib.qrgpu_last_error.argtypes = [vp]; lib.qrgpu_last_error.restype = C.c_char_p
     lib.qrgpu_device_info.argtypes = [vp, C.c_char_p, ip, C.POINTER(ip)]
@@ -377,6 +378,10 @@ class Context:
     def set_warm_start(self, on=True):
         """Start each robot slot's active set from its previous solve (speed only; results agree with a cold start to solver tolerance)."""
         self._chk(self._lib.qrgpu_set_warm_start(self._h, 1 if on else 0))
+
+    def set_hessian_mode(self, mode="f32"):
+        """K4 arithmetic: "f32" (exact, default) or "bf16x3" (three-limb bf16 on the bf16 matrix cores: BASELINE.json configs[4])."""
+        self._chk(self._lib.qrgpu_mpc_set_hessian_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]))
 
     def set_planned_list(self, on=True, big_nls=0):
         """Robots that needed the rescue pass last call are solved beside the main launch this call (scheduling only)."""
