@@ -61,7 +61,8 @@ struct MpcLaunch {
     // allotment, or belong to the big class nls >= big_nls) are solved by a list launch of their own, issued on a second stream AT THE
     // START of the next call, beside the main launch (which skips them), instead of after it.  pre_list / pre_count[parity] / skip[robot] are
     // written by the trailing list launch's planning workgroups from the `big` bit each solve leaves in cost[robot] (bit 8).
-    int *pre_count;
+    int *pre_count;             // [0], [1] list lengths by call parity, [2] planning workgroups done (last one publishes the hint)
+    int *pre_hint;              // the same two lengths in pinned host memory (the host decides from them whether to issue the planned launch), or null
     int *pre_list;
     unsigned char *skip;
     int big_nls;                // 0 = no class rule

@@ -1538,6 +1538,15 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                     if (big) P.pre_list[atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 1)] = i;
                 }
                 __syncthreads();
+                // the last of the eight planning workgroups tells the host how long the list is (a write to pinned host memory: no copy
+                // command on the stream, no sync)
+                if (threadIdx.x == 0 && P.pre_hint) {
+                    __threadfence();
+                    if (atomicAdd(P.pre_count + 2, 1) == 7) {
+                        P.pre_hint[P.rescue_parity ^ 1] = atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 0);
+                        __threadfence_system();
+                    }
+                }
             }
         }
         const int *list = planned ? P.pre_list : P.rescue_list;
@@ -1552,7 +1561,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         if (slot < 0) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
             if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
-            if (P.pre_count) P.pre_count[P.rescue_parity ^ 1] = 0;
+            if (P.pre_count) { P.pre_count[P.rescue_parity ^ 1] = 0; P.pre_count[2] = 0; }
         }
         const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
         if (P.skip && P.skip[rid]) return;             // solved by the planned list launch, beside this one

@@ -199,8 +199,9 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 4)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_pre_hint, c->h_pre_count, 0) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
@@ -367,12 +368,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
     P.pre_count = planned ? c->d_pre : nullptr;
-    P.pre_list = planned ? c->d_pre + 2 : nullptr;
+    P.pre_list = planned ? c->d_pre + 4 : nullptr;
+    P.pre_hint = planned ? c->d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
     P.lds_main = P.lds_bytes;
     if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
-        HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 2 * sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 4 * sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
     }
     // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 2 = the same on four waves
@@ -443,11 +445,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
         HIPCHK(c, hipGetLastError());
-        if (planned) {
-            // the list just planned (parity ^ 1) is what the next call reads
-            HIPCHK(c, hipMemcpyAsync(c->h_pre_count + (c->rescue_parity ^ 1), c->d_pre + (c->rescue_parity ^ 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            c->plan_n = n;
-        }
+        if (planned) c->plan_n = n;        // (the length of the list just planned reaches h_pre_count by itself)
         c->rescue_parity ^= 1;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch

@@ -38,6 +38,7 @@ struct qrgpu_ctx {
     int *d_pre = nullptr;
     unsigned char *d_skip = nullptr;
     int plan_n = 0;
+    int *d_pre_hint = nullptr;    // device-side address of h_pre_count
     int *h_pre_count = nullptr;   // pinned: the planned list's length as of the last call (copied back without a sync; stale by a call or two at worst)
     bool planned = true;
     int big_nls = 0;
