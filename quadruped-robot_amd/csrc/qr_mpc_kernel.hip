@@ -1518,7 +1518,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 //                 of the rescue list (robots whose working set outgrew the main pass's registers or LDS) with this launch's larger LDS
 //                 allotment and the BIG register set.
 template <int MAXB, bool BIG, bool LIST, int NTHR>
-__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : 1))
+__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
@@ -1572,7 +1572,8 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
 template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
-template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16
+template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
+template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

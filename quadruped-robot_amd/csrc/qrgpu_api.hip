@@ -28,6 +28,7 @@ extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, M
 extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -381,9 +382,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // (QRGPU_MAIN_THREADS=256, for A/B runs; six waves were measured too: the second workgroup of a CU then often cannot be placed until
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = small ? (main_threads == 256 ? 2 : 3) : 1;
+    static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
+    const int var = small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0);
     const void *fn = var == 2 ? (const void *)qr_mpc_kernel<4, false, false, 256>
-                   : var == 3 ? (const void *)qr_mpc_kernel<2, false, false, 512> : (const void *)qr_mpc_kernel<9, true, false, 256>;
+                   : var == 3 ? (const void *)qr_mpc_kernel<2, false, false, 512>
+                   : var == 0 ? (const void *)qr_mpc_kernel<5, true, false, 512> : (const void *)qr_mpc_kernel<9, true, false, 256>;
     if (c->configured_lds[var] < P.lds_bytes) {
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
         c->configured_lds[var] = P.lds_bytes;
@@ -425,7 +428,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         const dim3 grid(8 * ((n + 7) / 8));
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
-        const int threads = var == 3 ? 512 : 256;
+        const int threads = (var == 3 || var == 0) ? 512 : 256;
         HIPCHK(c, hipExtLaunchKernel(fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
