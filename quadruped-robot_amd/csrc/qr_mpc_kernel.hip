@@ -419,7 +419,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             sLs[pos] = tid;
             fmk[pos] = (double)(sGait[tid] * C.fmax);
         }
-        if (tid == 0) { sMisc[0] = __popcll(mask); sMisc[2] = (int)(unsigned)mask; sMisc[3] = (int)(unsigned)(mask >> 32); }
+        if (tid == 0) { sMisc[0] = __popcll(mask); sMisc[1] = 0; sMisc[2] = (int)(unsigned)mask; sMisc[3] = (int)(unsigned)(mask >> 32); }
     }
     // v = Aqp x0 - X_d, one horizon step per thread (wave 1 so it overlaps the above)
     if (tid >= 64 && tid < 64 + h) {
@@ -725,6 +725,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
     }
     __syncthreads();               // every block is in registers: the M region can now carry the pivot panels
+    // A wave beyond the active set's four that owns no block (a trotting robot's 300 blocks fill 4.7 of the 8 waves) is done: it would only
+    // load panels and wait at barriers (a wave that has ended no longer counts there), competing for the LDS pipe with the ones that work.
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS && (tid & ~63) >= npairs) return;
     {
         double *panel0 = Mb, *panel1 = Mb + NL * 9;
 #ifdef QR_SWEEP_STAMPS
@@ -733,11 +736,24 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #else
 #define VS_STAMP(i) do { } while (0)
 #endif
-        // the pivot column of step kk out of block sl: block (a, kk), a >= kk, is C_a; block (kk, b), b < kk, is C_b'
+        // the pivot column of step kk out of block sl: block (a, kk), a > kk, is C_a; block (kk, b), b < kk, is C_b'; the owner of the
+        // pivot block (kk, kk) publishes P^-1 (3x3 symmetric, adjugate / determinant) in its place: once per pivot, not once per thread
         auto write_panel = [&](int sl, int kk, double *pn) {
             if (bb[sl] == kk) {
+                if (ba[sl] == kk) {
+                    const double *Pk = A[sl].m;
+                    const double p00 = Pk[0], p01 = 0.5 * (Pk[1] + Pk[3]), p02 = 0.5 * (Pk[2] + Pk[6]), p11 = Pk[4], p12 = 0.5 * (Pk[5] + Pk[7]), p22 = Pk[8];
+                    const double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
+                    const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
+                    const double det = p00 * c00 + p01 * c01 + p02 * c02;
+                    if (!(det > 0.0) || !(p00 > 0.0)) sMisc[1] = 1;                  // -> QRGPU_ST_MPC_NOTSPD, picked up by thread 0 after the sweep
+                    const double id = fast_rcp(det);
+                    double *d = pn + 9 * kk;
+                    d[0] = c00 * id; d[1] = c01 * id; d[2] = c02 * id; d[4] = c11 * id; d[5] = c12 * id; d[8] = c22 * id;
+                } else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) pn[9 * ba[sl] + i] = A[sl].m[i];
+                    for (int i = 0; i < 9; ++i) pn[9 * ba[sl] + i] = A[sl].m[i];
+                }
             } else if (ba[sl] == kk) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -761,19 +777,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
                 for (int i = 0; i < 9; ++i) { Cx0[i] = Cx[i]; Cb0[i] = Cb[i]; }
             }
-            // P^-1 (3x3 symmetric, adjugate / determinant), redundantly per thread
+            // P^-1 as its owner published it (upper triangle)
             double Pi[9];
             {
                 const double *Pk = pan + 9 * k;
-                const double p00 = Pk[0], p01 = 0.5 * (Pk[1] + Pk[3]), p02 = 0.5 * (Pk[2] + Pk[6]), p11 = Pk[4], p12 = 0.5 * (Pk[5] + Pk[7]), p22 = Pk[8];
-                const double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
-                const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
-                const double det = p00 * c00 + p01 * c01 + p02 * c02;
-                if (!(det > 0.0) || !(p00 > 0.0)) st |= QRGPU_ST_MPC_NOTSPD_D;
-                const double id = fast_rcp(det);
-                Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
-                Pi[3] = Pi[1];    Pi[4] = c11 * id; Pi[5] = c12 * id;
-                Pi[6] = Pi[2];    Pi[7] = Pi[5];    Pi[8] = c22 * id;
+                Pi[0] = Pk[0]; Pi[1] = Pk[1]; Pi[2] = Pk[2]; Pi[4] = Pk[4]; Pi[5] = Pk[5]; Pi[8] = Pk[8];
+                Pi[3] = Pi[1]; Pi[6] = Pi[2]; Pi[7] = Pi[5];
             }
 #ifdef QR_SWEEP_STAMPS
             asm volatile("" :: "v"(Pi[0]), "v"(Pi[4]), "v"(Pi[8]), "v"(Pi[5]));
@@ -837,6 +846,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // phases 0-3 may run on more than four waves (NTHR / 64: one block of a trotting robot's Hessian per thread); the active set is a
     // four-wave protocol, so the others are done here (a wave that has ended no longer counts at the workgroup's barriers)
     if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) return;
+    if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
     if (P.flops) {
         const int NTf = (ns + 15) >> 4;

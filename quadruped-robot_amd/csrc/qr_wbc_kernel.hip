@@ -291,6 +291,19 @@ __device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real th
     wsync();
 }
 
+// Inverse of a symmetric 3 x 3 W (row-major; the lower triangle is read) by cofactors, every lane for itself: iv = {00, 10, 11, 20, 21, 22}.
+// Returns psd_pinv's fast-path test: leading minors > 0 and 1 / ||W^-1||_F > thr, i.e. every eigenvalue provably above the cut.
+__device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6])
+{
+    const real a = W[0], b = W[3], c = W[4], d = W[6], e = W[7], f = W[8];
+    const real c00 = c * f - e * e, c10 = d * e - b * f, c20 = b * e - c * d, c11 = a * f - d * d, c21 = b * d - a * e, c22 = a * c - b * b;
+    const real det = a * c00 + b * c10 + d * c20;
+    const real id = 1.0 / det;
+    iv[0] = c00 * id; iv[1] = c10 * id; iv[2] = c11 * id; iv[3] = c20 * id; iv[4] = c21 * id; iv[5] = c22 * id;
+    const real fro = (iv[0] * iv[0] + iv[2] * iv[2] + iv[5] * iv[5]) + 2.0 * (iv[1] * iv[1] + iv[3] * iv[3] + iv[4] * iv[4]);
+    return (a > 0.0) && (c22 > 0.0) && (det > 0.0) && (fro == fro) && (1.0 > thr * __builtin_sqrt(fro));
+}
+
 #define QR_WBC_LDS_DOUBLES 4608
 
 // 37 KB of LDS per robot allows 4 wavefronts per CU = 1 per SIMD, so each may take the whole 512-entry register file
@@ -705,17 +718,39 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 #pragma unroll
     for (int e = 0; e < 9; ++e) if (lane == e) sRT[e] = Rwb.m[e % 3][e / 3];
     wsync();
-    // task Jacobian loader: Jt <- task t
-    auto load_Jt = [&](int t) {
-        for (int e = lane; e < 54; e += 64) {
-            const int i = e / 18, j = e - 18 * i;
-            real v = 0.0;
-            if (t == 0) { if (j < 3) v = sRT[3 * i + j]; }
-            else if (t == 1) { if (j >= 3 && j < 6) v = sRT[3 * i + j - 3]; }
-            else { v = (j < 6) ? 0.0 : JcA[54 * TLEG(t - 2) + e]; }        // virtualDepend = false: base columns zeroed
-            Jt[e] = v;
+    // A task Jacobian is non-zero in three columns only: orientation = base angular columns 0-2 (Rot^T), position = 3-5 (Rot^T), swing foot
+    // = that leg's joints 6+3l.. (virtualDepend = false zeroes its base columns).  J3[i * ld + k] is entry (i, c0 + k).
+#define TASK_COLS(t, c0, J3, ld)                                                                           \
+    const int c0 = ((t) == 0) ? 0 : ((t) == 1) ? 3 : 6 + 3 * TLEG((t) - 2);                                \
+    const real *J3 = ((t) < 2) ? sRT : JcA + 54 * TLEG((t) - 2) + c0;                                      \
+    const int ld = ((t) < 2) ? 3 : 18
+    // JtPre = Jt N_pre (3 x 18): three terms per entry
+    auto jt_npre = [&](const real *J3, int ld, int c0) {
+        if (lane < 54) {
+            const int i = lane / 18, j = lane - 18 * i;
+            const real *nr = Np + c0 * 18 + j, *jr = J3 + i * ld;
+            JtP[lane] = (jr[0] * nr[0] + jr[1] * nr[18]) + jr[2] * nr[36];
         }
         wsync();
+    };
+    // N_pre <- N_pre - T JtPre  (T = N_pre pinv, 18 x 3): the rank-3 form of N_pre (I - pinv JtPre)
+    auto npre_update = [&](const real *T) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 324) {
+                const int i = fdiv16(e, rcp16(18)), j = e - 18 * i;
+                Np[e] -= (T[3 * i] * JtP[j] + T[3 * i + 1] * JtP[18 + j]) + T[3 * i + 2] * JtP[36 + j];
+            }
+        }
+        wsync();
+    };
+    // lamI (registers, every lane) <- pinv of the 3 x 3 in `lam` with eigenvalue cut thr
+    auto pinv3 = [&](real thr, real iv[6]) {
+        if (!sym3_inverse(lam, thr, iv)) {          // wave-uniform (every lane read the same nine numbers); rare: kinematic singularities
+            psd_pinv(lane, lam, 3, thr, lamI, scr);
+            iv[0] = lamI[0]; iv[1] = lamI[3]; iv[2] = lamI[4]; iv[3] = lamI[6]; iv[4] = lamI[7]; iv[5] = lamI[8];
+        }
     };
 
     QW_TS(5);
@@ -735,37 +770,36 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             wsync();
         }
         for (int t = 0; t < nt; ++t) {
-            load_Jt(t);
-            gemm<18>(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                   // JtPre = Jt N_pre
-            gemm<18>(lane, lam, 3, JtP, 18, false, JtP, 18, true, 3, 3, 18);
-            psd_pinv(lane, lam, 3, thr2, lamI, scr);
-            gemm<3>(lane, JtB, 3, JtP, 18, true, lamI, 3, false, 18, 3, 3);                    // pinv(JtPre) 18x3
-            // delta_q = prev + pinv (posErr - Jt prev),  qdot likewise
-            if (lane < 6) {
-                const int which = lane / 3, i = lane - 3 * which;
-                const real *prevv = which ? dq2 : dq1;
-                const real *tgt = which ? (tkV + 3 * t) : (tkE + 3 * t);
-                real acc = tgt[i];
-                if (t > 0) for (int k = 0; k < 18; ++k) acc -= Jt[i * 18 + k] * prevv[k];
-                tv[lane] = acc;
+            TASK_COLS(t, c0, J3, ld);
+            jt_npre(J3, ld, c0);
+            if (lane < 9) { const int a = lane / 3, b2 = lane - 3 * a; lam[lane] = dot18(JtP + a * 18, 1, JtP + b2 * 18, 1, 18); }
+            wsync();
+            real iv[6];
+            pinv3(thr2, iv);
+            if (lane < 54) {                                                                  // pinv(JtPre) = JtPre^T W^+ (18 x 3)
+                const int r = lane / 3, j = lane - 3 * r;
+                const real i0 = j == 0 ? iv[0] : j == 1 ? iv[1] : iv[3], i1 = j == 0 ? iv[1] : j == 1 ? iv[2] : iv[4], i2 = j == 0 ? iv[3] : j == 1 ? iv[4] : iv[5];
+                JtB[lane] = (JtP[r] * i0 + JtP[18 + r] * i1) + JtP[36 + r] * i2;
             }
             wsync();
+            // delta_q = prev + pinv (posErr - Jt prev),  qdot likewise (lanes 0-17 / 18-35); T1 = N_pre pinv for the projector update
+            real upd = 0.0;
             if (lane < 36) {
                 const int which = lane / 18, i = lane - 18 * which;
-                real *vec = which ? dq2 : dq1;
-                real acc = (t > 0) ? vec[i] : 0.0;
-                for (int k = 0; k < 3; ++k) acc += JtB[i * 3 + k] * tv[3 * which + k];
-                scr[lane] = acc;
+                const real *prevv = which ? dq2 : dq1;
+                const real *tgt = which ? (tkV + 3 * t) : (tkE + 3 * t);
+                real tv3[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    tv3[k] = tgt[k];
+                    if (t > 0) tv3[k] -= (J3[k * ld] * prevv[c0] + J3[k * ld + 1] * prevv[c0 + 1]) + J3[k * ld + 2] * prevv[c0 + 2];
+                }
+                upd = ((t > 0) ? prevv[i] : 0.0) + ((JtB[3 * i] * tv3[0] + JtB[3 * i + 1] * tv3[1]) + JtB[3 * i + 2] * tv3[2]);
             }
+            if (t < nt - 1 && lane < 54) { const int r = lane / 3, j = lane - 3 * r; T1[lane] = dot18(Np + r * 18, 1, JtB + j, 3, 18); }
             wsync();
-            if (lane < 36) { if (lane < 18) dq1[lane] = scr[lane]; else dq2[lane - 18] = scr[lane]; }
-            wsync();
-            if (t < nt - 1) {
-                // N_pre <- N_pre (I - pinv JtPre)
-                // N_pre (I - pinv JtPre) = N_pre - (N_pre pinv) JtPre : an 18x3 and a rank-3 product instead of 18x18x18
-                gemm<18>(lane, T1, 3, Np, 18, false, JtB, 3, false, 18, 3, 18);
-                gemm<3>(lane, Np, 18, T1, 3, false, JtP, 18, false, 18, 18, 3, -1.0, 1.0, Np, 18);
-            }
+            if (lane < 36) { if (lane < 18) dq1[lane] = upd; else dq2[lane - 18] = upd; }
+            if (t < nt - 1) npre_update(T1); else wsync();
         }
         if (lane < 12) {
             g_qdes[(size_t)lane * n + rid] = (float)(qj[lane] + dq1[6 + lane]);
@@ -792,25 +826,33 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         wsync();
     }
     for (int t = 0; t < nt; ++t) {
-        load_Jt(t);
-        gemm<18>(lane, JtP, 18, Jt, 18, false, Np, 18, false, 3, 18, 18);                    // JtPre = Jt Npre
-        gemm<18>(lane, T1, 3, Ai, 18, false, JtP, 18, true, 18, 3, 18);                      // temp = Ainv JtPre^T (18x3)
-        gemm<18>(lane, lam, 3, JtP, 18, false, T1, 3, false, 3, 3, 18);
-        psd_pinv(lane, lam, 3, thrW, lamI, scr);
-        gemm<3>(lane, JtB, 3, T1, 3, false, lamI, 3, false, 18, 3, 3);                      // JtBar
-        if (lane < 3) {
-            real acc = tkX[3 * t + lane] - ((t >= 2) ? Jcd[3 * TLEG(t - 2) + lane] : 0.0);
-            for (int k = 0; k < 18; ++k) acc -= Jt[lane * 18 + k] * qdd[k];
-            tv[lane] = acc;
+        TASK_COLS(t, c0, J3, ld);
+        jt_npre(J3, ld, c0);
+        if (lane < 54) { const int r = lane / 3, i = lane - 3 * r; T1[lane] = dot18(Ai + r * 18, 1, JtP + i * 18, 1, 18); }      // temp = Ainv JtPre^T (18 x 3)
+        wsync();
+        if (lane < 9) { const int a = lane / 3, b2 = lane - 3 * a; lam[lane] = dot18(JtP + a * 18, 1, T1 + b2, 3, 18); }        // lambda^-1 = JtPre temp
+        wsync();
+        real iv[6];
+        pinv3(thrW, iv);
+        if (lane < 54) {                                                                                                      // JtBar = temp lambda
+            const int r = lane / 3, j = lane - 3 * r;
+            const real i0 = j == 0 ? iv[0] : j == 1 ? iv[1] : iv[3], i1 = j == 0 ? iv[1] : j == 1 ? iv[2] : iv[4], i2 = j == 0 ? iv[3] : j == 1 ? iv[4] : iv[5];
+            JtB[lane] = (T1[3 * r] * i0 + T1[3 * r + 1] * i1) + T1[3 * r + 2] * i2;
         }
         wsync();
-        if (lane < 18) qdd[lane] += JtB[lane * 3] * tv[0] + JtB[lane * 3 + 1] * tv[1] + JtB[lane * 3 + 2] * tv[2];
-        wsync();
-        if (t < nt - 1) {
-            // Npre (I - JtBar JtPre) = Npre - (Npre JtBar) JtPre
-            gemm<18>(lane, T2, 3, Np, 18, false, JtB, 3, false, 18, 3, 18);
-            gemm<3>(lane, Np, 18, T2, 3, false, JtP, 18, false, 18, 18, 3, -1.0, 1.0, Np, 18);
+        // qdd += JtBar (xddot - JtDotQdot - Jt qdd): every lane forms the three residuals itself; T2 = Npre JtBar for the projector update
+        real upd = 0.0;
+        if (lane < 18) {
+            real tv3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                tv3[k] = tkX[3 * t + k] - ((t >= 2) ? Jcd[c0 - 6 + k] : 0.0) - ((J3[k * ld] * qdd[c0] + J3[k * ld + 1] * qdd[c0 + 1]) + J3[k * ld + 2] * qdd[c0 + 2]);
+            upd = qdd[lane] + ((JtB[3 * lane] * tv3[0] + JtB[3 * lane + 1] * tv3[1]) + JtB[3 * lane + 2] * tv3[2]);
         }
+        if (t < nt - 1 && lane < 54) { const int r = lane / 3, j = lane - 3 * r; T2[lane] = dot18(Np + r * 18, 1, JtB + j, 3, 18); }
+        wsync();
+        if (lane < 18) qdd[lane] = upd;
+        if (t < nt - 1) npre_update(T2); else wsync();
     }
 
     QW_TS(7);
