@@ -24,6 +24,7 @@
 // their gravity term is exactly zero and their Coriolis term (<= 1e-7 N m) is dropped.
 // ============================================================================
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "qr_device_types.h"
 #include "qr_wave_helpers.h"
 
@@ -242,6 +243,7 @@ __device__ __forceinline__ real spd_inverse(int lane, real *A, int ld, int n, re
 // (QI/utils/qr_algebra.h:119-141: singular values <= thr are dropped; strict '>').
 // Fast path: plain inverse when every eigenvalue provably exceeds thr; otherwise Jacobi
 // eigen-decomposition on lane 0.  Winv may not alias W.  scr: >= n*n + n doubles.
+template <int UMAX = 3>
 __device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real thr, real *Winv, real *scr)
 {
     if (n == 1) {   // 1x1 special case compares the entry itself (quirk 7)
@@ -251,7 +253,7 @@ __device__ __forceinline__ void psd_pinv(int lane, const real *W, int n, real th
     }
     for (int e = lane; e < n * n; e += 64) Winv[e] = W[e];
     wsync();
-    const real minpiv = spd_inverse<3>(lane, Winv, n, n, scr);        // n <= 12: 144 elements
+    const real minpiv = spd_inverse<UMAX>(lane, Winv, n, n, scr);     // n * n <= 64 * UMAX (n <= 12: 144 elements)
     real fro = 0.0;
     for (int e = lane; e < n * n; e += 64) fro += Winv[e] * Winv[e];
     fro = wsum(fro);
@@ -304,10 +306,28 @@ __device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6]
     return (a > 0.0) && (c22 > 0.0) && (det > 0.0) && (fro == fro) && (1.0 > thr * __builtin_sqrt(fro));
 }
 
-#define QR_WBC_LDS_DOUBLES 4608
+// LDS: what both waves share, then one workspace per wave of identical layout.  The relaxation QP of wave 0 runs over the memory of its
+// finished recursion: Nq (30 x 18) = NP + T1, Sq (18 x 18) = JB + JTP + JTB.
+#define QW_NP    0      // 324 null-space projector
+#define QW_T1    324    // 216 (18 x dimFr, 18 x 3)
+#define QW_JB    540    // 216 JcBar / pinv
+#define QW_JTP   756    // 54  3 x 18
+#define QW_JTB   810    // 54  18 x 3
+#define QW_T2    864    // 54
+#define QW_LAM   918    // 144
+#define QW_LAMI  1062   // 144
+#define QW_SCR   1206   // 144*2 + 16 = 304
+#define QW_VEC   1510   // 3 x 18: qdd, tv, tv2 (wave 1: delta_q, qdot)
+#define QW_QP    1564   // qd_ 32, qr_ 32, qu_ 32, qc0 32, qx 18, qw 18, qz 18
+#define QW_SIZE  1746
+#define QR_WBC_SHARED_DOUBLES 1392
+#define QR_WBC_LDS_DOUBLES (QR_WBC_SHARED_DOUBLES + 2 * QW_SIZE)       // 4884 doubles = 39 072 B: four workgroups per CU
 
-// 37 KB of LDS per robot allows 4 wavefronts per CU = 1 per SIMD, so each may take the whole 512-entry register file
-__global__ __launch_bounds__(64, 1)
+// Two wavefronts per robot, 39 KB of LDS: 4 workgroups per CU = 2 waves per SIMD, 256 VGPRs each.
+//   wave 0: Jacobians, composite inertias, H, G -> A^-1                    -> prioritized acceleration recursion -> relaxation QP -> torques
+//   wave 1: velocities, foot kinematics, Jcdqd, Coriolis -> the task set   -> K12 kinematic projection (when asked for) -> q_des, qd_des
+// One workgroup barrier after the load, one where the two meet; everything else is wave-local (wsync).
+__global__ __launch_bounds__(128, 2)
 void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
@@ -316,10 +336,12 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */)
 {
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#define QW_TS1(i) do { if (dbgT && threadIdx.x == 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
     int qp_iters = 0;
     const int rid = xcd_robot_index(blockIdx.x, n);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (rid < 0) return;
     int tyid = type_id ? type_id[rid] : 0;
     const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
@@ -329,113 +351,84 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     __shared__ real sm[QR_WBC_LDS_DOUBLES];
     real *A = sm;                  // 324  mass matrix
     real *Ai = A + 324;            // 324  A^-1
-    real *Np = Ai + 324;           // 324  null-space projector
-    real *T1 = Np + 324;           // 324
-    real *T2 = T1 + 324;           // 324
-    real *JcA = T2 + 324;          // 4 x 54   foot Jacobians (3x18 each)
+    real *JcA = Ai + 324;          // 4 x 54   foot Jacobians (3x18 each)
     real *JC = JcA + 216;          // 12 x 18  stacked contact Jacobian
-    real *JB = JC + 216;           // 18 x 12  JcBar / pinv
-    real *Jt = JB + 216;           // 3 x 18
-    real *JtP = Jt + 54;           // 3 x 18
-    real *JtB = JtP + 54;          // 18 x 3
-    real *lam = JtB + 54;          // 144
-    real *lamI = lam + 144;        // 144
-    real *scr = lamI + 144;        // 144*2 + 16 = 304
-    real *st = scr + 304;          // 37 state
+    real *st = JC + 216;           // 37 state
     real *cm = st + 40;            // 67 cmd
     real *Gv = cm + 68;            // 18
     real *Cv = Gv + 18;            // 18
-    real *qdd = Cv + 18;           // 18
-    real *tv = qdd + 18;           // 18 scratch vector
-    real *tv2 = tv + 18;           // 18
-    real *Jcd = tv2 + 18;          // 12 Jcdqd
+    real *Jcd = Cv + 18;           // 12 Jcdqd
     real *pGC = Jcd + 12;          // 12
     real *vGC = pGC + 12;          // 12
     real *tkX = vGC + 12;          // 6 tasks x 3: xddot
     real *tkE = tkX + 18;          // posErr
     real *tkV = tkE + 18;          // desiredVel
-    real *legB = tkV + 18;         // 4 x 16: per-leg contributions to the base (rbi 10, fvp 6)
-    real *dq1 = legB + 64;         // 18 delta_q
-    real *dq2 = dq1 + 18;          // 18 qdot
-    real *Nq = dq2 + 18;           // 30 x 18 QP constraint normals
-    real *Sq = Nq + 540;           // 18 x 18 S^-1
-    real *qd_ = Sq + 324;          // 32 d
+    real *legB = tkV + 18;         // 4 x 16: per-leg contributions to the base (rbi 10: wave 0, fvp 6: wave 1)
+    real *sRT = legB + 64;         // 9  Rot^T (body -> world), read with run-time indices by the task Jacobians
+    real *W = sm + QR_WBC_SHARED_DOUBLES + wv * QW_SIZE;     // this wave's workspace
+    real *Np = W + QW_NP, *T1 = W + QW_T1, *JB = W + QW_JB, *JtP = W + QW_JTP, *JtB = W + QW_JTB, *T2 = W + QW_T2;
+    real *lam = W + QW_LAM, *lamI = W + QW_LAMI, *scr = W + QW_SCR;
+    real *qdd = W + QW_VEC, *tv = qdd + 18;
+    real *dq1 = qdd, *dq2 = tv;                       // (wave 1's names for the same slots)
+    real *Nq = W + QW_NP;          // 30 x 18 QP constraint normals
+    real *Sq = W + QW_JB;          // 18 x 18 S^-1
+    real *qd_ = W + QW_QP;         // 32 d
     real *qr_ = qd_ + 32;          // 32 r
     real *qu_ = qr_ + 32;          // 32 u
     real *qc0 = qu_ + 32;          // 32 constraint offsets
     real *qx = qc0 + 32;           // 18 z
-    real *qw = qx + 18;            // 18
-    real *qz = qw + 18;            // 18
-    real *sRT = qz + 18;           // 9  Rot^T (body -> world), read with run-time indices by the task Jacobian loader
-    __shared__ int sI[64];         // task kinds / active list
+    __shared__ int sI[64];         // active list of the QP
 
-    // ---------------- load ----------------
-    if (lane < 37) st[lane] = (real)g_state[(size_t)lane * n + rid];
-    if (g_tau) for (int i = lane; i < 67; i += 64) cm[i] = (real)((g_fr && i >= 51 && i < 63) ? g_fr[(size_t)(i - 51) * n + rid] : g_cmd[(size_t)i * n + rid]);
-    for (int e = lane; e < 324; e += 64) A[e] = 0.0;
-    for (int e = lane; e < 216; e += 64) JcA[e] = 0.0;
-    wsync();
+    // ---------------- load (wave 0: state, wave 1: commands) ----------------
+    if (wv == 0) {
+        if (lane < 37) st[lane] = (real)g_state[(size_t)lane * n + rid];
+        for (int e = lane; e < 324; e += 64) A[e] = 0.0;
+        for (int e = lane; e < 216; e += 64) JcA[e] = 0.0;
+    } else if (g_tau) {
+        for (int i = lane; i < 67; i += 64) cm[i] = (real)((g_fr && i >= 51 && i < 63) ? g_fr[(size_t)(i - 51) * n + rid] : g_cmd[(size_t)i * n + rid]);
+    }
+    __syncthreads();
     const real *quat = st, *pos = st + 4, *bv = st + 7, *qj = st + 13, *qdj = st + 25;
     const m3 Rwb = quat_to_rot_wb(quat);        // world -> body  (E of Xup[5])
+    // contacts: stance feet; task list: 0 = body orientation, 1 = body position, then swing feet in leg order
+    int nc = 0, nt = 2;
+    unsigned cpack = 0, tpack = 0;      // leg ids of the contacts / swing-foot tasks, 4 bits each (no indexed local arrays -> no scratch)
+    if (g_tau) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {   // readfirstlane: LDS loads count as divergent, the contact pattern is wave-uniform
+            const int in_contact = __builtin_amdgcn_readfirstlane(cm[63 + l] != 0.0 ? 1 : 0);
+            if (in_contact) { cpack |= (unsigned)l << (4 * nc); ++nc; } else { tpack |= (unsigned)l << (4 * (nt - 2)); ++nt; }
+        }
+    }
+#define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
+#define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
+    const int dimFr = 3 * nc;
 
     QW_TS(1);
-    // ---------------- K8-K10 per leg (lanes 0-3) ----------------
-    if (lane < 4) {
-        const int leg = lane, side = leg & 1;   // side 0: right (legs 0,2; sideSign<0), 1: left
+    // ---------------- K8-K10 per leg (lanes 0-3 of both waves) ----------------
+    // Wave 0 takes what the mass matrix needs (contact Jacobians, composite inertias, H, gravity), wave 1 what depends on the velocities
+    // (bias accelerations, foot position / velocity, Jcdqd, Coriolis) and then the task set: two chains of half the length side by side.
+    struct LegFrames { v3 r_a, r_h, r_k, loc; m3 Ea, Eh, Ek, Eabs_a, Eabs_h, Eabs_k; };
+    auto leg_frames = [&](int leg) {
+        LegFrames F;
+        const int side = leg & 1;           // side 0: right (legs 0,2; sideSign<0), 1: left
         const real sx = (leg < 2) ? 1.0 : -1.0, sy = side ? 1.0 : -1.0;
-        const v3 r_a = mk(sx * K.abad_loc[0], sy * K.abad_loc[1], K.abad_loc[2]);
-        const v3 r_h = mk(0.0, sy * K.hip_l, 0.0);
-        const v3 r_k = mk(0.0, 0.0, -K.upper_l);
-        const v3 loc = mk(0.0, side ? -K.foot_y : K.foot_y, -K.lower_l);
-        const real q0 = qj[3 * leg], q1 = qj[3 * leg + 1], q2 = qj[3 * leg + 2];
-        const real d0 = qdj[3 * leg], d1 = qdj[3 * leg + 1], d2 = qdj[3 * leg + 2];
-        const m3 Ea = coord_rot(0, q0), Eh = coord_rot(1, q1), Ek = coord_rot(1, q2);
-        const v3 ex = mk(1, 0, 0), ey = mk(0, 1, 0);
-        // velocities, bias accelerations
-        sv6 v5; v5.a = mk(bv[0], bv[1], bv[2]); v5.l = mk(bv[3], bv[4], bv[5]);
-        sv6 va = xmotion(Ea, r_a, v5); sv6 vJa; vJa.a = d0 * ex; vJa.l = mk(0, 0, 0); va.a = va.a + vJa.a;
-        sv6 ca = crm(va, vJa);
-        sv6 vh = xmotion(Eh, r_h, va); sv6 vJh; vJh.a = d1 * ey; vJh.l = mk(0, 0, 0); vh.a = vh.a + vJh.a;
-        sv6 ch = crm(vh, vJh);
-        sv6 vk = xmotion(Ek, r_k, vh); sv6 vJk; vJk.a = d2 * ey; vJk.l = mk(0, 0, 0); vk.a = vk.a + vJk.a;
-        sv6 ck = crm(vk, vJk);
-        sv6 aa = ca;
-        sv6 ah = xmotion(Eh, r_h, aa); ah.a = ah.a + ch.a; ah.l = ah.l + ch.l;
-        sv6 ak = xmotion(Ek, r_k, ah); ak.a = ak.a + ck.a; ak.l = ak.l + ck.l;
-        // absolute rotations (world -> link) and link origins in the world
-        const m3 Eabs_a = mul(Ea, Rwb), Eabs_h = mul(Eh, Eabs_a), Eabs_k = mul(Ek, Eabs_h);
-        // Foot position / velocity exactly as forwardKinematics does it (:506-521): through the bottom-left
-        // block of Xa and invertSXform / sXFormPoint, which use E^T as E^-1.  With the float-rounded (not
-        // exactly unit) quaternion of the state this differs from the textbook sum of offsets by O(|q|^2-1) * 1 m,
-        // which the foot task's Kp = 500 would turn into 1e-5 N m.
-        {
-            auto skewm = [](v3 r) { m3 S = {{{0, -r.z, r.y}, {r.z, 0, -r.x}, {-r.y, r.x, 0}}}; return S; };
-            auto neg = [](const m3 &A_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = -A_.m[i][j]; return C_; };
-            auto addm = [](const m3 &A_, const m3 &B_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = A_.m[i][j] + B_.m[i][j]; return C_; };
-            auto unskew = [](const m3 &M_) { return mk(0.5 * (M_.m[2][1] - M_.m[1][2]), 0.5 * (M_.m[0][2] - M_.m[2][0]), 0.5 * (M_.m[1][0] - M_.m[0][1])); };   // matToSkewVec
-            const v3 p5 = mk(pos[0], pos[1], pos[2]);
-            const m3 B5 = neg(mul(Rwb, skewm(p5)));                                              // createSXform(R, pos) bottom-left
-            const m3 Ba = addm(mul(neg(mul(Ea, skewm(r_a))), Rwb), mul(Ea, B5));                 // Xup[a] * Xa[5]
-            const m3 Bh = addm(mul(neg(mul(Eh, skewm(r_h))), Eabs_a), mul(Eh, Ba));
-            const m3 Bk = addm(mul(neg(mul(Ek, skewm(r_k))), Eabs_h), mul(Ek, Bh));
-            const m3 E = Eabs_k, Et = transpose(Eabs_k);
-            const v3 r1 = (-1.0) * unskew(mul(Et, Bk));                                          // invertSXform: r
-            const v3 Er1 = mul(E, r1);
-            const m3 BLi = mul(Et, skewm(Er1));                                                  // Xai bottom-left = -E^T [-E r]x
-            const v3 rp = (-1.0) * unskew(mul(E, BLi));                                          // translationFromSXform(Xai)
-            const v3 pf = mul(Et, loc - rp);                                                     // sXFormPoint
-            const v3 wS = mul(Et, vk.a);
-            const v3 vS = mul(BLi, vk.a) + mul(Et, vk.l);
-            const v3 vf = vS + cross(wS, pf);                                                    // spatialToLinearVelocity
-            pGC[3 * leg] = pf.x; pGC[3 * leg + 1] = pf.y; pGC[3 * leg + 2] = pf.z;
-            vGC[3 * leg] = vf.x; vGC[3 * leg + 1] = vf.y; vGC[3 * leg + 2] = vf.z;
-        }
-        // Jcdqd = Rai [ (a_lin + a_ang x loc) + w x (v_lin + w x loc) ]
-        {
-            const v3 t = (ak.l + cross(ak.a, loc)) + cross(vk.a, vk.l + cross(vk.a, loc));
-            const v3 jd = mulT(Eabs_k, t);
-            Jcd[3 * leg] = jd.x; Jcd[3 * leg + 1] = jd.y; Jcd[3 * leg + 2] = jd.z;
-        }
+        F.r_a = mk(sx * K.abad_loc[0], sy * K.abad_loc[1], K.abad_loc[2]);
+        F.r_h = mk(0.0, sy * K.hip_l, 0.0);
+        F.r_k = mk(0.0, 0.0, -K.upper_l);
+        F.loc = mk(0.0, side ? -K.foot_y : K.foot_y, -K.lower_l);
+        F.Ea = coord_rot(0, qj[3 * leg]); F.Eh = coord_rot(1, qj[3 * leg + 1]); F.Ek = coord_rot(1, qj[3 * leg + 2]);
+        // absolute rotations (world -> link)
+        F.Eabs_a = mul(F.Ea, Rwb); F.Eabs_h = mul(F.Eh, F.Eabs_a); F.Eabs_k = mul(F.Ek, F.Eabs_h);
+        return F;
+    };
+    const v3 ex = mk(1, 0, 0), ey = mk(0, 1, 0);
+    if (wv == 0) {
+      if (lane < 4) {
+        const int leg = lane, side = leg & 1;
+        const LegFrames F = leg_frames(leg);
+        const v3 r_a = F.r_a, r_h = F.r_h, r_k = F.r_k, loc = F.loc;
+        const m3 &Ea = F.Ea, &Eh = F.Eh, &Ek = F.Ek, &Eabs_a = F.Eabs_a, &Eabs_h = F.Eabs_h, &Eabs_k = F.Eabs_k;
         // contact Jacobian columns: world velocity of the foot per unit generalized velocity
         {
             real *J = JcA + 54 * leg;
@@ -458,10 +451,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             }
         }
         // composite inertias (rotor constants are folded into the *_eff parents on the host)
-        const rbi Ik = rbi_load(K.rb[QR_RB_KNEE]);
-        const rbi Ih = rbi_load(K.rb[QR_RB_HIP + side]), Ih_e = rbi_load(K.rb[QR_RB_HIP_EFF + side]);
-        const rbi Ia = rbi_load(K.rb[QR_RB_ABAD + side]), Ia_e = rbi_load(K.rb[QR_RB_ABAD_EFF + side]);
-        const rbi ICk = Ik;
+        const rbi ICk = rbi_load(K.rb[QR_RB_KNEE]);
+        const rbi Ih_e = rbi_load(K.rb[QR_RB_HIP_EFF + side]);
+        const rbi Ia_e = rbi_load(K.rb[QR_RB_ABAD_EFF + side]);
         const rbi ICh = rbi_add(Ih_e, rbi_to_parent(ICk, Ek, r_k));
         const rbi ICa = rbi_add(Ia_e, rbi_to_parent(ICh, Eh, r_h));
         const rbi ICa_b = rbi_to_parent(ICa, Ea, r_a);
@@ -512,32 +504,13 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             Gv[jh] = -cross(ICh.h, g_h).y;
             Gv[jk] = -cross(ICk.h, g_k).y;
         }
-        // Coriolis (:633-665) with link inertias
-        {
-            sv6 fk = rbi_mul(Ik, ak); { sv6 c = crf(vk, rbi_mul(Ik, vk)); fk.a = fk.a + c.a; fk.l = fk.l + c.l; }
-            sv6 fh = rbi_mul(Ih, ah); { sv6 c = crf(vh, rbi_mul(Ih, vh)); fh.a = fh.a + c.a; fh.l = fh.l + c.l; }
-            sv6 fa = rbi_mul(Ia, aa); { sv6 c = crf(va, rbi_mul(Ia, va)); fa.a = fa.a + c.a; fa.l = fa.l + c.l; }
-            Cv[jk] = fk.a.y;
-            { sv6 t = xforceT(Ek, r_k, fk); fh.a = fh.a + t.a; fh.l = fh.l + t.l; }
-            Cv[jh] = fh.a.y;
-            { sv6 t = xforceT(Eh, r_h, fh); fa.a = fa.a + t.a; fa.l = fa.l + t.l; }
-            Cv[ja] = fa.a.x;
-            sv6 t = xforceT(Ea, r_a, fa);
-            LB[10] = t.a.x; LB[11] = t.a.y; LB[12] = t.a.z; LB[13] = t.l.x; LB[14] = t.l.y; LB[15] = t.l.z;
-        }
-    }
-    wsync();
-    QW_TS(2);
-    // ---------------- base block (lane 0) ----------------
-    if (lane == 0) {
+      }
+      wsync();
+      QW_TS(2);
+      // ---------------- base block of H and G (lane 0) ----------------
+      if (lane == 0) {
         rbi IC5 = rbi_load(K.rb[QR_RB_BASE_EFF]);
-        sv6 fb; fb.a = mk(0, 0, 0); fb.l = mk(0, 0, 0);
-        for (int l = 0; l < 4; ++l) {
-            const real *LB = legB + 16 * l;
-            rbi c = rbi_load(LB);
-            IC5 = rbi_add(IC5, c);
-            fb.a = fb.a + mk(LB[10], LB[11], LB[12]); fb.l = fb.l + mk(LB[13], LB[14], LB[15]);
-        }
+        for (int l = 0; l < 4; ++l) IC5 = rbi_add(IC5, rbi_load(legB + 16 * l));
         // H[0:6,0:6] = IC5 as a 6x6
         const real I6[3][3] = {{IC5.I[0], IC5.I[3], IC5.I[4]}, {IC5.I[3], IC5.I[1], IC5.I[5]}, {IC5.I[4], IC5.I[5], IC5.I[2]}};
         const real hx[3][3] = {{0, -IC5.h.z, IC5.h.y}, {IC5.h.z, 0, -IC5.h.x}, {-IC5.h.y, IC5.h.x, 0}};
@@ -554,24 +527,79 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         const v3 a5 = mul(Rwb, mk(0, 0, -9.81));
         const v3 gt = cross(IC5.h, a5);
         Gv[0] = -gt.x; Gv[1] = -gt.y; Gv[2] = -gt.z; Gv[3] = -IC5.m * a5.x; Gv[4] = -IC5.m * a5.y; Gv[5] = -IC5.m * a5.z;
-        // C[0:6] = fvp5 + sum of leg contributions; fvp5 = v5 x* (I5 v5)  (avp5 = 0)
-        const rbi I5 = rbi_load(K.rb[QR_RB_BASE]);
+      }
+      wsync();
+      QW_TS(3);
+    } else {
+      if (lane < 4) {
+        const int leg = lane, side = leg & 1;
+        const LegFrames F = leg_frames(leg);
+        const v3 r_a = F.r_a, r_h = F.r_h, r_k = F.r_k, loc = F.loc;
+        const m3 &Ea = F.Ea, &Eh = F.Eh, &Ek = F.Ek, &Eabs_a = F.Eabs_a, &Eabs_h = F.Eabs_h, &Eabs_k = F.Eabs_k;
+        const real d0 = qdj[3 * leg], d1 = qdj[3 * leg + 1], d2 = qdj[3 * leg + 2];
+        // velocities, bias accelerations
         sv6 v5; v5.a = mk(bv[0], bv[1], bv[2]); v5.l = mk(bv[3], bv[4], bv[5]);
-        const sv6 c5 = crf(v5, rbi_mul(I5, v5));
-        Cv[0] = c5.a.x + fb.a.x; Cv[1] = c5.a.y + fb.a.y; Cv[2] = c5.a.z + fb.a.z;
-        Cv[3] = c5.l.x + fb.l.x; Cv[4] = c5.l.y + fb.l.y; Cv[5] = c5.l.z + fb.l.z;
+        sv6 va = xmotion(Ea, r_a, v5); sv6 vJa; vJa.a = d0 * ex; vJa.l = mk(0, 0, 0); va.a = va.a + vJa.a;
+        sv6 ca = crm(va, vJa);
+        sv6 vh = xmotion(Eh, r_h, va); sv6 vJh; vJh.a = d1 * ey; vJh.l = mk(0, 0, 0); vh.a = vh.a + vJh.a;
+        sv6 ch = crm(vh, vJh);
+        sv6 vk = xmotion(Ek, r_k, vh); sv6 vJk; vJk.a = d2 * ey; vJk.l = mk(0, 0, 0); vk.a = vk.a + vJk.a;
+        sv6 ck = crm(vk, vJk);
+        sv6 aa = ca;
+        sv6 ah = xmotion(Eh, r_h, aa); ah.a = ah.a + ch.a; ah.l = ah.l + ch.l;
+        sv6 ak = xmotion(Ek, r_k, ah); ak.a = ak.a + ck.a; ak.l = ak.l + ck.l;
+        // Foot position / velocity exactly as forwardKinematics does it (:506-521): through the bottom-left
+        // block of Xa and invertSXform / sXFormPoint, which use E^T as E^-1.  With the float-rounded (not
+        // exactly unit) quaternion of the state this differs from the textbook sum of offsets by O(|q|^2-1) * 1 m,
+        // which the foot task's Kp = 500 would turn into 1e-5 N m.
+        {
+            auto skewm = [](v3 r) { m3 S = {{{0, -r.z, r.y}, {r.z, 0, -r.x}, {-r.y, r.x, 0}}}; return S; };
+            auto neg = [](const m3 &A_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = -A_.m[i][j]; return C_; };
+            auto addm = [](const m3 &A_, const m3 &B_) { m3 C_; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C_.m[i][j] = A_.m[i][j] + B_.m[i][j]; return C_; };
+            auto unskew = [](const m3 &M_) { return mk(0.5 * (M_.m[2][1] - M_.m[1][2]), 0.5 * (M_.m[0][2] - M_.m[2][0]), 0.5 * (M_.m[1][0] - M_.m[0][1])); };   // matToSkewVec
+            const v3 p5 = mk(pos[0], pos[1], pos[2]);
+            const m3 B5 = neg(mul(Rwb, skewm(p5)));                                              // createSXform(R, pos) bottom-left
+            const m3 Ba = addm(mul(neg(mul(Ea, skewm(r_a))), Rwb), mul(Ea, B5));                 // Xup[a] * Xa[5]
+            const m3 Bh = addm(mul(neg(mul(Eh, skewm(r_h))), Eabs_a), mul(Eh, Ba));
+            const m3 Bk = addm(mul(neg(mul(Ek, skewm(r_k))), Eabs_h), mul(Ek, Bh));
+            const m3 E = Eabs_k, Et = transpose(Eabs_k);
+            const v3 r1 = (-1.0) * unskew(mul(Et, Bk));                                          // invertSXform: r
+            const v3 Er1 = mul(E, r1);
+            const m3 BLi = mul(Et, skewm(Er1));                                                  // Xai bottom-left = -E^T [-E r]x
+            const v3 rp = (-1.0) * unskew(mul(E, BLi));                                          // translationFromSXform(Xai)
+            const v3 pf = mul(Et, loc - rp);                                                     // sXFormPoint
+            const v3 wS = mul(Et, vk.a);
+            const v3 vS = mul(BLi, vk.a) + mul(Et, vk.l);
+            const v3 vf = vS + cross(wS, pf);                                                    // spatialToLinearVelocity
+            pGC[3 * leg] = pf.x; pGC[3 * leg + 1] = pf.y; pGC[3 * leg + 2] = pf.z;
+            vGC[3 * leg] = vf.x; vGC[3 * leg + 1] = vf.y; vGC[3 * leg + 2] = vf.z;
+        }
+        // Jcdqd = Rai [ (a_lin + a_ang x loc) + w x (v_lin + w x loc) ]
+        {
+            const v3 t = (ak.l + cross(ak.a, loc)) + cross(vk.a, vk.l + cross(vk.a, loc));
+            const v3 jd = mulT(Eabs_k, t);
+            Jcd[3 * leg] = jd.x; Jcd[3 * leg + 1] = jd.y; Jcd[3 * leg + 2] = jd.z;
+        }
+        // Coriolis (:633-665) with link inertias
+        {
+            const rbi Ik = rbi_load(K.rb[QR_RB_KNEE]), Ih = rbi_load(K.rb[QR_RB_HIP + side]), Ia = rbi_load(K.rb[QR_RB_ABAD + side]);
+            const int ja = 6 + 3 * leg, jh = ja + 1, jk = ja + 2;
+            sv6 fk = rbi_mul(Ik, ak); { sv6 c = crf(vk, rbi_mul(Ik, vk)); fk.a = fk.a + c.a; fk.l = fk.l + c.l; }
+            sv6 fh = rbi_mul(Ih, ah); { sv6 c = crf(vh, rbi_mul(Ih, vh)); fh.a = fh.a + c.a; fh.l = fh.l + c.l; }
+            sv6 fa = rbi_mul(Ia, aa); { sv6 c = crf(va, rbi_mul(Ia, va)); fa.a = fa.a + c.a; fa.l = fa.l + c.l; }
+            Cv[jk] = fk.a.y;
+            { sv6 t = xforceT(Ek, r_k, fk); fh.a = fh.a + t.a; fh.l = fh.l + t.l; }
+            Cv[jh] = fh.a.y;
+            { sv6 t = xforceT(Eh, r_h, fh); fa.a = fa.a + t.a; fa.l = fa.l + t.l; }
+            Cv[ja] = fa.a.x;
+            sv6 t = xforceT(Ea, r_a, fa);
+            real *LB = legB + 16 * leg;
+            LB[10] = t.a.x; LB[11] = t.a.y; LB[12] = t.a.z; LB[13] = t.l.x; LB[14] = t.l.y; LB[15] = t.l.z;
+        }
+      }
+      wsync();
     }
-    wsync();
-    if (g_dbg) {
-        float *o = g_dbg + (size_t)rid * (324 + 18 + 18 + 216 + 36);
-        for (int e = lane; e < 324; e += 64) o[e] = (float)A[e];
-        if (lane < 18) { o[324 + lane] = (float)Gv[lane]; o[342 + lane] = (float)Cv[lane]; }
-        for (int e = lane; e < 216; e += 64) o[360 + e] = (float)JcA[e];
-        if (lane < 12) { o[576 + lane] = (float)Jcd[lane]; o[588 + lane] = (float)pGC[lane]; o[600 + lane] = (float)vGC[lane]; }
-        if (!g_tau) return;
-    }
-
-    QW_TS(3);
+    if (wv == 0) {
     // ---------------- K13 GetModelRes: A^-1 ----------------
     // The joints of different legs do not couple (H(leg a, leg b) = 0), so A = [Abb Abl; Abl' diag(L0..L3)] is inverted through the
     // 6 x 6 Schur complement of the floating base instead of 18 pivots: Li = L^-1 (cofactors), T = Abl Li, Sb = Abb - T Abl',
@@ -628,19 +656,24 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         wsync();
     }
 
-    QW_TS(4);
-    // ---------------- K11 tasks and contacts ----------------
-    // task list: 0 = body orientation, 1 = body position, then swing feet in leg order; contacts: stance feet.
-    int nc = 0, nt = 2;
-    unsigned cpack = 0, tpack = 0;      // leg ids of the contacts / swing-foot tasks, 4 bits each (no indexed local arrays -> no scratch)
+      QW_TS(4);
+      // stacked contact Jacobian; RotT[i][j] = Rwb[j][i] with static indices only (a register array indexed at run time would be demoted to scratch)
+      for (int e = lane; e < 54 * nc; e += 64) { const int k = e / 54; JC[e] = JcA[54 * CLEG(k) + (e - 54 * k)]; }
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {       // readfirstlane: LDS loads count as divergent, the contact pattern is wave-uniform
-        const int in_contact = __builtin_amdgcn_readfirstlane(cm[63 + l] != 0.0 ? 1 : 0);
-        if (in_contact) { cpack |= (unsigned)l << (4 * nc); ++nc; } else { tpack |= (unsigned)l << (4 * (nt - 2)); ++nt; }
-    }
-#define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
-#define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
-    if (lane == 0) {
+      for (int e = 0; e < 9; ++e) if (lane == e) sRT[e] = Rwb.m[e % 3][e / 3];
+    } else {
+      // ---------------- base block of C (lane 0): fvp5 + the legs' contributions; fvp5 = v5 x* (I5 v5)  (avp5 = 0) ----------------
+      if (lane == 0) {
+        sv6 fb; fb.a = mk(0, 0, 0); fb.l = mk(0, 0, 0);
+        for (int l = 0; l < 4; ++l) { const real *LB = legB + 16 * l; fb.a = fb.a + mk(LB[10], LB[11], LB[12]); fb.l = fb.l + mk(LB[13], LB[14], LB[15]); }
+        const rbi I5 = rbi_load(K.rb[QR_RB_BASE]);
+        sv6 v5; v5.a = mk(bv[0], bv[1], bv[2]); v5.l = mk(bv[3], bv[4], bv[5]);
+        const sv6 c5 = crf(v5, rbi_mul(I5, v5));
+        Cv[0] = c5.a.x + fb.a.x; Cv[1] = c5.a.y + fb.a.y; Cv[2] = c5.a.z + fb.a.z;
+        Cv[3] = c5.l.x + fb.l.x; Cv[4] = c5.l.y + fb.l.y; Cv[5] = c5.l.z + fb.l.z;
+      }
+      // ---------------- K11 tasks (lane 0) ----------------
+      if (lane == 0 && g_tau) {
         const m3 RotT = transpose(Rwb);
         // --- orientation task (qr_task_body_orientation.cpp:43-81)
         {
@@ -710,14 +743,19 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             }
         }
     }
-    // stacked contact Jacobian
-    for (int e = lane; e < 54 * nc; e += 64) { const int k = e / 54; JC[e] = JcA[54 * CLEG(k) + (e - 54 * k)]; }
-    wsync();
-    const int dimFr = 3 * nc;
-    // RotT[i][j] = Rwb[j][i]; static indices only (a register array indexed at run time would be demoted to scratch)
-#pragma unroll
-    for (int e = 0; e < 9; ++e) if (lane == e) sRT[e] = Rwb.m[e % 3][e / 3];
-    wsync();
+      QW_TS1(11);
+    }
+    __syncthreads();                  // the two waves meet: dynamics and A^-1 from wave 0, Jcdqd / C / the task set from wave 1
+    if (g_dbg) {
+        if (wv == 0) {
+            float *o = g_dbg + (size_t)rid * (324 + 18 + 18 + 216 + 36);
+            for (int e = lane; e < 324; e += 64) o[e] = (float)A[e];
+            if (lane < 18) { o[324 + lane] = (float)Gv[lane]; o[342 + lane] = (float)Cv[lane]; }
+            for (int e = lane; e < 216; e += 64) o[360 + e] = (float)JcA[e];
+            if (lane < 12) { o[576 + lane] = (float)Jcd[lane]; o[588 + lane] = (float)pGC[lane]; o[600 + lane] = (float)vGC[lane]; }
+        }
+        if (!g_tau) return;
+    }
     // A task Jacobian is non-zero in three columns only: orientation = base angular columns 0-2 (Rot^T), position = 3-5 (Rot^T), swing foot
     // = that leg's joints 6+3l.. (virtualDepend = false zeroes its base columns).  J3[i * ld + k] is entry (i, c0 + k).
 #define TASK_COLS(t, c0, J3, ld)                                                                           \
@@ -753,21 +791,70 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         }
     };
 
+    // The contact level of either recursion, for D = dimFr rows known at compile time (static trip counts, no predicated loads):
+    //   dynamic (wave 0, K13):   JcBar = A^-1 Jc' (Jc A^-1 Jc')^+,   qdd = JcBar (-Jcdqd),   N = I - JcBar Jc
+    //   kinematic (wave 1, K12): pinv  = Jc' (Jc Jc')^+,                                      N = I - pinv Jc
+    auto contact_part = [&](auto Dc, const bool dynamic, const real thr) {
+        constexpr int D = decltype(Dc)::value;
+        constexpr int UM = (D * D + 63) / 64;
+        if (dynamic) {
+            for (int e = lane; e < 18 * D; e += 64) { const int i = e / D, j = e - D * i; T1[e] = dot18(Ai + i * 18, 1, JC + j * 18, 1, 18); }      // temp = Ainv Jc' (18 x D)
+            wsync();
+        }
+        for (int e = lane; e < D * D; e += 64) {                                                    // lambda^-1 = Jc temp  /  Jc Jc'
+            const int i = e / D, j = e - D * i;
+            lam[e] = dynamic ? dot18(JC + i * 18, 1, T1 + j, D, 18) : dot18(JC + i * 18, 1, JC + j * 18, 1, 18);
+        }
+        wsync();
+        psd_pinv<UM>(lane, lam, D, thr, lamI, scr);
+        for (int e = lane; e < 18 * D; e += 64) {                                                   // JcBar = temp lambda  /  pinv = Jc' W^+
+            const int i = e / D, j = e - D * i;
+            real av[D], bv[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) { av[k] = dynamic ? T1[i * D + k] : JC[k * 18 + i]; bv[k] = lamI[k * D + j]; }
+            real a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; k += 3) { a0 += av[k] * bv[k]; a1 += av[k + 1] * bv[k + 1]; a2 += av[k + 2] * bv[k + 2]; }
+            JB[e] = (a0 + a1) + a2;
+        }
+        wsync();
+        if (dynamic && lane < 18) {
+            real acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc -= JB[lane * D + k] * Jcd[3 * CLEG(k / 3) + k % 3];
+            qdd[lane] = acc;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = lane + 64 * u;
+            if (e < 324) {
+                const int i = fdiv16(e, rcp16(18)), j = e - 18 * i;
+                real av[D], bv[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { av[k] = JB[i * D + k]; bv[k] = JC[k * 18 + j]; }
+                real a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; k += 3) { a0 += av[k] * bv[k]; a1 += av[k + 1] * bv[k + 1]; a2 += av[k + 2] * bv[k + 2]; }
+                Np[e] = ((i == j) ? 1.0 : 0.0) - ((a0 + a1) + a2);
+            }
+        }
+        wsync();
+    };
+
     QW_TS(5);
-    // ---------------- K12 kinematic multitask projection (only when its outputs are requested) ----------------
-    if (g_qdes) {
+    // ---------------- K12 kinematic multitask projection (wave 1; only when its outputs are requested) ----------------
+    if (wv == 1) {
+      if (g_qdes) {
         const real thr2 = 1e-6;       // singular value > 1e-3  <=>  eigenvalue of J J^T > 1e-6
         // Nc = I - pinv(Jc) Jc
-        if (nc > 0) {
-            gemm<18>(lane, lam, dimFr, JC, 18, false, JC, 18, true, dimFr, dimFr, 18);          // Jc Jc^T
-            psd_pinv(lane, lam, dimFr, thr2, lamI, scr);
-            gemm<12>(lane, JB, dimFr, JC, 18, true, lamI, dimFr, false, 18, dimFr, dimFr);        // pinv = Jc^T W^+
-            gemm<12>(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
-            for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
-            wsync();
-        } else {
-            for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
-            wsync();
+        switch (nc) {
+            case 1: contact_part(std::integral_constant<int, 3>{}, false, thr2); break;
+            case 2: contact_part(std::integral_constant<int, 6>{}, false, thr2); break;
+            case 3: contact_part(std::integral_constant<int, 9>{}, false, thr2); break;
+            case 4: contact_part(std::integral_constant<int, 12>{}, false, thr2); break;
+            default:
+                for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
+                wsync();
         }
         for (int t = 0; t < nt; ++t) {
             TASK_COLS(t, c0, J3, ld);
@@ -805,27 +892,26 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             g_qdes[(size_t)lane * n + rid] = (float)(qj[lane] + dq1[6 + lane]);
             g_qdes[(size_t)(12 + lane) * n + rid] = (float)dq2[6 + lane];
         }
-        wsync();
+      }
+      QW_TS1(13);
+      return;
     }
 
-    QW_TS(6);
     // ---------------- K13 MakeTorque: prioritized acceleration recursion ----------------
     const real thrW = 1e-4;       // WeightedInverse default threshold (qr_wholebody_impulse_ctrl.hpp:110)
-    if (dimFr > 0) {
-        gemm<18>(lane, T1, dimFr, Ai, 18, false, JC, 18, true, 18, dimFr, 18);               // temp = Ainv Jc^T   (18 x dimFr)
-        gemm<18>(lane, lam, dimFr, JC, 18, false, T1, dimFr, false, dimFr, dimFr, 18);       // lambda = Jc temp
-        psd_pinv(lane, lam, dimFr, thrW, lamI, scr);
-        gemm<12>(lane, JB, dimFr, T1, dimFr, false, lamI, dimFr, false, 18, dimFr, dimFr);   // JcBar
-        if (lane < 18) { real acc = 0.0; for (int k = 0; k < dimFr; ++k) acc -= JB[lane * dimFr + k] * Jcd[3 * CLEG(k / 3) + k % 3]; qdd[lane] = acc; }
-        gemm<12>(lane, Np, 18, JB, dimFr, false, JC, 18, false, 18, 18, dimFr, -1.0);
-        for (int i = lane; i < 18; i += 64) Np[i * 18 + i] += 1.0;
-        wsync();
-    } else {
-        if (lane < 18) qdd[lane] = 0.0;
-        for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
-        wsync();
+    switch (nc) {
+        case 1: contact_part(std::integral_constant<int, 3>{}, true, thrW); break;
+        case 2: contact_part(std::integral_constant<int, 6>{}, true, thrW); break;
+        case 3: contact_part(std::integral_constant<int, 9>{}, true, thrW); break;
+        case 4: contact_part(std::integral_constant<int, 12>{}, true, thrW); break;
+        default:
+            if (lane < 18) qdd[lane] = 0.0;
+            for (int e = lane; e < 324; e += 64) Np[e] = ((e / 18) == (e % 18)) ? 1.0 : 0.0;
+            wsync();
     }
+    QW_TS(12);
     for (int t = 0; t < nt; ++t) {
+        if (t == 1) QW_TS(14);
         TASK_COLS(t, c0, J3, ld);
         jt_npre(J3, ld, c0);
         if (lane < 54) { const int r = lane / 3, i = lane - 3 * r; T1[lane] = dot18(Ai + r * 18, 1, JtP + i * 18, 1, 18); }      // temp = Ainv JtPre^T (18 x 3)

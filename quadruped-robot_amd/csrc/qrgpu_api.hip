@@ -471,7 +471,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     if (rc) return rc;
     {
         TimerScope ts(c, 1);
-        hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(64), 0, c->stream, n, c->d_wbc, d_type, d_state,
+        hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
                            ready_mask(c->wbc_ready), epilogue);
     }
