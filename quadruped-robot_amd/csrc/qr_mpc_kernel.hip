@@ -807,13 +807,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) D[3 * i + j] = Cx[3 * i] * Pi[j] + Cx[3 * i + 1] * Pi[3 + j] + Cx[3 * i + 2] * Pi[6 + j];
+                    for (int j = 0; j < 3; ++j) D[3 * i + j] = __builtin_fma(Cx[3 * i + 2], Pi[6 + j], __builtin_fma(Cx[3 * i + 1], Pi[3 + j], Cx[3 * i] * Pi[j]));
                 if (a != k && b != k) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
-                            A[sl].m[3 * i + j] -= D[3 * i] * Cb[3 * j] + D[3 * i + 1] * Cb[3 * j + 1] + D[3 * i + 2] * Cb[3 * j + 2];
+                            A[sl].m[3 * i + j] = __builtin_fma(-D[3 * i + 2], Cb[3 * j + 2], __builtin_fma(-D[3 * i + 1], Cb[3 * j + 1], __builtin_fma(-D[3 * i], Cb[3 * j], A[sl].m[3 * i + j])));     // three chained fma, no separate mul / sub
                 } else {
                     // pivot row / column: A_xk = D (x > k), A_kx = D' (x < k), A_kk = -P^-1
                     const bool piv = (a == k && b == k), tr = (a == k);

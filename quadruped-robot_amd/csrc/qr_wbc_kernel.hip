@@ -79,6 +79,14 @@ __device__ __forceinline__ m3 coord_rot(int axis, real th)
     else                { R = {{{c, s, 0}, {-s, c, 0}, {0, 0, 1}}}; }
     return R;
 }
+__device__ __forceinline__ m3 coord_rot_sc(int axis, real s, real c)
+{
+    m3 R;
+    if (axis == 0)      { R = {{{1, 0, 0}, {0, c, s}, {0, -s, c}}}; }
+    else if (axis == 1) { R = {{{c, 0, -s}, {0, 1, 0}, {s, 0, c}}}; }
+    else                { R = {{{c, s, 0}, {-s, c, 0}, {0, 0, 1}}}; }
+    return R;
+}
 // quaternionToRotationMatrix (:186-203): world -> body.
 __device__ __forceinline__ m3 quat_to_rot_wb(const real *q)
 {
@@ -404,6 +412,20 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 #define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
     const int dimFr = 3 * nc;
 
+    // sines and cosines of the twelve joint angles (and, on wave 1, of the commanded roll / pitch / yaw) in one go on fifteen lanes, instead of
+    // three (six) calls one after the other inside the per-leg chains; each wave keeps its own copy (scr is idle until A^-1)
+    {
+        real *sS = scr + 160, *sC = scr + 176;
+        if (lane < 15) {
+            const real th = (lane < 12) ? qj[lane] : ((wv == 1 && g_tau) ? cm[9 + lane - 12] : 0.0);
+            real s_, c_;
+            sincos(th, &s_, &c_);
+            sS[lane] = s_; sC[lane] = c_;
+        }
+        wsync();
+    }
+    const real *sS = scr + 160, *sC = scr + 176;
+
     QW_TS(1);
     // ---------------- K8-K10 per leg (lanes 0-3 of both waves) ----------------
     // Wave 0 takes what the mass matrix needs (contact Jacobians, composite inertias, H, gravity), wave 1 what depends on the velocities
@@ -417,7 +439,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         F.r_h = mk(0.0, sy * K.hip_l, 0.0);
         F.r_k = mk(0.0, 0.0, -K.upper_l);
         F.loc = mk(0.0, side ? -K.foot_y : K.foot_y, -K.lower_l);
-        F.Ea = coord_rot(0, qj[3 * leg]); F.Eh = coord_rot(1, qj[3 * leg + 1]); F.Ek = coord_rot(1, qj[3 * leg + 2]);
+        F.Ea = coord_rot_sc(0, sS[3 * leg], sC[3 * leg]); F.Eh = coord_rot_sc(1, sS[3 * leg + 1], sC[3 * leg + 1]); F.Ek = coord_rot_sc(1, sS[3 * leg + 2], sC[3 * leg + 2]);
         // absolute rotations (world -> link)
         F.Eabs_a = mul(F.Ea, Rwb); F.Eabs_h = mul(F.Eh, F.Eabs_a); F.Eabs_k = mul(F.Ek, F.Eabs_h);
         return F;
@@ -678,7 +700,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         // --- orientation task (qr_task_body_orientation.cpp:43-81)
         {
             // quatDes = rpyToQuat(pBody_RPY_des): rotationMatrixToQuaternion(rpyToRotMat(rpy))
-            const m3 Rr = mul(mul(coord_rot(0, cm[9]), coord_rot(1, cm[10])), coord_rot(2, cm[11]));
+            const m3 Rr = mul(mul(coord_rot_sc(0, sS[12], sC[12]), coord_rot_sc(1, sS[13], sC[13])), coord_rot_sc(2, sS[14], sC[14]));
             const m3 r = transpose(Rr);
             real qd4[4];
             const real tr = r.m[0][0] + r.m[1][1] + r.m[2][2];
