@@ -258,6 +258,23 @@ int qrgpu_estimator_state_doubles(int window);
 int qrgpu_estimator_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_est_in, const unsigned *d_tick,
                                  double *d_est_state, float *d_est_out);
 
+/* Ground-plane fit and control frame of n robots for one control tick: qrGroundSurfaceEstimator::Update / GetNormalVector /
+ * ComputeControlFrame (QS/estimators/qr_ground_surface_estimator.cpp:40-70,151-206), which qrStateEstimatorContainer::Update runs in front
+ * of the robot estimator (QI/estimators/qr_state_estimator_container.h:76-81).  The fit fires when all four feet are in contact and one of
+ * them newly so; the control frame is the base's heading (the reference assumes a flat ground in the world, :168), low-pass filtered as
+ * roll / pitch / yaw with ratio 0.8 and roll := 0.
+ * d_ground_in [23][n]: footContact[4], footPositionsInBaseFrame[12] (3*leg+axis), basePosition[3], quat_wxyz[4].
+ * d_ground_state [QRGPU_GROUND_STATE_DOUBLES][n] doubles is the estimators' memory (lastContactState[4], a[3], n[3], controlFrameRPY[3]);
+ * reset != 0 applies Reset() before the update.  d_ground_out [QRGPU_GROUND_OUT_ROWS][n] (may be NULL): plane coefficients a[3]
+ * (z = a0 + a1 x + a2 y, base frame), unit normal n[3], controlFrameRPY[3], controlFrameOrientation[4], stateDataFlow.groundRMat[9]
+ * (row-major), stateDataFlow.baseRInControlFrame[9], updated flag.  d_est_in (may be NULL): the estimator's input array, whose rows 45-53
+ * (GetAlignedDirections) receive groundRMat, so that ground fit -> pose estimator stays on the device. */
+#define QRGPU_GROUND_IN_ROWS 23
+#define QRGPU_GROUND_STATE_DOUBLES 13
+#define QRGPU_GROUND_OUT_ROWS 32
+int qrgpu_ground_update_batch(qrgpu_ctx *ctx, int n, int reset, const float *d_ground_in, double *d_ground_state, float *d_ground_out,
+                              float *d_est_in);
+
 /* Open-loop gait generator (qrOpenLoopGaitGenerator::Update + Schedule, QS/gait/qr_openloop_gait_generator.cpp:126-249) of n robots for
  * one control tick.  d_contact [4][n]: robot->GetFootContact().  d_gait_state [QRGPU_GAIT_STATE_FLOATS][n] is the generators' memory;
  * reset != 0 applies Reset(0) before the update.  d_gait_out [24][n] (may be NULL): phaseInFullCycle[4], normalizedPhase[4],

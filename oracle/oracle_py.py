@@ -303,6 +303,16 @@ def swing_targets(geom3, hip_offset12, in58, out72_prev=None):
     return out
 
 
+def ground_run(in23):
+    """Ground-plane estimator of one robot from Reset(): in23 [T][23] (contact[4], footPositionsInBaseFrame[12], basePosition[3], quat[4])
+    -> out [T][32] (a[3], n[3], controlFrameRPY[3], controlFrameOrientation[4], groundRMat[9], baseRInControlFrame[9], updated)."""
+    a = np.ascontiguousarray(in23, _f)
+    assert a.ndim == 2 and a.shape[1] == 23
+    out = np.zeros((a.shape[0], 32), _f)
+    lib().qro_ground_run(a.shape[0], _fp(a), _fp(out))
+    return out
+
+
 def gait_run(cfg19, time, contact, stop=None):
     """Open-loop gait generator of one robot from Reset(0): time [T], contact [T][4] -> out [T][24]
     (phaseInFullCycle, normalizedPhase, desiredLegState, legState, curLegState, swingTimeRemaining)."""

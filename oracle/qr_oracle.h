@@ -236,6 +236,11 @@ struct EstimatorState {
 int ekf3_step(double x[3], double P[9], double qvar, double rvar, const double deltaV[3], const double z[3]);
 void estimator_update(const EstimatorConfig &cfg, const float in[54], unsigned tick, EstimatorState &s, float out[42]);
 
+// Ground-plane fit + control frame (qr_oracle_ground.cpp): qrGroundSurfaceEstimator, QS/estimators/qr_ground_surface_estimator.cpp:40-70,151-206
+struct GroundState { bool last_contact[4]; double a[3], n[3], rpy[3]; };
+void ground_reset(GroundState &s);
+void ground_update(const float in[23], GroundState &s, float out[32]);
+
 // Open-loop gait generator (qr_oracle_gait.cpp).  LegState: SWING 0, STANCE 1, EARLY_CONTACT 2.
 struct GaitConfig {                                   // config/a1_sim/openloop_gait_generator.yaml, gait "advanced_trot"
     float stance_duration[4] = {0.5f, 0.5f, 0.5f, 0.5f}, duty_factor[4] = {0.6f, 0.6f, 0.6f, 0.6f}, initial_leg_phase[4] = {0.5f, 0.f, 0.f, 0.5f};

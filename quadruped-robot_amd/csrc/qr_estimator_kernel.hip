@@ -599,4 +599,143 @@ __global__ void __launch_bounds__(64) qr_foothold_kernel(int n, FootholdDesc D, 
 #undef FI
 }
 
+// Ground-plane fit and control frame, one thread per robot, the reference's double arithmetic on the float robot state:
+//   qrGroundSurfaceEstimator::Update / GetNormalVector / ComputeControlFrame    quadruped/src/estimators/qr_ground_surface_estimator.cpp:40-70,151-206
+// (run by qrStateEstimatorContainer::Update in front of the robot estimator, quadruped/include/quadruped/estimators/qr_state_estimator_container.h:76-81).
+// The update fires when all four feet are in contact and one of them newly so; the control frame assumes a flat ground in the world
+// (nInWorldFrame := (0, 0, 1), :168), i.e. it is the base's heading, low-pass filtered as roll / pitch / yaw (ratio 0.8), roll := 0.
+// g_in [23][n]: footContact[4], footPositionsInBaseFrame[12] (3*leg+axis), basePosition[3], quat_wxyz[4].  g_st [13][n] doubles:
+// lastContactState[4], a[3], n[3], controlFrameRPY[3].  g_out [32][n]: a, n, controlFrameRPY, controlFrameOrientation[4], groundRMat[9]
+// (row-major), baseRInControlFrame[9], updated.  g_est_in (may be null): the estimator's input array, whose rows 45-53
+// (GetAlignedDirections) receive groundRMat.
+__global__ void __launch_bounds__(64) qr_ground_kernel(int n, int fresh, const float *__restrict__ g_in, double *__restrict__ g_st, float *__restrict__ g_out,
+                                                       float *__restrict__ g_est_in)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define IN(f) g_in[(size_t)(f) * N + i]
+#define ST(f) g_st[(size_t)(f) * N + i]
+    double a[3], nv[3], rpy[3];
+    bool last[4];
+    if (fresh) {                     // Reset(): a = 0, n = (0, 0, 1), controlFrameRPY = 0, lastContactState = 0
+        for (int k = 0; k < 3; ++k) { a[k] = 0.0; nv[k] = (k == 2) ? 1.0 : 0.0; rpy[k] = 0.0; }
+        for (int k = 0; k < 4; ++k) last[k] = false;
+    } else {
+        for (int k = 0; k < 4; ++k) last[k] = ST(k) != 0.0;
+        for (int k = 0; k < 3; ++k) { a[k] = ST(4 + k); nv[k] = ST(7 + k); rpy[k] = ST(10 + k); }
+    }
+    bool shouldUpdate = false;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool c = IN(k) != 0.f;
+        if (c) { if (!last[k]) shouldUpdate = true; ++cnt; }
+        ST(k) = c ? 1.0 : 0.0;
+    }
+    const float qf0 = IN(19), qf1 = IN(20), qf2 = IN(21), qf3 = IN(22);
+    const bool upd = !(cnt <= 3 || !shouldUpdate);
+    if (upd) {
+        double W[4][3], pZ[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { W[l][0] = 1.0; W[l][1] = (double)IN(4 + 3 * l); W[l][2] = (double)IN(5 + 3 * l); pZ[l] = (double)IN(6 + 3 * l); }
+        double ww[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { double acc = 0; for (int l = 0; l < 4; ++l) acc += W[l][r] * W[l][c]; ww[r][c] = acc; }
+        double inv[3][3];
+        {
+            const double c00 = ww[1][1] * ww[2][2] - ww[1][2] * ww[2][1], c01 = ww[1][2] * ww[2][0] - ww[1][0] * ww[2][2], c02 = ww[1][0] * ww[2][1] - ww[1][1] * ww[2][0];
+            const double det = ww[0][0] * c00 + ww[0][1] * c01 + ww[0][2] * c02;
+            const double id = 1.0 / det;
+            inv[0][0] = c00 * id; inv[1][0] = c01 * id; inv[2][0] = c02 * id;
+            inv[0][1] = (ww[0][2] * ww[2][1] - ww[0][1] * ww[2][2]) * id; inv[1][1] = (ww[0][0] * ww[2][2] - ww[0][2] * ww[2][0]) * id; inv[2][1] = (ww[0][1] * ww[2][0] - ww[0][0] * ww[2][1]) * id;
+            inv[0][2] = (ww[0][1] * ww[1][2] - ww[0][2] * ww[1][1]) * id; inv[1][2] = (ww[0][2] * ww[1][0] - ww[0][0] * ww[1][2]) * id; inv[2][2] = (ww[0][0] * ww[1][1] - ww[0][1] * ww[1][0]) * id;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { double m = 0; for (int c = 0; c < 3; ++c) m += inv[r][c] * W[l][c]; acc += m * pZ[l]; }
+            a[r] = acc;
+        }
+        const double factor = sqrt(a[1] * a[1] + a[2] * a[2] + 1);
+        nv[0] = -a[1] / factor; nv[1] = -a[2] / factor; nv[2] = 1.0 / factor;
+        // base x axis (first column of quaternionToRotationMatrix(quat)^T) in double
+        const double e0 = (double)qf0, e1 = (double)qf1, e2 = (double)qf2, e3 = (double)qf3;
+        double x[3] = {1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 + e0 * e3), 2 * (e1 * e3 - e0 * e2)};
+        const double nW[3] = {0, 0, 1};
+        double y[3] = {nW[1] * x[2] - nW[2] * x[1], nW[2] * x[0] - nW[0] * x[2], nW[0] * x[1] - nW[1] * x[0]};
+        { const double nn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]); y[0] /= nn; y[1] /= nn; y[2] /= nn; }
+        x[0] = y[1] * nW[2] - y[2] * nW[1]; x[1] = y[2] * nW[0] - y[0] * nW[2]; x[2] = y[0] * nW[1] - y[1] * nW[0];
+        { const double nn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); x[0] /= nn; x[1] /= nn; x[2] /= nn; }
+        // rotationMatrixToRPY(R^T), R = [x y n]: rotationMatrixToQuaternion transposes its argument again, so r = R
+        const double r00 = x[0], r01 = y[0], r02 = nW[0], r10 = x[1], r11 = y[1], r12 = nW[1], r20 = x[2], r21 = y[2], r22 = nW[2];
+        double q0, q1, q2, q3;
+        const double tr = r00 + r11 + r22;
+        if (tr > 0.0) { const double S = sqrt(tr + 1.0) * 2.0; q0 = 0.25 * S; q1 = (r21 - r12) / S; q2 = (r02 - r20) / S; q3 = (r10 - r01) / S; }
+        else if (r00 > r11 && r00 > r22) { const double S = sqrt(1.0 + r00 - r11 - r22) * 2.0; q0 = (r21 - r12) / S; q1 = 0.25 * S; q2 = (r01 + r10) / S; q3 = (r02 + r20) / S; }
+        else if (r11 > r22) { const double S = sqrt(1.0 + r11 - r00 - r22) * 2.0; q0 = (r02 - r20) / S; q1 = (r01 + r10) / S; q2 = 0.25 * S; q3 = (r12 + r21) / S; }
+        else { const double S = sqrt(1.0 + r22 - r00 - r11) * 2.0; q0 = (r10 - r01) / S; q1 = (r02 + r20) / S; q2 = (r12 + r21) / S; q3 = 0.25 * S; }
+        double nr[3];
+        const double as = fmin(-2. * (q1 * q3 - q0 * q2), .99999);
+        nr[2] = atan2(2 * (q1 * q2 + q0 * q3), q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3);
+        nr[1] = asin(as);
+        nr[0] = atan2(2 * (q2 * q3 + q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3);
+        const double ratio = 0.8;
+        for (int k = 0; k < 3; ++k) rpy[k] = (1 - ratio) * rpy[k] + ratio * nr[k];
+        rpy[0] = 0;
+        for (int k = 0; k < 3; ++k) { ST(4 + k) = a[k]; ST(7 + k) = nv[k]; ST(10 + k) = rpy[k]; }
+    } else if (fresh) {
+        for (int k = 0; k < 3; ++k) { ST(4 + k) = a[k]; ST(7 + k) = nv[k]; ST(10 + k) = rpy[k]; }
+    }
+    // R = rpyToRotMat(rpy)^T, rpyToRotMat = Rx(r) Ry(p) Rz(y) of coordinate-transform matrices (qr_se3.h:72-89,109-116)
+    double Rm[3][3];
+    {
+        double sr, cr, sp, cp, sy, cy;
+        sincos(rpy[0], &sr, &cr); sincos(rpy[1], &sp, &cp); sincos(rpy[2], &sy, &cy);
+        const double X[9] = {1, 0, 0, 0, cr, sr, 0, -sr, cr}, Y[9] = {cp, 0, -sp, 0, 1, 0, sp, 0, cp}, Z[9] = {cy, sy, 0, -sy, cy, 0, 0, 0, 1};
+        double XY[9], M[9];
+        mulmat3(X, Y, XY); mulmat3(XY, Z, M);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rm[r][c] = M[3 * c + r];
+    }
+    if (g_out || g_est_in) {
+        float g[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[r][c] = (float)Rm[r][c];
+        if (g_est_in) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g_est_in[(size_t)(45 + 3 * r + c) * N + i] = g[r][c];
+        if (g_out) {
+            // controlFrameOrientation = rpyToQuat(rpy) = rotationMatrixToQuaternion(rpyToRotMat(rpy)): r = rpyToRotMat^T = Rm
+            double q0, q1, q2, q3;
+            const double r00 = Rm[0][0], r01 = Rm[0][1], r02 = Rm[0][2], r10 = Rm[1][0], r11 = Rm[1][1], r12 = Rm[1][2], r20 = Rm[2][0], r21 = Rm[2][1], r22 = Rm[2][2];
+            const double tr = r00 + r11 + r22;
+            if (tr > 0.0) { const double S = sqrt(tr + 1.0) * 2.0; q0 = 0.25 * S; q1 = (r21 - r12) / S; q2 = (r02 - r20) / S; q3 = (r10 - r01) / S; }
+            else if (r00 > r11 && r00 > r22) { const double S = sqrt(1.0 + r00 - r11 - r22) * 2.0; q0 = (r21 - r12) / S; q1 = 0.25 * S; q2 = (r01 + r10) / S; q3 = (r02 + r20) / S; }
+            else if (r11 > r22) { const double S = sqrt(1.0 + r11 - r00 - r22) * 2.0; q0 = (r02 - r20) / S; q1 = (r01 + r10) / S; q2 = 0.25 * S; q3 = (r12 + r21) / S; }
+            else { const double S = sqrt(1.0 + r22 - r00 - r11) * 2.0; q0 = (r10 - r01) / S; q1 = (r02 + r20) / S; q2 = (r12 + r21) / S; q3 = 0.25 * S; }
+            // baseRMat (float, qr_robot.cpp:70) = quaternionToRotationMatrix(quat)^T
+            const float e0 = qf0, e1 = qf1, e2 = qf2, e3 = qf3;
+            float B[3][3];
+            B[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); B[0][1] = 2 * (e1 * e2 - e0 * e3); B[0][2] = 2 * (e1 * e3 + e0 * e2);
+            B[1][0] = 2 * (e1 * e2 + e0 * e3); B[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); B[1][2] = 2 * (e2 * e3 - e0 * e1);
+            B[2][0] = 2 * (e1 * e3 - e0 * e2); B[2][1] = 2 * (e2 * e3 + e0 * e1); B[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+#define OUT(f) g_out[(size_t)(f) * N + i]
+            for (int k = 0; k < 3; ++k) { OUT(k) = (float)a[k]; OUT(3 + k) = (float)nv[k]; OUT(6 + k) = (float)rpy[k]; }
+            OUT(9) = (float)q0; OUT(10) = (float)q1; OUT(11) = (float)q2; OUT(12) = (float)q3;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    OUT(13 + 3 * r + c) = g[r][c];
+                    float acc = 0.f;
+                    for (int k = 0; k < 3; ++k) acc += g[k][r] * B[k][c];
+                    OUT(22 + 3 * r + c) = acc;
+                }
+            OUT(31) = upd ? 1.f : 0.f;
+#undef OUT
+        }
+    }
+#undef IN
+#undef ST
+}
+
 }  // namespace qrgpu

@@ -1,5 +1,5 @@
 // ============================================================================
-// Whole-body-control tick for a batch of quadrupeds: one 64-lane wavefront
+// Whole-body-control tick for a batch of quadrupeds: two 64-lane wavefronts
 // (= one workgroup) per robot, all matrices LDS-resident, fp64 arithmetic on the
 // fp32 inputs.  gfx950 (MI355X) only.
 //
@@ -13,12 +13,12 @@
 //   K13 qrWholeBodyImpulseCtrl::GetModelRes / MakeTorque            QS/controllers/wbc/qr_wholebody_impulse_ctrl.cpp:50-299
 //   K14 UpdateLegCMD (stance legs take the WBC torque)              qr_wbc_locomotion_controller.cpp:205-219
 //
-// Structure: lanes 0-3 walk one leg each through the kinematic tree with 3-vector
-// / rigid-body-inertia (m, h, Ibar) algebra instead of generic 6x6 products; the
-// 18x18 / n x 18 dense algebra (A^-1 by symmetric sweep, null-space recursions,
-// Gram-matrix pseudo-inverses with an eigenvalue guard + Jacobi fallback that
-// reproduces pseudoInverse()'s singular-value cut, the relaxation QP by a
-// Schur-complement Goldfarb-Idnani) runs lane-parallel over matrix elements.
+// Structure: wave 0 carries the torque chain (dynamics -> A^-1 -> acceleration recursion -> relaxation QP), wave 1 the velocity-dependent
+// terms, the task set and the kinematic projection K12 (see the kernel's header).  Lanes 0-3 of each walk one leg through the kinematic tree
+// with 3-vector / rigid-body-inertia (m, h, Ibar) algebra instead of generic 6x6 products; the 18x18 / n x 18 dense algebra (A^-1 through
+// the base's Schur complement, null-space recursions over three-column task Jacobians, Gram-matrix pseudo-inverses with an eigenvalue
+// guard + Jacobi fallback that reproduces pseudoInverse()'s singular-value cut, the relaxation QP by a Schur-complement Goldfarb-Idnani)
+// runs lane-parallel over matrix elements.
 // Rotor bodies (1e-8 kg, gear 1): their constant isotropic inertia is folded into the
 // parent link on the host, the +k on H(j,j) and the k*axis coupling term are kept,
 // their gravity term is exactly zero and their Coriolis term (<= 1e-7 N m) is dropped.

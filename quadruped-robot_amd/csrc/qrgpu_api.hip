@@ -32,6 +32,7 @@ extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, Mp
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
+__global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_swing_kernel(int n, EstimatorDesc D, const float *g_in, float *g_cmd, float *g_tgt_world, float *g_qdes);
 __global__ void qr_foothold_kernel(int n, FootholdDesc D, const float *g_in, const float *g_gait_state, const float *g_gait_out, float *g_swing);
 __global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
@@ -558,6 +559,15 @@ int qrgpu_gait_update_batch(qrgpu_ctx *c, int n, const qrgpu_gait_desc *desc, fl
     memcpy(D.initial_leg_state, desc->initial_leg_state, 16);
     D.contact_detection_phase_threshold = desc->contact_detection_phase_threshold; D.wait_time = desc->wait_time; D.advanced_trot = desc->advanced_trot;
     hipLaunchKernelGGL(qr_gait_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, current_time, robot_stop, reset, d_contact, d_gait_state, d_gait_out, d_fe_in);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+int qrgpu_ground_update_batch(qrgpu_ctx *c, int n, int reset, const float *d_ground_in, double *d_ground_state, float *d_ground_out, float *d_est_in)
+{
+    if (!c || n <= 0 || n > c->max_batch || !d_ground_in || !d_ground_state) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(qr_ground_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, reset, d_ground_in, d_ground_state, d_ground_out, d_est_in);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

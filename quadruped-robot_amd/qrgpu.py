@@ -87,7 +87,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
-           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
+           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode"]
@@ -139,6 +139,7 @@ def load_library():
     lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_gait_desc_default.argtypes = [C.POINTER(gait_desc_struct)]; lib.qrgpu_gait_desc_default.restype = None
     lib.qrgpu_gait_update_batch.argtypes = [vp, ip, C.POINTER(gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp]
+    lib.qrgpu_ground_update_batch.argtypes = [vp, ip, ip, vp, vp, vp, vp]
     lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_foothold_desc_default.argtypes = [C.POINTER(foothold_desc_struct)]; lib.qrgpu_foothold_desc_default.restype = None
     lib.qrgpu_footholds_batch.argtypes = [vp, ip, C.POINTER(foothold_desc_struct), vp, vp, vp, vp]
@@ -333,6 +334,11 @@ class Context:
         d.contact_detection_phase_threshold = float(cfg19[16]); d.wait_time = float(cfg19[17]); d.advanced_trot = int(cfg19[18])
         self._chk(self._lib.qrgpu_gait_update_batch(self._h, n, C.byref(d), float(current_time), int(bool(stop)), int(bool(reset)), _dp(contact),
                                                     _dp(gait_state), _dp(gait_out), _dp(fe_in)))
+
+    def ground_update_batch(self, n, ground_in, ground_state, ground_out=None, est_in=None, reset=False):
+        """qrGroundSurfaceEstimator::Update of n robots (qr_ground_surface_estimator.cpp:40-70,151-206): ground_in [23][n],
+        ground_state [13][n] doubles (memory), ground_out [32][n]; est_in: rows 45-53 receive groundRMat."""
+        self._chk(self._lib.qrgpu_ground_update_batch(self._h, n, int(bool(reset)), _dp(ground_in), _dp(ground_state), _dp(ground_out), _dp(est_in)))
 
     def footholds_batch(self, n, desc29, fh_in, swing_in, gait_state=None, gait_out=None):
         """Swing-leg selection + foothold heuristic (qr_swing_leg_controller.cpp:211-236, qr_foothold_planner.cpp:110-239).
