@@ -292,6 +292,32 @@ void qrgpu_gait_desc_default(qrgpu_gait_desc *d);
 int qrgpu_gait_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_gait_desc *desc, float current_time, int robot_stop, int reset, const float *d_contact,
                             float *d_gait_state, float *d_gait_out, float *d_fe_in);
 
+/* Walk gait generator of n robots for one control tick (qrWalkGaitGenerator::Update, QS/gait/qr_walk_gait_generator.cpp:202-288; the
+ * constructor's bookkeeping :66-193 is done on the host from `desc`), and the contacts / force-window ratios its sub-states select in
+ * TorqueStanceLegController::UpdateFRatio's walk branch (QS/controllers/balance_controller/qr_torque_stance_leg_controller.cpp:125-168).
+ * current_time is the time the reference passes to Update (it is NOT taken relative to the last reset there).  d_contact [4][n]:
+ * robot->GetFootContact().  d_walk_state [QRGPU_WALK_STATE_FLOATS][n] is the generators' memory; reset: 2 = as constructed, 1 = Reset()
+ * (stateIndexOfLegs and the detection members survive a Reset in the reference), 0 = carry on.
+ * d_walk_out [QRGPU_WALK_OUT_ROWS][n] (may be NULL): phaseInFullCycle[4], normalizedPhase[4], desiredLegState[4] (LegState /
+ * SubLegState values: STANCE 1, LOAD_FORCE 5, UNLOAD_FORCE 6, FULL_STANCE 7, TRUE_SWING 8), legState[4], curLegState[4],
+ * detectedLegState[4] (SWING 0, STANCE 1, EARLY_CONTACT 2, LOSE_CONTACT 3), detectedEventTickPhase[4], moveBasePhase, contacts[4],
+ * fMinRatio[4], fMaxRatio[4].  d_ratio [8][n] (may be NULL): fMinRatio, fMaxRatio laid out as qrgpu_vmc_force_world_batch takes them;
+ * d_vmc_in (may be NULL): its rows 18-21 (contacts) are written.  Legs with duty factor 0 (USERDEFINED_SWING) are not supported; members the
+ * reference leaves uninitialised until their first write (moveBasePhase, detectedLegState, detectedEventTickPhase) start at zero. */
+#define QRGPU_WALK_STATE_FLOATS 33
+#define QRGPU_WALK_OUT_ROWS 41
+typedef struct {
+    float stance_duration[4], duty_factor[4], initial_leg_phase[4];   /* openloop_gait_generator.yaml, gait "walk": 7.5, 0.75, (0.5, 0, 0.75, 0.25) */
+    int initial_leg_state[4];                                          /* LegState: SWING 0, STANCE 1 */
+    float contact_detection_phase_threshold;                           /* 0.1 */
+    int n_states;                                                      /* entries of state_switch_que / state_ratio (<= 4) */
+    int state_switch[4];                                               /* SubLegState: full_stance 7, unload_force 6, true_swing 8, load_force 5 */
+    float state_ratio[4];                                              /* 0.2, 0.3, 0.3, 0.2 */
+} qrgpu_walk_gait_desc;
+void qrgpu_walk_gait_desc_default(qrgpu_walk_gait_desc *d);
+int qrgpu_walk_gait_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_walk_gait_desc *desc, float current_time, int robot_stop, int reset,
+                                 const float *d_contact, float *d_walk_state, float *d_walk_out, float *d_ratio, float *d_vmc_in);
+
 /* Swing-leg targets of the MPC/WBC mode (qrRaibertSwingLegController::GetAction, ADVANCED_TROT case on horizontal terrain,
  * QS/controllers/qr_swing_leg_controller.cpp:362-398,408-424): XY-linear / Z-parabola foot trajectory between the lift-off point and the
  * planned foothold, its world-frame image for the WBC foot tasks, and the inverse-kinematics joint targets of the swing command.

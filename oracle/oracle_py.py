@@ -303,6 +303,17 @@ def swing_targets(geom3, hip_offset12, in58, out72_prev=None):
     return out
 
 
+def walk_run(cfg26, time, contact, stop=None):
+    """Walk gait generator of one robot as constructed + Reset(0): time [T], contact [T][4] -> out [T][41] (phaseInFullCycle,
+    normalizedPhase, desiredLegState, legState, curLegState, detectedLegState, detectedEventTickPhase, moveBasePhase, contacts, fMinRatio,
+    fMaxRatio)."""
+    t = np.ascontiguousarray(time, _f); c = np.ascontiguousarray(contact, _f)
+    out = np.zeros((t.shape[0], 41), _f)
+    st = np.ascontiguousarray(stop, np.int32) if stop is not None else None
+    lib().qro_walk_run(_fp(np.ascontiguousarray(cfg26, _f)), t.shape[0], _fp(t), _fp(c), _ip(st) if st is not None else None, _fp(out))
+    return out
+
+
 def ground_run(in23):
     """Ground-plane estimator of one robot from Reset(): in23 [T][23] (contact[4], footPositionsInBaseFrame[12], basePosition[3], quat[4])
     -> out [T][32] (a[3], n[3], controlFrameRPY[3], controlFrameOrientation[4], groundRMat[9], baseRInControlFrame[9], updated)."""

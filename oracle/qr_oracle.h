@@ -241,6 +241,18 @@ struct GroundState { bool last_contact[4]; double a[3], n[3], rpy[3]; };
 void ground_reset(GroundState &s);
 void ground_update(const float in[23], GroundState &s, float out[32]);
 
+// Walk gait generator + the force-window ratios of its sub-states (qr_oracle_walk.cpp): qrWalkGaitGenerator, QS/gait/qr_walk_gait_generator.cpp;
+// TorqueStanceLegController::UpdateFRatio (walk branch), QS/controllers/balance_controller/qr_torque_stance_leg_controller.cpp:125-168
+struct WalkConfig {                                   // config/a1_sim/openloop_gait_generator.yaml, gait "walk"
+    float stance_duration[4], duty_factor[4], initial_leg_phase[4]; int initial_leg_state[4];
+    float contact_detection_phase_threshold; int n_states; int state_switch[4]; float state_ratio[4];
+};
+struct WalkDerived { int nq; int que[4]; float ratio[4], accum[5], true_swing_start_in_swing, full[4]; int state_index0[4]; };
+struct WalkState { int cur[4], desired[4], leg[4], detected[4], state_index[4]; float phase[4], nphase[4], event_phase[4], move_base_phase; };
+void walk_derive(const WalkConfig &c, WalkDerived &d);
+void walk_reset(const WalkConfig &c, const WalkDerived &d, WalkState &s, bool constructed);
+void walk_update(const WalkConfig &c, const WalkDerived &d, float currentTime, const float contact[4], bool stop, WalkState &s, float out[41]);
+
 // Open-loop gait generator (qr_oracle_gait.cpp).  LegState: SWING 0, STANCE 1, EARLY_CONTACT 2.
 struct GaitConfig {                                   // config/a1_sim/openloop_gait_generator.yaml, gait "advanced_trot"
     float stance_duration[4] = {0.5f, 0.5f, 0.5f, 0.5f}, duty_factor[4] = {0.6f, 0.6f, 0.6f, 0.6f}, initial_leg_phase[4] = {0.5f, 0.f, 0.f, 0.5f};

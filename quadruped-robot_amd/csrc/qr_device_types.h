@@ -120,6 +120,14 @@ struct GaitDesc {
     int advanced_trot;
 };
 
+// Walk gait generator parameters after the constructor's bookkeeping (qrgpu_walk_gait_desc -> qrgpu_api.hip)
+struct WalkDesc {
+    float duty_factor[4], initial_leg_phase[4], full[4];
+    int initial_leg_state[4], state_index0[4];
+    float contact_detection_phase_threshold, true_swing_start_in_swing;
+    int nq; int que[4]; float ratio[4], accum[5];
+};
+
 // Bytes of LDS in front of the block-packed inverse Hessian (must match the carve in qr_mpc_kernel.hip).
 // The four-wave active set needs the exchange buffers xz[4][NV], xr[4][64]; the single-wave one (h > 11 by default, and the
 // rescue pass) the staging arrays wl, yl, rl and the sAct / sPos tables.

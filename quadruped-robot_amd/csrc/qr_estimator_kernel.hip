@@ -738,4 +738,93 @@ __global__ void __launch_bounds__(64) qr_ground_kernel(int n, int fresh, const f
 #undef ST
 }
 
+// Walk gait generator and the force windows its sub-states select, one thread per robot, plain float arithmetic with the reference's
+// float / double mix:
+//   qrWalkGaitGenerator::Update                                   quadruped/src/gait/qr_walk_gait_generator.cpp:202-288
+//   qrGaitGenerator::Reset                                       quadruped/include/quadruped/gait/qr_gait.h:76-87
+//   TorqueStanceLegController::UpdateFRatio (walk branch)         quadruped/src/controllers/balance_controller/qr_torque_stance_leg_controller.cpp:125-168
+// st [QRGPU_WALK_STATE_FLOATS = 33][n]: cur[4], desired[4], leg[4], detected[4], stateIndexOfLegs[4], phase[4], normalizedPhase[4],
+// detectedEventTickPhase[4], moveBasePhase.  fresh: 2 = as constructed (+ Reset(0)), 1 = Reset() only (stateIndexOfLegs and the detection
+// members survive a Reset in the reference).  g_out [41][n]: phaseInFullCycle[4], normalizedPhase[4], desiredLegState[4], legState[4],
+// curLegState[4], detectedLegState[4], detectedEventTickPhase[4], moveBasePhase, contacts[4], fMinRatio[4], fMaxRatio[4].
+// g_ratio [8][n] (may be null): fMinRatio, fMaxRatio as qrgpu_vmc_force_world_batch takes them; g_vmc_in (may be null): rows 18-21 (contacts).
+__global__ void __launch_bounds__(64) qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *__restrict__ g_contact,
+                                                          float *__restrict__ st, float *__restrict__ g_out, float *__restrict__ g_ratio, float *__restrict__ g_vmc_in)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define ST(f) st[(size_t)(f) * N + i]
+    float mbp = (fresh == 2) ? 0.f : ST(32);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        int cur, desired, leg, detected, sidx;
+        float phase, nphase, evp;
+        if (fresh) {
+            cur = desired = leg = D.initial_leg_state[l]; nphase = 0.f;
+            if (fresh == 2) { sidx = D.state_index0[l]; phase = 0.f; detected = 0; evp = 0.f; }
+            else { sidx = (int)ST(16 + l); phase = ST(20 + l); detected = (int)ST(12 + l); evp = ST(28 + l); }
+        } else {
+            cur = (int)ST(l); desired = (int)ST(4 + l); leg = (int)ST(8 + l); detected = (int)ST(12 + l); sidx = (int)ST(16 + l);
+            phase = ST(20 + l); nphase = ST(24 + l); evp = ST(28 + l);
+        }
+        const bool contact = g_contact[(size_t)l * N + i] != 0.f;
+        if (!stop || (stop && cur == 0)) cur = desired;
+        const float augmentedTime = D.initial_leg_phase[l] * D.full[l] + currentTime;
+        phase = fmodf(augmentedTime, D.full[l]) / D.full[l];
+        const float ratio = D.duty_factor[l];
+        if (phase <= ratio) {
+            if (cur != 1) sidx = 0;
+            desired = 1; leg = 1;
+            nphase = phase / ratio;
+        } else {
+            desired = 0; leg = 0;
+            nphase = (float)((double)(phase - ratio) / (1.0 - (double)ratio));
+        }
+        if (desired == 0) {
+            int idx = sidx;
+            const float start = D.accum[idx], end = D.accum[idx + 1];
+            const float psc = (float)((double)(phase - ratio) / (1.0 - (double)ratio));
+            if (psc <= end && psc >= start) {
+                desired = D.que[idx];
+                nphase = (psc - start) / (end - start);
+            } else {
+                idx += 1;
+                if (idx > D.nq - 1) idx = D.nq - 1;      // (the reference indexes past its queue here: only if a tick were longer than a sub-state)
+                desired = D.que[idx];
+                sidx = idx;
+                nphase = (psc - D.accum[idx]) / D.ratio[idx];
+            }
+            mbp = (psc < D.true_swing_start_in_swing) ? psc / D.true_swing_start_in_swing : 1.0f;
+        }
+        detected = (desired != 1) ? 0 : 1;
+        if (!(nphase < D.contact_detection_phase_threshold)) {
+            if (desired == 8 && contact) { detected = 2; evp = phase; }
+            else if (desired == 1 && !contact) { detected = 3; evp = phase; }
+        }
+        ST(l) = (float)cur; ST(4 + l) = (float)desired; ST(8 + l) = (float)leg; ST(12 + l) = (float)detected; ST(16 + l) = (float)sidx;
+        ST(20 + l) = phase; ST(24 + l) = nphase; ST(28 + l) = evp;
+        // UpdateFRatio, walk branch
+        float ph = nphase, cont, fmax;
+        const float fmin = 0.001f;
+        if (detected == 1 || detected == 3) { cont = 1.f; fmax = 10.0f; }
+        else if (detected == 2) { cont = 1.f; const float t = fabsf(ph - 0.8f); fmax = 10.0f * fminf(0.01f, t); }
+        else if (desired == 5) { cont = 1.f; fmax = 10.0f * fmaxf(0.001f, ph); }
+        else if (desired == 6) { cont = 1.f; ph = ph / (3.f / 4.0f); fmax = 10.0f * fmaxf(0.001f, 1.0f - ph); }
+        else if (desired == 8) { cont = 0.f; fmax = 0.002f; }
+        else { cont = 1.f; fmax = 10.0f; }
+        if (g_out) {
+            g_out[(size_t)l * N + i] = phase; g_out[(size_t)(4 + l) * N + i] = nphase; g_out[(size_t)(8 + l) * N + i] = (float)desired;
+            g_out[(size_t)(12 + l) * N + i] = (float)leg; g_out[(size_t)(16 + l) * N + i] = (float)cur; g_out[(size_t)(20 + l) * N + i] = (float)detected;
+            g_out[(size_t)(24 + l) * N + i] = evp; g_out[(size_t)(29 + l) * N + i] = cont; g_out[(size_t)(33 + l) * N + i] = fmin; g_out[(size_t)(37 + l) * N + i] = fmax;
+        }
+        if (g_ratio) { g_ratio[(size_t)l * N + i] = fmin; g_ratio[(size_t)(4 + l) * N + i] = fmax; }
+        if (g_vmc_in) g_vmc_in[(size_t)(18 + l) * N + i] = cont;
+    }
+    ST(32) = mbp;
+    if (g_out) g_out[(size_t)28 * N + i] = mbp;
+#undef ST
+}
+
 }  // namespace qrgpu

@@ -33,6 +33,8 @@ __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
+__global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
+                                    float *g_vmc_in);
 __global__ void qr_swing_kernel(int n, EstimatorDesc D, const float *g_in, float *g_cmd, float *g_tgt_world, float *g_qdes);
 __global__ void qr_foothold_kernel(int n, FootholdDesc D, const float *g_in, const float *g_gait_state, const float *g_gait_out, float *g_swing);
 __global__ void qr_pack_state_kernel(int n, float c0, float c1, float c2, const float *g_in, const float *g_est, const float *g_rpy, float *g_mpc, float *g_fb);
@@ -559,6 +561,59 @@ int qrgpu_gait_update_batch(qrgpu_ctx *c, int n, const qrgpu_gait_desc *desc, fl
     memcpy(D.initial_leg_state, desc->initial_leg_state, 16);
     D.contact_detection_phase_threshold = desc->contact_detection_phase_threshold; D.wait_time = desc->wait_time; D.advanced_trot = desc->advanced_trot;
     hipLaunchKernelGGL(qr_gait_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, current_time, robot_stop, reset, d_contact, d_gait_state, d_gait_out, d_fe_in);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+void qrgpu_walk_gait_desc_default(qrgpu_walk_gait_desc *d)
+{   // config/a1_sim/openloop_gait_generator.yaml, gait "walk"
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    for (int l = 0; l < 4; ++l) { d->stance_duration[l] = 7.5f; d->duty_factor[l] = 0.75f; d->initial_leg_state[l] = 1; }
+    d->initial_leg_phase[0] = 0.5f; d->initial_leg_phase[1] = 0.f; d->initial_leg_phase[2] = 0.75f; d->initial_leg_phase[3] = 0.25f;
+    d->contact_detection_phase_threshold = 0.1f;
+    d->n_states = 4;
+    d->state_switch[0] = 7; d->state_switch[1] = 6; d->state_switch[2] = 8; d->state_switch[3] = 5;
+    d->state_ratio[0] = 0.2f; d->state_ratio[1] = 0.3f; d->state_ratio[2] = 0.3f; d->state_ratio[3] = 0.2f;
+}
+
+int qrgpu_walk_gait_update_batch(qrgpu_ctx *c, int n, const qrgpu_walk_gait_desc *desc, float current_time, int robot_stop, int reset,
+                                 const float *d_contact, float *d_walk_state, float *d_walk_out, float *d_ratio, float *d_vmc_in)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !d_contact || !d_walk_state || reset < 0 || reset > 2) return QRGPU_ERR_BAD_ARG;
+    if (desc->n_states < 1 || desc->n_states > 4) return QRGPU_ERR_BAD_ARG;
+    for (int l = 0; l < 4; ++l) if (!(desc->duty_factor[l] > 0.001f) || !(desc->duty_factor[l] < 1.f) || !(desc->stance_duration[l] > 0.f)) return QRGPU_ERR_BAD_ARG;
+    // the constructor's bookkeeping (qr_walk_gait_generator.cpp:87-157): sub-states below a ratio of 0.01 are dropped, the stance-like ones
+    // in front of true_swing add up to its start, running sums in float
+    WalkDesc D;
+    memset(&D, 0, sizeof(D));
+    float stand = 0.f;
+    for (int k = 0; k < desc->n_states; ++k) {
+        if (desc->state_ratio[k] < 0.01) continue;
+        const int st = desc->state_switch[k];
+        if (st != 5 && st != 6 && st != 7 && st != 8) return QRGPU_ERR_BAD_ARG;
+        if (st == 8) D.true_swing_start_in_swing = stand; else stand += desc->state_ratio[k];
+        D.que[D.nq] = st; D.ratio[D.nq] = desc->state_ratio[k]; ++D.nq;
+    }
+    if (D.nq < 1) return QRGPU_ERR_BAD_ARG;
+    D.accum[0] = 0.f;
+    for (int k = 0; k < D.nq; ++k) D.accum[k + 1] = D.accum[k] + D.ratio[k];
+    if (!(fabsf(D.accum[D.nq] - 1.0f) < 1e-4f)) return QRGPU_ERR_BAD_ARG;       // "not vaild ratio definition" (:124)
+    for (int l = 0; l < 4; ++l) {
+        D.duty_factor[l] = desc->duty_factor[l]; D.initial_leg_phase[l] = desc->initial_leg_phase[l]; D.initial_leg_state[l] = desc->initial_leg_state[l];
+        D.full[l] = desc->stance_duration[l] / desc->duty_factor[l];
+        D.state_index0[l] = 0;
+        if (desc->initial_leg_state[l] == 0) {
+            const float ph = (desc->initial_leg_phase[l] - desc->duty_factor[l]) / desc->duty_factor[l];
+            int k = 0;
+            while (k < D.nq && ph > D.accum[k]) k++;
+            D.state_index0[l] = k - 1 > 0 ? k - 1 : 0;
+        }
+    }
+    D.contact_detection_phase_threshold = desc->contact_detection_phase_threshold;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(qr_walk_gait_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, current_time, robot_stop, reset, d_contact, d_walk_state, d_walk_out,
+                       d_ratio, d_vmc_in);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

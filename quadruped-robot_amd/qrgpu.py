@@ -64,6 +64,12 @@ class gait_desc_struct(C.Structure):
                 ("advanced_trot", C.c_int)]
 
 
+class walk_gait_desc_struct(C.Structure):
+    _fields_ = [("stance_duration", C.c_float * 4), ("duty_factor", C.c_float * 4), ("initial_leg_phase", C.c_float * 4),
+                ("initial_leg_state", C.c_int * 4), ("contact_detection_phase_threshold", C.c_float), ("n_states", C.c_int),
+                ("state_switch", C.c_int * 4), ("state_ratio", C.c_float * 4)]
+
+
 EPILOGUE_HIP_COMP, EPILOGUE_CLIP = 1, 2
 COMM_ID_BYTES = 128
 
@@ -87,7 +93,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
-           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
+           "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode"]
@@ -139,6 +145,8 @@ def load_library():
     lib.qrgpu_estimator_update_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_gait_desc_default.argtypes = [C.POINTER(gait_desc_struct)]; lib.qrgpu_gait_desc_default.restype = None
     lib.qrgpu_gait_update_batch.argtypes = [vp, ip, C.POINTER(gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp]
+    lib.qrgpu_walk_gait_desc_default.argtypes = [C.POINTER(walk_gait_desc_struct)]; lib.qrgpu_walk_gait_desc_default.restype = None
+    lib.qrgpu_walk_gait_update_batch.argtypes = [vp, ip, C.POINTER(walk_gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp, vp]
     lib.qrgpu_ground_update_batch.argtypes = [vp, ip, ip, vp, vp, vp, vp]
     lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_foothold_desc_default.argtypes = [C.POINTER(foothold_desc_struct)]; lib.qrgpu_foothold_desc_default.restype = None
@@ -334,6 +342,18 @@ class Context:
         d.contact_detection_phase_threshold = float(cfg19[16]); d.wait_time = float(cfg19[17]); d.advanced_trot = int(cfg19[18])
         self._chk(self._lib.qrgpu_gait_update_batch(self._h, n, C.byref(d), float(current_time), int(bool(stop)), int(bool(reset)), _dp(contact),
                                                     _dp(gait_state), _dp(gait_out), _dp(fe_in)))
+
+    def walk_gait_update_batch(self, n, cfg26, current_time, contact, walk_state, walk_out=None, ratio=None, vmc_in=None, stop=False, reset=0):
+        """qrWalkGaitGenerator::Update of n robots + the walk branch of UpdateFRatio (qr_walk_gait_generator.cpp:202-288,
+        qr_torque_stance_leg_controller.cpp:125-168).  cfg26 = workload.walk_cfg(); reset: 2 = as constructed, 1 = Reset(), 0 = carry on."""
+        d = walk_gait_desc_struct()
+        v = np.asarray(cfg26, np.float32)
+        for l in range(4):
+            d.stance_duration[l] = float(v[l]); d.duty_factor[l] = float(v[4 + l]); d.initial_leg_phase[l] = float(v[8 + l]); d.initial_leg_state[l] = int(v[12 + l])
+            d.state_switch[l] = int(v[18 + l]); d.state_ratio[l] = float(v[22 + l])
+        d.contact_detection_phase_threshold = float(v[16]); d.n_states = int(v[17])
+        self._chk(self._lib.qrgpu_walk_gait_update_batch(self._h, n, C.byref(d), float(current_time), int(bool(stop)), int(reset), _dp(contact),
+                                                         _dp(walk_state), _dp(walk_out), _dp(ratio), _dp(vmc_in)))
 
     def ground_update_batch(self, n, ground_in, ground_state, ground_out=None, est_in=None, reset=False):
         """qrGroundSurfaceEstimator::Update of n robots (qr_ground_surface_estimator.cpp:40-70,151-206): ground_in [23][n],

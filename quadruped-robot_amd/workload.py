@@ -489,6 +489,16 @@ def gait_cfg(stance_duration=0.5, duty_factor=0.6, initial_leg_phase=(0.5, 0.0, 
                      wait_time, 1.0 if advanced_trot else 0.0], dtype=f32)
 
 
+def walk_cfg(stance_duration=7.5, duty_factor=0.75, initial_leg_phase=(0.5, 0.0, 0.75, 0.25), initial_leg_state=(1, 1, 1, 1),
+             contact_detection_phase_threshold=0.1, state_switch=(7, 6, 8, 5), state_ratio=(0.2, 0.3, 0.3, 0.2)):
+    """Packed walk gait parameters (config/a1_sim/openloop_gait_generator.yaml, gait "walk"; SubLegState: load_force 5, unload_force 6,
+    full_stance 7, true_swing 8): stance_duration[4], duty_factor[4], initial_leg_phase[4], initial_leg_state[4], threshold, n_states,
+    state_switch[4], state_ratio[4]."""
+    sw = list(state_switch) + [0] * (4 - len(state_switch)); sr = list(state_ratio) + [0.0] * (4 - len(state_ratio))
+    return np.array([*([stance_duration] * 4), *([duty_factor] * 4), *initial_leg_phase, *initial_leg_state, contact_detection_phase_threshold,
+                     len(state_switch), *sw, *sr], dtype=f32)
+
+
 def make_gait_contacts(n, ticks, cfg19, seed=0x6A, dt=0.002):
     """Foot contact streams [ticks][n][4] that mostly follow the nominal trot, with late touch-downs (lost contact at the end of a
     swing: exercises the hold of Schedule()) and early touch-downs (EARLY_CONTACT) sprinkled in."""
