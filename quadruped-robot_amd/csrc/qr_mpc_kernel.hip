@@ -1273,10 +1273,45 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     const double umax = -wave_min_d(hi ? (rq < rq2 ? rq : rq2) : rq);          // max u (>= 0 when any row is held properly)
                     const double worst = -wave_min_d(hi ? (-rq < -rq2 ? -rq : -rq2) : -rq);    // max r = -min u
                     const bool drop = worst > 1e-10 * (1.0 + (umax > 0.0 ? umax : 0.0));
+                    // Many wrong rows in the guess (a warm start keeps 60 % of its rows on average, and at h = 16 some keep a fifth): dropping them one
+                    // downdate round at a time costs 3-10 k cycles each, a block solve on what is left about 6 k + 1 k per row.  When at least
+                    // four rows and a quarter of the set have negative multipliers they all leave at once and the set is solved afresh.
+                    const double thr_neg = 1e-10 * (1.0 + (umax > 0.0 ? umax : 0.0));
+                    const bool neg1 = lane < q && rq > thr_neg, neg2 = hi && lane + 64 < q && rq2 > thr_neg;
+                    const int nneg = __popcll(__ballot(neg1)) + (hi ? __popcll(__ballot(neg2)) : 0);
+                    const bool block_drop = drop && P.no_block_drop != 1 && nneg >= (P.no_block_drop > 1 ? (P.no_block_drop >> 8) : 4) && (P.no_block_drop > 1 ? (P.no_block_drop & 255) : 4) * nneg >= q && nneg < q;
                     int lpos = -1;
-                    if (drop) { lpos = first_lane(lane < q && rq == worst); if (hi && lpos < 0) lpos = 64 + first_lane(lane + 64 < q && rq2 == worst); }
-                    if (lane == 0) { sCtl[2] = drop ? F_DROP : 0; sCtl[3] = lpos; }
+                    if (drop && !block_drop) { lpos = first_lane(lane < q && rq == worst); if (hi && lpos < 0) lpos = 64 + first_lane(lane + 64 < q && rq2 == worst); }
+                    if (lane == 0) { sCtl[2] = (drop && !block_drop) ? F_DROP : 0; sCtl[3] = lpos; }
                     __syncthreads();                      // B3
+                    if (block_drop) {
+                        // (the workers saw a round without a drop and wait at X1 for the next command)
+                        const unsigned long long k1 = __ballot(lane < q && !neg1), k2 = hi ? __ballot(lane + 64 < q && !neg2) : 0ull;
+                        const int n1 = __popcll(k1);
+                        const int np1 = __builtin_amdgcn_mbcnt_hi((unsigned)(k1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)k1, 0u));
+                        const int np2 = n1 + __builtin_amdgcn_mbcnt_hi((unsigned)(k2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)k2, 0u));
+                        if (own) {
+#pragma unroll
+                            for (int t = 0; t < 6; ++t) sPos[6 * kme + t] = (short)-1;
+                        }
+                        wave_sync();
+                        if (lane < q && !neg1) { sAct[np1] = 6 * ck + ct; sPos[6 * ck + ct] = (short)np1; }
+                        if (hi && lane + 64 < q && !neg2) { sAct[np2] = 6 * ck2 + ct2; sPos[6 * ck2 + ct2] = (short)np2; }
+                        q = n1 + (hi ? __popcll(k2) : 0);
+                        wave_sync();
+                        if (lane < q) { const int c = sAct[lane]; ck = (c * 10923) >> 16; ct = c - 6 * ck; }
+                        if (BIG && lane + 64 < q) { const int c = sAct[lane + 64]; ck2 = (c * 10923) >> 16; ct2 = c - 6 * ck2; }
+                        amask = 0; posk = 0;
+                        if (own) {
+#pragma unroll
+                            for (int t = 0; t < 6; ++t) { const int ps = sPos[6 * kme + t]; if (ps >= 0) { amask |= 1u << t; posk |= (unsigned long long)(ps & 0xff) << (8 * t); } }
+                        }
+#if defined(QR_DIAG_REFAC)
+                        if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 13] += nneg;
+#endif
+                        need_rebuild = true;
+                        break;
+                    }
                     if (!drop) {
                         x0 = gl[3 * kme] - ((xz[NV + 3 * kme] + xz[2 * NV + 3 * kme]) + xz[3 * NV + 3 * kme]);
                         x1 = gl[3 * kme + 1] - ((xz[NV + 3 * kme + 1] + xz[2 * NV + 3 * kme + 1]) + xz[3 * NV + 3 * kme + 1]);
@@ -1311,9 +1346,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     if (q == 0) { x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2]; uq = 0.0; uq2 = 0.0; break; }
                 }
 #if defined(QR_DIAG_REFAC)
-                if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 9] = clock64() - tr1;
+                if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 9] += clock64() - tr1;
 #endif
                 if (done) break;
+                if (need_rebuild) continue;               // (a block drop: solve on what is left)
             }
             double bs = INF; int bt = 0;
             {

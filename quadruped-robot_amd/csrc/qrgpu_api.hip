@@ -368,6 +368,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
+    { static const int nb = [] { const char *e = getenv("QRGPU_NO_BLOCK_DROP"); return e ? atoi(e) : 0; }(); P.no_block_drop = nb; }
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
