@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--excite", type=float, default=1.0)
     ap.add_argument("--draws", type=int, default=8, help="robot populations (generator seeds) the timed steps are split over; value = median")
     ap.add_argument("--seq", type=int, default=8, help="batches per temporally coherent sequence (walked back and forth)")
+    ap.add_argument("--walk", default="pingpong", choices=["pingpong", "forward"],
+                    help="how consecutive steps move through a sequence: back and forth (every step a neighbour of the last; on the way back time runs backwards), or forward only with one jump back to the start per --seq steps")
     ap.add_argument("--same-seed-ranks", action="store_true",
                     help="control experiment: every rank draws the same populations (identical work per GPU) instead of its own")
     ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend", "estimator"],
@@ -309,6 +311,8 @@ def main():
             host0 = seq
         dev_seq.append([[T(b[k]) for k in keys] for b in seq])
     walk = list(range(SEQ)) + list(range(SEQ - 2, 0, -1))        # 0 1 .. S-1 S-2 .. 1 | 0 1 ..: every step's batch is a neighbour of the last one
+    if args.walk == "forward":
+        walk = list(range(SEQ))                                  # 0 1 .. S-1 | 0 1 ..: time only runs forwards, one discontinuity per SEQ steps
     d_prev = torch.zeros((3, n), dtype=torch.float32, device=dev)
     d_force = torch.zeros((12, n), dtype=torch.float32, device=dev)
     d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
