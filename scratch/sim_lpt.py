@@ -31,5 +31,11 @@ for k in range(3, 8):
     c = costs[k]
     prev = costs[k - 1]
     ema = 0.5 * costs[k - 1] + 0.3 * costs[k - 2] + 0.2 * costs[k - 3]
+    # what the hardware does today: eight pools (XCDs) of 64 slots, robots [128 x, 128 x + 128) in pool x, each pool longest-first by the previous tick
+    chunked = max(sched(128 * x + np.argsort(-prev[128 * x:128 * x + 128]), c, 64) for x in range(8))
+    # one global longest-first order dealt round-robin to the pools
+    g = np.argsort(-prev)
+    dealt = max(sched(g[x::8], c, 64) for x in range(8))
+    print("          eight pools of 64 slots: chunk-local order %.0f, global order dealt round-robin %.0f" % (chunked, dealt))
     print("tick %d: corr(prev, now) %.2f | makespan: slot order %.0f, by previous tick %.0f, by 3-tick average %.0f, by true cost (ideal LPT) %.0f, lower bound %.0f" % (
         k, np.corrcoef(prev, c)[0, 1], sched(range(n), c), sched(np.argsort(-prev), c), sched(np.argsort(-ema), c), sched(np.argsort(-c), c), max(c.max(), c.sum() / 512)))
