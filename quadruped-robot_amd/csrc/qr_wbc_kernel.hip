@@ -331,6 +331,268 @@ __device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6]
 #define QR_WBC_SHARED_DOUBLES 1392
 #define QR_WBC_LDS_DOUBLES (QR_WBC_SHARED_DOUBLES + 2 * QW_SIZE)       // 4884 doubles = 39 072 B: four workgroups per CU
 
+// leg ids of the contacts / swing-foot tasks, 4 bits each in `cpack` / `tpack` (no indexed local arrays -> no scratch)
+#define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
+#define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
+
+// The relaxation QP of K13 and the torque store (+ K14 tail), on one wavefront.  Inputs in LDS: A (mass matrix), JC (stacked contact
+// Jacobian), qdd (commanded accelerations of the recursion), Cv, Gv, cm (commands incl. Fr_des and the contact flags).  Wq: >= QW_SIZE doubles
+// of workspace laid out as the QW_* offsets say (Nq over NP + T1, Sq over JB + JTP + JTB, the vectors at VEC / QP).
+__device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, const int n, const WbcConst &K, const int nc, const unsigned cpack, const bool bad_type,
+                                                 const real *A, const real *JC, const real *qdd, const real *Cv, const real *Gv, const real *cm, real *W, int *sI,
+                                                 float *__restrict__ g_tau, int *__restrict__ g_status, const int merge_tau, const int status_or, const int epilogue,
+                                                 long long *__restrict__ dbgT)
+{
+#define QW_TSF(i) do { if (dbgT && (threadIdx.x & 63) == 0 && threadIdx.x < 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+    int qp_iters = 0;
+    const int dimFr = 3 * nc;
+    real *tv = W + QW_VEC + 18;
+    real *Nq = W + QW_NP;          // 30 x 18 QP constraint normals
+    real *Sq = W + QW_JB;          // 18 x 18 S^-1
+    real *qd_ = W + QW_QP;         // 32 d
+    real *qr_ = qd_ + 32;          // 32 r
+    real *qu_ = qr_ + 32;          // 32 u
+    real *qc0 = qu_ + 32;          // 32 constraint offsets
+    real *qx = qc0 + 32;           // 18 z
+    QW_TSF(7);
+    // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
+    //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
+    //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
+    //   inequalities    :  Uf (Fr_des + z_f) - ineqVec >= 0
+    const int nz = 6 + dimFr, np_ = 6, mi = 6 * nc;
+    // gen (tv) = A qdd + C + G - Jc^T Fr_des  (all 18 rows; rows 6.. are reused for the torque)
+    if (lane < 18) {
+        real acc = Cv[lane] + Gv[lane];
+        for (int k = 0; k < 18; ++k) acc += A[lane * 18 + k] * qdd[k];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * CLEG(k / 3) + k % 3];
+        tv[lane] = acc;
+    }
+    // constraint normals Nq[c][0:nz], offsets qc0[c]
+    for (int e = lane; e < (np_ + mi) * nz; e += 64) {
+        const int c = e / nz, j = e - c * nz;
+        real v = 0.0;
+        if (c < 6) v = (j < 6) ? A[c * 18 + j] : -JC[(j - 6) * 18 + c];
+        else {
+            const int u = c - 6, k = u / 6, tt = u - 6 * k;      // Uf row tt of contact k
+            if (j >= 6 && (j - 6) / 3 == k) {
+                const int ax = (j - 6) - 3 * k;
+                // Uf rows: [0 0 1] [1 0 mu] [-1 0 mu] [0 1 mu] [0 -1 mu] [0 0 -1]   (qr_single_contact.cpp:40-62)
+                if (tt == 0) v = (ax == 2) ? 1.0 : 0.0;
+                else if (tt == 5) v = (ax == 2) ? -1.0 : 0.0;
+                else { const int a2 = (tt - 1) >> 1; v = (ax == a2) ? (((tt - 1) & 1) ? -1.0 : 1.0) : ((ax == 2) ? (real)K.mu : 0.0); }
+            }
+        }
+        Nq[c * 18 + j] = v;
+    }
+    wsync();
+    if (lane < np_ + mi) {
+        const int c = lane;
+        real v;
+        if (c < 6) v = tv[c];
+        else {
+            const int u = c - 6, k = u / 6, tt = u - 6 * k;
+            real acc = 0.0;
+            for (int ax = 0; ax < 3; ++ax) acc += Nq[c * 18 + 6 + 3 * k + ax] * cm[51 + 3 * CLEG(k) + ax];     // Uf Fr_des
+            v = acc - ((tt == 5) ? -(real)K.max_fz : 0.0);                                                    // - ineqVec
+        }
+        qc0[c] = v;
+    }
+    if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
+    wsync();
+    int stw = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
+    {
+        // Goldfarb-Idnani, Schur-complement form, M = W^-1 diagonal, dense normals.
+        int q = 0;
+        const real iw_fb = 1.0 / (real)K.w_fb, iw_fr = 1.0 / (real)K.w_fr;
+        auto Minv = [&](int j) -> real { return (j < 6) ? iw_fb : iw_fr; };
+        // one "add constraint c" attempt; returns 0 added, 1 dropped-one-and-retry, 2 failure/infeasible, 3 dependent
+        int iter = 0;
+        const int maxit = 200;
+        int *iter_out = &qp_iters;
+        bool fail = false;
+        int *act = sI;             // active ids
+        int *posi = sI + 32;       // constraint -> position or -1
+        if (lane < 32) posi[lane] = -1;
+        wsync();
+        // The six floating-base equalities enter together instead of one active-set iteration each: with S_e = N_e M N_e' (6 x 6),
+        // u_e = -S_e^-1 c_e, z = M N_e' u_e, S^-1 = S_e^-1, working set = {0..5}.  Same point the six equality iterations reach.
+        int next_eq = 0;
+        {
+            if (lane < 36) {
+                const int a = lane / 6, b2 = lane - 6 * a;
+                real acc = 0.0;
+                for (int j = 0; j < nz; ++j) acc += Nq[a * 18 + j] * Minv(j) * Nq[b2 * 18 + j];
+                Sq[a * 18 + b2] = acc;
+            }
+            wsync();
+            real tr = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tr += Sq[a * 18 + a];
+            const real minpiv = spd_inverse<1>(lane, Sq, 18, 6, qd_);
+            if (!(minpiv > 1e-14 * tr)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; }      // dependent equalities
+            if (lane < 6) {
+                real acc = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < 6; ++b2) acc -= Sq[lane * 18 + b2] * qc0[b2];
+                qu_[lane] = acc; act[lane] = lane; posi[lane] = lane;
+            }
+            wsync();
+            if (lane < nz) {
+                real acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc += Nq[a * 18 + lane] * qu_[a];
+                qx[lane] = Minv(lane) * acc;
+            }
+            q = 6; next_eq = np_;
+            wsync();
+        }
+        // Working-set vectors in registers: position i lives in lane i (constraint id act_r, multiplier u_r, and d, r of the current
+        // change); lane c also knows whether constraint c is active.  Only S^-1, the normals and x go through LDS; uniform gathers are
+        // v_readlane, reductions DPP.  (The six equalities are already in and are never dropped: every row handled here is an inequality.)
+        int act_r = (lane < 6) ? lane : 0;
+        real u_r = (lane < 6) ? qu_[lane] : 0.0;
+        bool active_c = lane < 6;
+        const real INF_ = __builtin_inf();
+        while (!fail) {
+            int p;
+            {
+                real bs = -1e-10; bool cand = false;
+                if (lane >= 6 && lane < np_ + mi && !active_c) {
+                    const int cj = 6 + 3 * ((lane - 6) / 6);                    // the three force unknowns of this row's contact
+                    const real s_ = qc0[lane] + (Nq[lane * 18 + cj] * qx[cj] + Nq[lane * 18 + cj + 1] * qx[cj + 1] + Nq[lane * 18 + cj + 2] * qx[cj + 2]);
+                    if (s_ < bs) { bs = s_; cand = true; }
+                }
+                const real mn = wave_min_d(bs);
+                if (!(mn < -1e-10)) break;
+                p = first_lane(cand && bs == mn);                               // lowest-id row holding the minimum (lane == constraint id)
+                if (p < 0) break;
+            }
+            real up = 0.0;
+            for (;;) {
+                if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
+                *iter_out = iter;
+                // an inequality row touches the three force unknowns of one contact: its products are three terms, not a reduction
+                const int pj = 6 + 3 * ((p - 6) / 6);
+                const real pn0 = Nq[p * 18 + pj], pn1 = Nq[p * 18 + pj + 1], pn2 = Nq[p * 18 + pj + 2];
+                const real delta = (pn0 * pn0 + pn1 * pn1 + pn2 * pn2) * iw_fr;
+                // w = M n_p is iw_fr * n_p on those three unknowns and zero elsewhere
+                const real w0 = iw_fr * pn0, w1 = iw_fr * pn1, w2 = iw_fr * pn2;
+                real dq_ = 0.0;
+                if (lane < q) { const real *na = Nq + act_r * 18 + pj; dq_ = na[0] * w0 + na[1] * w1 + na[2] * w2; }
+                // r = S^-1 d: lane i walks row i, d_j by v_readlane
+                real rq_ = 0.0;
+                {
+                    const real *Srow = Sq + ((lane < q) ? lane : 0) * 18;
+#pragma unroll
+                    for (int c = 0; c < 18; c += 6) {           // chunks of six columns, a chunk's loads in flight together
+                        if (c >= q) continue;
+                        real sv[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) sv[j] = Srow[c + j];                        // (row stride 18: in bounds; columns >= q are stale, masked below)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) rq_ += (c + j < q) ? sv[j] * readlane_d(dq_, c + j) : 0.0;
+                    }
+                    if (lane >= q) rq_ = 0.0;
+                }
+                const real dr = wave_sum_d(rq_ * dq_);
+                const real zc = delta - dr;
+                real t1; int lpos;
+                {
+                    const real tt = (lane < q && act_r >= np_ && rq_ > 0.0) ? u_r * fast_rcp(rq_) : INF_;
+                    t1 = wave_min_d(tt);
+                    lpos = (t1 < INF_) ? first_lane(tt == t1) : 0x7fffffff;
+                }
+                const real sp = qc0[p] + (pn0 * qx[pj] + pn1 * qx[pj + 1] + pn2 * qx[pj + 2]);
+                const bool have_z = zc > 1e-13 * delta;
+                const real izc = fast_rcp(zc);
+                const real t2 = have_z ? -sp * izc : INF_;
+                const real t = t1 < t2 ? t1 : t2;
+                if (!(t < INF_)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
+                if (have_z) {
+                    // z = w - M N r ; x += t z
+                    real acc = 0.0;
+                    const int lz = (lane < nz) ? lane : 0;
+#pragma unroll
+                    for (int c = 0; c < 18; c += 6) {
+                        if (c >= q) continue;
+                        real nv[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) nv[j] = Nq[__builtin_amdgcn_readlane(act_r, c + j) * 18 + lz];     // (lanes >= q hold act_r = 0: a valid row)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc += (c + j < q) ? nv[j] * readlane_d(rq_, c + j) : 0.0;
+                    }
+                    if (lane < nz) {
+                        const real wl_ = (lane == pj) ? w0 : (lane == pj + 1) ? w1 : (lane == pj + 2) ? w2 : 0.0;
+                        qx[lane] += t * (wl_ - Minv(lane) * acc);
+                    }
+                }
+                u_r -= t * rq_;
+                up += t;
+                if (have_z && t == t2) {
+                    const real isg = izc;
+                    if (lane < q) qr_[lane] = rq_;
+                    wsync();                                                    // r and the new x are in LDS
+                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; } }
+                    if (lane < q) { Sq[q * 18 + lane] = -rq_ * isg; Sq[lane * 18 + q] = -rq_ * isg; }
+                    if (lane == 0) Sq[q * 18 + q] = isg;
+                    if (lane == q) { act_r = p; u_r = up; }
+                    if (lane == p) active_c = true;
+                    ++q;
+                    wsync();
+                    break;
+                }
+                // partial or dual-only step: position lpos leaves
+                {
+                    const int l = lpos, last = q - 1;
+                    const int cdrop = __builtin_amdgcn_readlane(act_r, l), alast = __builtin_amdgcn_readlane(act_r, last);
+                    const real ulast = readlane_d(u_r, last);
+                    if (lane < q) qd_[lane] = Sq[lane * 18 + l];
+                    wsync();
+                    const real isl = 1.0 / qd_[l];
+                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; } }
+                    wsync();
+                    if (l != last) {
+                        if (lane < last) qr_[lane] = (lane == l) ? Sq[last * 18 + last] : Sq[last * 18 + lane];
+                        wsync();
+                        if (lane < last) { Sq[l * 18 + lane] = qr_[lane]; Sq[lane * 18 + l] = qr_[lane]; }
+                        if (lane == l) { act_r = alast; u_r = ulast; }
+                    }
+                    if (lane == cdrop) active_c = false;
+                    --q;
+                    wsync();
+                }
+            }
+        }
+    }
+
+    QW_TSF(8);
+    if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + 10] = qp_iters;
+    // ---------------- GetSolution (:210-228) + store ----------------
+    // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
+    if (lane < 12) {
+        const int row = 6 + lane;
+        real acc = tv[row];                                  // (A qdd_cmd + C + G - Jc^T Fr_des)[row]
+        for (int k = 0; k < 6; ++k) acc += A[row * 18 + k] * qx[k];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + row] * qx[6 + k];
+        const int leg = lane / 3;
+        const bool stance = cm[63 + leg] != 0.0;
+        if (!epilogue) {
+            if (!merge_tau || stance) g_tau[(size_t)lane * n + rid] = (float)acc;
+        } else {
+            // K14 tail (fused tick): UpdateLegCMD overwrites the stance legs (:205-219) AFTER qrFSMStateLocomotion::Run added the +-0.9 N m abad
+            // compensation to every leg (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), so the compensation survives on swing legs only (their
+            // command is what the MPC kernel left in g_tau); then the +-23 N m clip (QS/fsm/qr_safety_checker.cpp:48-66).  legCmd.tua is a double.
+            double t = stance ? (double)(float)acc : (double)g_tau[(size_t)lane * n + rid];
+            if (!stance && (epilogue & 1) && lane % 3 == 0) t += (double)((leg & 1) ? 0.9f : -0.9f);
+            if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
+            g_tau[(size_t)lane * n + rid] = (float)t;
+        }
+    }
+    if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
+    QW_TSF(9);
+#undef QW_TSF
+}
+
 // Two wavefronts per robot, 39 KB of LDS: 4 workgroups per CU = 2 waves per SIMD, 256 VGPRs each.
 //   wave 0: Jacobians, composite inertias, H, G -> A^-1                    -> prioritized acceleration recursion -> relaxation QP -> torques
 //   wave 1: velocities, foot kinematics, Jcdqd, Coriolis -> the task set   -> K12 kinematic projection (when asked for) -> q_des, qd_des
@@ -408,8 +670,6 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             if (in_contact) { cpack |= (unsigned)l << (4 * nc); ++nc; } else { tpack |= (unsigned)l << (4 * (nt - 2)); ++nt; }
         }
     }
-#define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
-#define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
     const int dimFr = 3 * nc;
 
     // sines and cosines of the twelve joint angles (and, on wave 1, of the commanded roll / pitch / yaw) in one go on fifteen lanes, instead of
@@ -963,242 +1223,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (t < nt - 1) npre_update(T2); else wsync();
     }
 
-    QW_TS(7);
-    // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
-    //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
-    //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
-    //   inequalities    :  Uf (Fr_des + z_f) - ineqVec >= 0
-    const int nz = 6 + dimFr, np_ = 6, mi = 6 * nc;
-    // gen (tv) = A qdd + C + G - Jc^T Fr_des  (all 18 rows; rows 6.. are reused for the torque)
-    if (lane < 18) {
-        real acc = Cv[lane] + Gv[lane];
-        for (int k = 0; k < 18; ++k) acc += A[lane * 18 + k] * qdd[k];
-        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * CLEG(k / 3) + k % 3];
-        tv[lane] = acc;
-    }
-    // constraint normals Nq[c][0:nz], offsets qc0[c]
-    for (int e = lane; e < (np_ + mi) * nz; e += 64) {
-        const int c = e / nz, j = e - c * nz;
-        real v = 0.0;
-        if (c < 6) v = (j < 6) ? A[c * 18 + j] : -JC[(j - 6) * 18 + c];
-        else {
-            const int u = c - 6, k = u / 6, tt = u - 6 * k;      // Uf row tt of contact k
-            if (j >= 6 && (j - 6) / 3 == k) {
-                const int ax = (j - 6) - 3 * k;
-                // Uf rows: [0 0 1] [1 0 mu] [-1 0 mu] [0 1 mu] [0 -1 mu] [0 0 -1]   (qr_single_contact.cpp:40-62)
-                if (tt == 0) v = (ax == 2) ? 1.0 : 0.0;
-                else if (tt == 5) v = (ax == 2) ? -1.0 : 0.0;
-                else { const int a2 = (tt - 1) >> 1; v = (ax == a2) ? (((tt - 1) & 1) ? -1.0 : 1.0) : ((ax == 2) ? (real)K.mu : 0.0); }
-            }
-        }
-        Nq[c * 18 + j] = v;
-    }
-    wsync();
-    if (lane < np_ + mi) {
-        const int c = lane;
-        real v;
-        if (c < 6) v = tv[c];
-        else {
-            const int u = c - 6, k = u / 6, tt = u - 6 * k;
-            real acc = 0.0;
-            for (int ax = 0; ax < 3; ++ax) acc += Nq[c * 18 + 6 + 3 * k + ax] * cm[51 + 3 * CLEG(k) + ax];     // Uf Fr_des
-            v = acc - ((tt == 5) ? -(real)K.max_fz : 0.0);                                                    // - ineqVec
-        }
-        qc0[c] = v;
-    }
-    if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
-    wsync();
-    int stw = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
-    {
-        // Goldfarb-Idnani, Schur-complement form, M = W^-1 diagonal, dense normals.
-        int q = 0;
-        const real iw_fb = 1.0 / (real)K.w_fb, iw_fr = 1.0 / (real)K.w_fr;
-        auto Minv = [&](int j) -> real { return (j < 6) ? iw_fb : iw_fr; };
-        // one "add constraint c" attempt; returns 0 added, 1 dropped-one-and-retry, 2 failure/infeasible, 3 dependent
-        int iter = 0;
-        const int maxit = 200;
-        int *iter_out = &qp_iters;
-        bool fail = false;
-        int *act = sI;             // active ids
-        int *posi = sI + 32;       // constraint -> position or -1
-        if (lane < 32) posi[lane] = -1;
-        wsync();
-        // The six floating-base equalities enter together instead of one active-set iteration each: with S_e = N_e M N_e' (6 x 6),
-        // u_e = -S_e^-1 c_e, z = M N_e' u_e, S^-1 = S_e^-1, working set = {0..5}.  Same point the six equality iterations reach.
-        int next_eq = 0;
-        {
-            if (lane < 36) {
-                const int a = lane / 6, b2 = lane - 6 * a;
-                real acc = 0.0;
-                for (int j = 0; j < nz; ++j) acc += Nq[a * 18 + j] * Minv(j) * Nq[b2 * 18 + j];
-                Sq[a * 18 + b2] = acc;
-            }
-            wsync();
-            real tr = 0.0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) tr += Sq[a * 18 + a];
-            const real minpiv = spd_inverse<1>(lane, Sq, 18, 6, qd_);
-            if (!(minpiv > 1e-14 * tr)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; }      // dependent equalities
-            if (lane < 6) {
-                real acc = 0.0;
-#pragma unroll
-                for (int b2 = 0; b2 < 6; ++b2) acc -= Sq[lane * 18 + b2] * qc0[b2];
-                qu_[lane] = acc; act[lane] = lane; posi[lane] = lane;
-            }
-            wsync();
-            if (lane < nz) {
-                real acc = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) acc += Nq[a * 18 + lane] * qu_[a];
-                qx[lane] = Minv(lane) * acc;
-            }
-            q = 6; next_eq = np_;
-            wsync();
-        }
-        // Working-set vectors in registers: position i lives in lane i (constraint id act_r, multiplier u_r, and d, r of the current
-        // change); lane c also knows whether constraint c is active.  Only S^-1, the normals and x go through LDS; uniform gathers are
-        // v_readlane, reductions DPP.  (The six equalities are already in and are never dropped: every row handled here is an inequality.)
-        int act_r = (lane < 6) ? lane : 0;
-        real u_r = (lane < 6) ? qu_[lane] : 0.0;
-        bool active_c = lane < 6;
-        const real INF_ = __builtin_inf();
-        while (!fail) {
-            int p;
-            {
-                real bs = -1e-10; bool cand = false;
-                if (lane >= 6 && lane < np_ + mi && !active_c) {
-                    const int cj = 6 + 3 * ((lane - 6) / 6);                    // the three force unknowns of this row's contact
-                    const real s_ = qc0[lane] + (Nq[lane * 18 + cj] * qx[cj] + Nq[lane * 18 + cj + 1] * qx[cj + 1] + Nq[lane * 18 + cj + 2] * qx[cj + 2]);
-                    if (s_ < bs) { bs = s_; cand = true; }
-                }
-                const real mn = wave_min_d(bs);
-                if (!(mn < -1e-10)) break;
-                p = first_lane(cand && bs == mn);                               // lowest-id row holding the minimum (lane == constraint id)
-                if (p < 0) break;
-            }
-            real up = 0.0;
-            for (;;) {
-                if (++iter > maxit) { stw |= QRGPU_ST_WBC_MAXITER_D; fail = true; break; }
-                *iter_out = iter;
-                // an inequality row touches the three force unknowns of one contact: its products are three terms, not a reduction
-                const int pj = 6 + 3 * ((p - 6) / 6);
-                const real pn0 = Nq[p * 18 + pj], pn1 = Nq[p * 18 + pj + 1], pn2 = Nq[p * 18 + pj + 2];
-                const real delta = (pn0 * pn0 + pn1 * pn1 + pn2 * pn2) * iw_fr;
-                // w = M n_p is iw_fr * n_p on those three unknowns and zero elsewhere
-                const real w0 = iw_fr * pn0, w1 = iw_fr * pn1, w2 = iw_fr * pn2;
-                real dq_ = 0.0;
-                if (lane < q) { const real *na = Nq + act_r * 18 + pj; dq_ = na[0] * w0 + na[1] * w1 + na[2] * w2; }
-                // r = S^-1 d: lane i walks row i, d_j by v_readlane
-                real rq_ = 0.0;
-                {
-                    const real *Srow = Sq + ((lane < q) ? lane : 0) * 18;
-#pragma unroll
-                    for (int c = 0; c < 18; c += 6) {           // chunks of six columns, a chunk's loads in flight together
-                        if (c >= q) continue;
-                        real sv[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) sv[j] = Srow[c + j];                        // (row stride 18: in bounds; columns >= q are stale, masked below)
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) rq_ += (c + j < q) ? sv[j] * readlane_d(dq_, c + j) : 0.0;
-                    }
-                    if (lane >= q) rq_ = 0.0;
-                }
-                const real dr = wave_sum_d(rq_ * dq_);
-                const real zc = delta - dr;
-                real t1; int lpos;
-                {
-                    const real tt = (lane < q && act_r >= np_ && rq_ > 0.0) ? u_r * fast_rcp(rq_) : INF_;
-                    t1 = wave_min_d(tt);
-                    lpos = (t1 < INF_) ? first_lane(tt == t1) : 0x7fffffff;
-                }
-                const real sp = qc0[p] + (pn0 * qx[pj] + pn1 * qx[pj + 1] + pn2 * qx[pj + 2]);
-                const bool have_z = zc > 1e-13 * delta;
-                const real izc = fast_rcp(zc);
-                const real t2 = have_z ? -sp * izc : INF_;
-                const real t = t1 < t2 ? t1 : t2;
-                if (!(t < INF_)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; break; }
-                if (have_z) {
-                    // z = w - M N r ; x += t z
-                    real acc = 0.0;
-                    const int lz = (lane < nz) ? lane : 0;
-#pragma unroll
-                    for (int c = 0; c < 18; c += 6) {
-                        if (c >= q) continue;
-                        real nv[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) nv[j] = Nq[__builtin_amdgcn_readlane(act_r, c + j) * 18 + lz];     // (lanes >= q hold act_r = 0: a valid row)
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) acc += (c + j < q) ? nv[j] * readlane_d(rq_, c + j) : 0.0;
-                    }
-                    if (lane < nz) {
-                        const real wl_ = (lane == pj) ? w0 : (lane == pj + 1) ? w1 : (lane == pj + 2) ? w2 : 0.0;
-                        qx[lane] += t * (wl_ - Minv(lane) * acc);
-                    }
-                }
-                u_r -= t * rq_;
-                up += t;
-                if (have_z && t == t2) {
-                    const real isg = izc;
-                    if (lane < q) qr_[lane] = rq_;
-                    wsync();                                                    // r and the new x are in LDS
-                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; Sq[i * 18 + j] += qr_[i] * qr_[j] * isg; } }
-                    if (lane < q) { Sq[q * 18 + lane] = -rq_ * isg; Sq[lane * 18 + q] = -rq_ * isg; }
-                    if (lane == 0) Sq[q * 18 + q] = isg;
-                    if (lane == q) { act_r = p; u_r = up; }
-                    if (lane == p) active_c = true;
-                    ++q;
-                    wsync();
-                    break;
-                }
-                // partial or dual-only step: position lpos leaves
-                {
-                    const int l = lpos, last = q - 1;
-                    const int cdrop = __builtin_amdgcn_readlane(act_r, l), alast = __builtin_amdgcn_readlane(act_r, last);
-                    const real ulast = readlane_d(u_r, last);
-                    if (lane < q) qd_[lane] = Sq[lane * 18 + l];
-                    wsync();
-                    const real isl = 1.0 / qd_[l];
-                    { const int rq2 = rcp16(q); for (int e = lane; e < q * q; e += 64) { const int i = fdiv16(e, rq2), j = e - i * q; if (i != l && j != l) Sq[i * 18 + j] -= qd_[i] * qd_[j] * isl; } }
-                    wsync();
-                    if (l != last) {
-                        if (lane < last) qr_[lane] = (lane == l) ? Sq[last * 18 + last] : Sq[last * 18 + lane];
-                        wsync();
-                        if (lane < last) { Sq[l * 18 + lane] = qr_[lane]; Sq[lane * 18 + l] = qr_[lane]; }
-                        if (lane == l) { act_r = alast; u_r = ulast; }
-                    }
-                    if (lane == cdrop) active_c = false;
-                    --q;
-                    wsync();
-                }
-            }
-        }
-    }
-
-    QW_TS(8);
-    if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + 10] = qp_iters;
-    // ---------------- GetSolution (:210-228) + store ----------------
-    // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
-    if (lane < 12) {
-        const int row = 6 + lane;
-        real acc = tv[row];                                  // (A qdd_cmd + C + G - Jc^T Fr_des)[row]
-        for (int k = 0; k < 6; ++k) acc += A[row * 18 + k] * qx[k];
-        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + row] * qx[6 + k];
-        const int leg = lane / 3;
-        const bool stance = cm[63 + leg] != 0.0;
-        if (!epilogue) {
-            if (!merge_tau || stance) g_tau[(size_t)lane * n + rid] = (float)acc;
-        } else {
-            // K14 tail (fused tick): UpdateLegCMD overwrites the stance legs (:205-219) AFTER qrFSMStateLocomotion::Run added the +-0.9 N m abad
-            // compensation to every leg (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), so the compensation survives on swing legs only (their
-            // command is what the MPC kernel left in g_tau); then the +-23 N m clip (QS/fsm/qr_safety_checker.cpp:48-66).  legCmd.tua is a double.
-            double t = stance ? (double)(float)acc : (double)g_tau[(size_t)lane * n + rid];
-            if (!stance && (epilogue & 1) && lane % 3 == 0) t += (double)((leg & 1) ? 0.9f : -0.9f);
-            if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
-            g_tau[(size_t)lane * n + rid] = (float)t;
-        }
-    }
-    if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
-    QW_TS(9);
+    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or, epilogue, dbgT);
 }
 
 }  // namespace qrgpu
