@@ -1516,7 +1516,20 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             const bool good = (st & 0xff) == 0;
             warm[lane] = 0;
             wave_sync();
-            if (own && good) warm[sLs[kme]] = (unsigned char)amask;
+            unsigned keep = amask;
+            if (P.warm_uthr > 0.0) {
+                // only rows held with a multiplier above a fraction of the largest go into the next tick's guess
+                const double um = -wave_min_d((lane < q) ? -uq : 0.0);
+                const double um2 = (BIG && q > 64) ? -wave_min_d((lane + 64 < q) ? -uq2 : 0.0) : 0.0;
+                const double thr_u = P.warm_uthr * (um > um2 ? um : um2);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int pos = (int)((posk >> (8 * t)) & 0xffu);
+                    const double ut = (BIG && pos >= 64) ? __shfl(uq2, pos - 64, 64) : __shfl(uq, pos & 63, 64);
+                    if (((amask >> t) & 1u) && !(ut > thr_u)) keep &= ~(1u << t);
+                }
+            }
+            if (own && good) warm[sLs[kme]] = (unsigned char)keep;
             if (lane == 0) {
                 *(unsigned long long *)(warm + 64) = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
                 warm[QR_WARM_STRIDE - 1] = good ? (unsigned char)h : 0;

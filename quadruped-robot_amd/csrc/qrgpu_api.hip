@@ -368,6 +368,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
     P.rescue_parity = c->rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
+    // rows enter the next tick's guess only when their multiplier exceeds 2 % of the solve's largest (weakly held rows are the ones that do
+    // not persist: measured 0.2446 -> 0.2211 ms per launch at h = 10, neutral at h = 5; at h = 16, where a missing row costs 7-13 k cycles
+    // to add, every threshold measured worse, so none is applied there).  QRGPU_WARM_UTHR overrides.
+    { static const double wu = [] { const char *e = getenv("QRGPU_WARM_UTHR"); return e ? atof(e) : -1.0; }(); P.warm_uthr = wu >= 0.0 ? wu : (4 * P.horizon <= 44 ? 0.02 : 0.0); }
     { static const int nb = [] { const char *e = getenv("QRGPU_NO_BLOCK_DROP"); return e ? atoi(e) : 0; }(); P.no_block_drop = nb; }
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
