@@ -1577,7 +1577,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 //                 of the rescue list (robots whose working set outgrew the main pass's registers or LDS) with this launch's larger LDS
 //                 allotment and the BIG register set.
 template <int MAXB, bool BIG, bool LIST, int NTHR>
-__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
+__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
@@ -1616,6 +1616,19 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
     } else {
+        if (P.rescue_mode == 3) {
+            // planned list, one robot per workgroup (so that the waves beyond the active set's four may leave after the sweep, which a workgroup
+            // striding over a list cannot allow): entry blockIdx.x of the list the last call's planning left.  The grid is the host's
+            // unsynchronised copy of the list's length; should the list be longer, the last workgroup hands the remainder to the trailing list
+            // launch, and workgroups past the end of a shorter list leave at once.
+            int cnt = P.pre_count[P.rescue_parity];
+            cnt = cnt < P.n ? cnt : P.n;
+            if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list)
+                for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = P.pre_list[e2];
+            if ((int)blockIdx.x >= cnt) return;
+            mpc_solve_robot<MAXB, BIG, NTHR>(P, io, P.pre_list[blockIdx.x], smem);
+            return;
+        }
         const int slot = xcd_robot_index(blockIdx.x, P.n);
         if (slot < 0) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
@@ -1633,6 +1646,7 @@ template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO); 
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
+template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

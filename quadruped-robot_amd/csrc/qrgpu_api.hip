@@ -27,6 +27,7 @@ template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel
 extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
@@ -427,6 +428,21 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         }
+        // QRGPU_PLANNED_WAVES=4: the four-wave list kernel, a workgroup striding over the list (this round's first form)
+        static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
+        if (planned_waves == 8) {
+            // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
+            // hands a longer list's tail to the trailing launch)
+            L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
+            int g3 = c->h_pre_count[c->rescue_parity];
+            g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
+            if (c->configured_rescue[1] < c->lds_per_cu) {
+                HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<2, true, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
+                c->configured_rescue[1] = c->lds_per_cu;
+            }
+            void *largs[2] = {(void *)&L, (void *)&io};
+            HIPCHK(c, hipExtLaunchKernel((const void *)qr_mpc_kernel<2, true, false, 512>, dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
+        } else
         hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, ls, L, io);
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
