@@ -58,7 +58,7 @@ def test_all_kernels_present(pkg):
     """Every kernel of the path and of the SURVEY 8f rows is in the gfx950 code object."""
     data = open(pkg._build.build(), "rb").read()
     for k in (b"qr_mpc_kernel", b"qr_wbc_kernel", b"qr_vmc_kernel", b"qr_frontend_kernel", b"qr_estimator_kernel", b"qr_pack_state_kernel",
-              b"qr_swing_kernel", b"qr_gait_kernel", b"qr_foothold_kernel", b"qr_lpt_order_kernel"):
+              b"qr_swing_kernel", b"qr_gait_kernel", b"qr_foothold_kernel", b"qr_lpt_order_kernel", b"qr_ground_kernel", b"qr_walk_gait_kernel"):
         assert k in data, k
 
 
@@ -72,6 +72,10 @@ def test_desc_defaults(pkg):
     f = pkg.qrgpu.foothold_desc_struct(); lib.qrgpu_foothold_desc_default(C.byref(f))
     assert abs(f.swing_kp[1] - 0.16) < 1e-7 and abs(f.foot_clearance - 0.01) < 1e-9 and abs(f.default_hip_position[1] + 0.135) < 1e-7
     assert np.allclose(np.array(f.hip_offset[:] + f.default_hip_position[:] + [f.hip_l] + f.swing_kp[:] + [f.foot_clearance], np.float32), pkg.workload.foothold_cfg("a1"))
+    w = pkg.qrgpu.walk_gait_desc_struct(); lib.qrgpu_walk_gait_desc_default(C.byref(w))
+    assert np.allclose(np.array(w.stance_duration[:] + w.duty_factor[:] + w.initial_leg_phase[:] + [float(x) for x in w.initial_leg_state[:]]
+                                + [w.contact_detection_phase_threshold, float(w.n_states)] + [float(x) for x in w.state_switch[:]] + w.state_ratio[:], np.float32),
+                       pkg.workload.walk_cfg())
 
 
 @pytest.mark.gpu
