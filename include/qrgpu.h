@@ -328,6 +328,25 @@ int qrgpu_walk_gait_update_batch(qrgpu_ctx *ctx, int n, const qrgpu_walk_gait_de
 int qrgpu_swing_targets_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const float *d_swing_in, float *d_wbc_cmd,
                               float *d_foot_target_world, float *d_qdes);
 
+/* Swing-leg action of the velocity mode -- the trot that the force-balance path (qrgpu_vmc_force_batch) belongs to:
+ * qrRaibertSwingLegController::GetAction, VELOCITY_LOCOMOTION case (QS/controllers/qr_swing_leg_controller.cpp:285-309, 408-424): the
+ * Raibert target in the base frame from the hip's horizontal velocity, XYLinear_ZParabola (height 0.1) between the lift-off point and that
+ * target at the warped phase of GenerateTrajectoryPoint(phaseModule = true), leg inverse kinematics.
+ * swing_vel_in [53][n]: swing flag[4] (the leg is in swingFootIds), normalizedPhase[4], phaseSwitchFootLocalPos[12] (3*leg+axis), estimated
+ * base velocity in the base frame[3], yaw rate, desiredSpeed[3] (stateDes 6..8), desiredTwistingSpeed (stateDes 11), dR[9]
+ * (stateDataFlow.baseRInControlFrame, row-major: rows 22-30 of qrgpu_ground_update_batch's output; the identity on PLANE / PLUM_PILES
+ * terrain), quat_wxyz[4], motor angles[12].  d_out [48][n], for the flagged legs only: footTargetPosition[12] (base frame),
+ * footPositionInBaseFrame[12], joint angle targets[12], joint velocity targets[12] (zero: the reference's parabola generator returns no
+ * velocity).  desc: leg lengths and robot->hipOffset (the inverse kinematics); vdesc: the controller's own parameters. */
+typedef struct {
+    float hip_position_com[12];       /* GetDefaultHipPosition() + comOffset, 3*leg+axis                              */
+    float stance_duration[4];         /* gaitGenerator->stanceDuration                                                */
+    float swing_kp[3];                /* user_parameters.yaml swingKp.trot: 0.03 x3                                   */
+    float desired_height;             /* user_parameters desiredHeight - footClearance: 0.26                          */
+} qrgpu_swing_velocity_desc;
+int qrgpu_swing_velocity_batch(qrgpu_ctx *ctx, int n, const qrgpu_estimator_desc *desc, const qrgpu_swing_velocity_desc *vdesc,
+                               const float *d_swing_vel_in, float *d_out);
+
 /* Swing-leg selection and the Raibert-type foothold heuristic that feed qrgpu_swing_targets_batch: qrRaibertSwingLegController::Update
  * (default branch, QS/controllers/qr_swing_leg_controller.cpp:211-236) + qrFootholdPlanner::ComputeHeuristicFootHold
  * (QS/planner/qr_foothold_planner.cpp:110-239) on flat ground (groundRMat = I).

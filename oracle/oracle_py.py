@@ -324,6 +324,15 @@ def ground_run(in23):
     return out
 
 
+def swing_velocity(geom3, hip_offset12, desc20, in53, out48_prev=None):
+    """Swing-leg action of the velocity mode (qr_swing_leg_controller.cpp:285-309, 408-424).  -> out[48]: footTargetPosition[12],
+    footPositionInBaseFrame[12], joint angle targets[12], joint velocity targets[12]; legs that are not flagged keep out48_prev (NaN)."""
+    out = np.full(48, np.nan, _f) if out48_prev is None else np.ascontiguousarray(out48_prev, _f).copy()
+    lib().qro_swing_velocity(_fp(np.ascontiguousarray(geom3, _f)), _fp(np.ascontiguousarray(hip_offset12, _f)), _fp(np.ascontiguousarray(desc20, _f)),
+                             _fp(np.ascontiguousarray(in53, _f)), _fp(out))
+    return out
+
+
 def gait_run(cfg19, time, contact, stop=None):
     """Open-loop gait generator of one robot from Reset(0): time [T], contact [T][4] -> out [T][24]
     (phaseInFullCycle, normalizedPhase, desiredLegState, legState, curLegState, swingTimeRemaining)."""

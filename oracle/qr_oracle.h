@@ -153,6 +153,7 @@ int mpc_solve_qp(const MpcAssembly &a, const float *gait, int horizon, double *u
 // K7: force -> (f_ff, torque).  qr_mpc_stance_leg_controller.cpp:402-409,139-153; QS/robots/qr_robot.cpp:148-172,241-251
 struct LegGeom { float hip_l = 0.08505f, upper_l = 0.2f, lower_l = 0.2f; };
 void mpc_force_to_torque(const LegGeom &geo, const float quat[4], const float q[12], const double f_world[12], float tau[12]);
+void swing_velocity_mode(const struct LegGeom &geo, const float hip_offset[12], const float desc[20], const float in[53], float out[48]);
 void analytical_leg_jacobian(const LegGeom &geo, const float q[3], int leg, float J[9] /*row-major*/);
 void foot_positions_in_base_frame(const LegGeom &geo, const float hipOffset[12], const float q[12], float out[12]); // QS/robots/qr_robot.cpp:127-146,175-184
 

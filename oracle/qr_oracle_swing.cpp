@@ -84,7 +84,99 @@ void swing_targets(const LegGeom &geo, const float hip_offset[12], const float i
     }
 }
 
+// Swing-leg action of the velocity mode (the trot of the VMC / force-balance path), QS/controllers/qr_swing_leg_controller.cpp:285-309 + 408-424:
+// the Raibert target in the base frame from the hip's horizontal velocity (estimated base velocity + yaw rate x hip lever, through
+// dR = baseRInControlFrame: the velocity mode runs on terrain type SLOPE, :271-276), XYLinear_ZParabola between the lift-off point and that
+// target (height 0.1, duration 1) at the warped phase of SwingFootTrajectory::GenerateTrajectoryPoint(phaseModule = true)
+// (QS/controllers/qr_foot_trajectory_generator.cpp:322-343), leg IK and J^-1 v.
+// desc[20]: hipPositions + comOffset [12] (3*leg+axis), stanceDuration[4], swingKp[3] (user_parameters swingKp.trot), desiredHeight - footClearance
+// in[53]: swing flag[4], normalizedPhase[4], phaseSwitchFootLocalPos[12], estimated base velocity (base frame)[3], yaw rate, desiredSpeed[3]
+//         (stateDes 6..8), desiredTwistingSpeed (stateDes 11), dR[9] (baseRInControlFrame, row-major), quat_wxyz[4], motor angles[12]
+// out[48]: footTargetPosition[12] (base frame), footPositionInBaseFrame[12], joint angle targets[12], joint velocity targets[12];
+//          entries of legs that are not flagged are left untouched.
+void swing_velocity_mode(const LegGeom &geo, const float hip_offset[12], const float desc[20], const float in[53], float out[48])
+{
+    const float *flag = in, *nphase = in + 4, *pswitch = in + 8, *bvel = in + 20, *sp = in + 24, *dR = in + 28, *quat = in + 37, *q = in + 41;
+    const float yawDot = in[23], twist = in[27];
+    Q4<float> qq = {{quat[0], quat[1], quat[2], quat[3]}};
+    const M3<float> Rwb = quaternionToRotationMatrix(qq);       // = baseRMat^T: robotBaseR.transpose() * v = Rwb v
+    for (int leg = 0; leg < 4; ++leg) {
+        if (flag[leg] == 0.f) continue;
+        const float ho[3] = {desc[3 * leg], desc[3 * leg + 1], desc[3 * leg + 2]};
+        const float tw[3] = {-ho[1], ho[0], 0.f};
+        float hv[3], hh[3], tgtv[3];
+        for (int i = 0; i < 3; ++i) hv[i] = bvel[i] + yawDot * tw[i];
+        for (int i = 0; i < 3; ++i) hh[i] = (dR[3 * i] * hv[0] + dR[3 * i + 1] * hv[1]) + dR[3 * i + 2] * hv[2];
+        hh[2] = 0.f;
+        for (int i = 0; i < 3; ++i) tgtv[i] = sp[i] + twist * tw[i];
+        float u[3];
+        for (int i = 0; i < 3; ++i) u[i] = hh[i] * desc[12 + leg] / 2.0f - desc[16 + i] * (tgtv[i] - hh[i]);
+        const float dh[3] = {0.f, 0.f, desc[19]};
+        float tgt[3];
+        for (int i = 0; i < 3; ++i) {
+            const float a = (dR[i] * u[0] + dR[3 + i] * u[1]) + dR[6 + i] * u[2];                    // dR^T u
+            const float b = (Rwb[i][0] * dh[0] + Rwb[i][1] * dh[1]) + Rwb[i][2] * dh[2];            // robotBaseR^T desiredHeight
+            const float off = (i < 2) ? ho[i] : 0.f;
+            tgt[i] = (a + off) - b;
+        }
+        const float *st = pswitch + 3 * leg;
+        // phase warp (phaseModule = true): double arithmetic on the float phase
+        const float inputPhase = nphase[leg];
+        float phase;
+        if (inputPhase <= 0.5) phase = (float)(0.8 * std::sin(inputPhase * M_PI));
+        else phase = (float)(0.8 + (inputPhase - 0.5) * 0.4);
+        float pw[3] = {0, 0, 0}, vw[3] = {0, 0, 0};
+        if (!(phase < 0.f - 1e-3) && !(phase >= 0.f + 1.f + 1e-3)) {
+            pw[0] = (1 - phase) * st[0] + phase * tgt[0];
+            pw[1] = (1 - phase) * st[1] + phase * tgt[1];
+            const float mid = std::max(tgt[2], st[2]) + 0.1f;
+            float dtp = phase - 0.f;
+            if (dtp > 1.f) dtp = 1.f;
+            if (!(dtp < 0.)) {
+                const float mid_phase = 0.5;
+                const float d1 = mid - st[2], d2 = tgt[2] - st[2];
+                const float d3 = std::pow((double)mid_phase, 2) - mid_phase;
+                const float ca = (d1 - d2 * mid_phase) / d3;
+                const float cb = (d2 * std::pow((double)mid_phase, 2) - d1) / d3;
+                const float cc = st[2];
+                pw[2] = ca * std::pow((double)phase, 2) + cb * phase + cc;
+            }
+        }
+        for (int i = 0; i < 3; ++i) { out[3 * leg + i] = tgt[i]; out[12 + 3 * leg + i] = pw[i]; }
+        const float sgn = ((leg + 1) % 2 == 0) ? 1.f : -1.f;
+        const float sh = geo.hip_l * sgn;
+        const float x = pw[0] - hip_offset[3 * leg], y = pw[1] - hip_offset[3 * leg + 1], z = pw[2] - hip_offset[3 * leg + 2];
+        const float lu = geo.upper_l, ll = geo.lower_l;
+        float tK = -std::acos(((x * x + y * y + z * z) - (sh * sh + lu * lu + ll * ll)) / (2 * ll * lu));
+        const float l = std::sqrt(lu * lu + ll * ll + 2 * lu * ll * std::cos(tK));
+        float tH = std::asin(-x / l) - tK / 2;
+        const float c1 = sh * y - l * std::cos(tH + tK / 2) * z;
+        const float s1 = l * std::cos(tH + tK / 2) * y + sh * z;
+        float tA = std::atan2(s1, c1);
+        float ang[3] = {tA, tH, tK};
+        float J[9];
+        analytical_leg_jacobian(geo, ang, leg, J);
+        const float det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
+        const float id = 1.f / det;
+        const float Ji[9] = {(J[4] * J[8] - J[5] * J[7]) * id, (J[2] * J[7] - J[1] * J[8]) * id, (J[1] * J[5] - J[2] * J[4]) * id,
+                             (J[5] * J[6] - J[3] * J[8]) * id, (J[0] * J[8] - J[2] * J[6]) * id, (J[2] * J[3] - J[0] * J[5]) * id,
+                             (J[3] * J[7] - J[4] * J[6]) * id, (J[1] * J[6] - J[0] * J[7]) * id, (J[0] * J[4] - J[1] * J[3]) * id};
+        for (int i = 0; i < 3; ++i) {
+            float a = ang[i];
+            if (std::isnan(a)) a = q[3 * leg + i];
+            out[24 + 3 * leg + i] = a;
+            out[36 + 3 * leg + i] = Ji[3 * i] * vw[0] + Ji[3 * i + 1] * vw[1] + Ji[3 * i + 2] * vw[2];
+        }
+    }
+}
+
 }  // namespace qro
+
+extern "C" void qro_swing_velocity(const float *geom3, const float *hip_offset12, const float *desc20, const float *in53, float *out48)
+{
+    qro::LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2];
+    qro::swing_velocity_mode(g, hip_offset12, desc20, in53, out48);
+}
 
 extern "C" void qro_swing_targets(const float *geom3, const float *hip_offset12, const float *in58, float *out72)
 {

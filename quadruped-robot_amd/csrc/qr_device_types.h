@@ -122,6 +122,9 @@ struct GaitDesc {
     int advanced_trot;
 };
 
+// Velocity-mode swing action parameters (qrgpu_swing_velocity_desc)
+struct SwingVelDesc { float hip_pos_com[12], stance_duration[4], swing_kp[3], desired_height; };
+
 // Walk gait generator parameters after the constructor's bookkeeping (qrgpu_walk_gait_desc -> qrgpu_api.hip)
 struct WalkDesc {
     float duty_factor[4], initial_leg_phase[4], full[4];

@@ -827,4 +827,100 @@ __global__ void __launch_bounds__(64) qr_walk_gait_kernel(int n, WalkDesc D, flo
 #undef ST
 }
 
+// Swing-leg action of the velocity mode (the trot of the force-balance path), one thread per robot:
+//   qrRaibertSwingLegController::GetAction, VELOCITY_LOCOMOTION case    quadruped/src/controllers/qr_swing_leg_controller.cpp:285-309, 408-424
+//   SwingFootTrajectory::GenerateTrajectoryPoint(phaseModule = true)   quadruped/src/controllers/qr_foot_trajectory_generator.cpp:322-343
+// g_in [53][n]: swing flag[4], normalizedPhase[4], phaseSwitchFootLocalPos[12], estimated base velocity (base frame)[3], yaw rate,
+// desiredSpeed[3], desiredTwistingSpeed, dR[9] (baseRInControlFrame, row-major: rows 22-30 of the ground kernel's output), quat_wxyz[4],
+// motor angles[12].  g_out [48][n], for the flagged legs: footTargetPosition[12] (base frame), footPositionInBaseFrame[12], joint angle
+// targets[12], joint velocity targets[12].
+__global__ void __launch_bounds__(64) qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *__restrict__ g_in, float *__restrict__ g_out)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = (size_t)n;
+#define IN(f) g_in[(size_t)(f) * N + i]
+    const float e0 = IN(37), e1 = IN(38), e2 = IN(39), e3 = IN(40);
+    float Rwb[3][3];                                                      // world -> body = baseRMat^T
+    Rwb[0][0] = 1 - 2 * (e2 * e2 + e3 * e3); Rwb[1][0] = 2 * (e1 * e2 - e0 * e3); Rwb[2][0] = 2 * (e1 * e3 + e0 * e2);
+    Rwb[0][1] = 2 * (e1 * e2 + e0 * e3); Rwb[1][1] = 1 - 2 * (e1 * e1 + e3 * e3); Rwb[2][1] = 2 * (e2 * e3 - e0 * e1);
+    Rwb[0][2] = 2 * (e1 * e3 - e0 * e2); Rwb[1][2] = 2 * (e2 * e3 + e0 * e1); Rwb[2][2] = 1 - 2 * (e1 * e1 + e2 * e2);
+    float dR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dR[k] = IN(28 + k);
+    const float bvel[3] = {IN(20), IN(21), IN(22)}, yawDot = IN(23), sp[3] = {IN(24), IN(25), IN(26)}, twist = IN(27);
+#pragma unroll
+    for (int leg = 0; leg < 4; ++leg) {
+        if (IN(leg) == 0.f) continue;
+        const float ho[3] = {V.hip_pos_com[3 * leg], V.hip_pos_com[3 * leg + 1], V.hip_pos_com[3 * leg + 2]};
+        const float tw[3] = {-ho[1], ho[0], 0.f};
+        float hv[3], hh[3], tgtv[3], u[3], tg[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hv[r] = bvel[r] + yawDot * tw[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hh[r] = (dR[3 * r] * hv[0] + dR[3 * r + 1] * hv[1]) + dR[3 * r + 2] * hv[2];
+        hh[2] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tgtv[r] = sp[r] + twist * tw[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) u[r] = hh[r] * V.stance_duration[leg] / 2.0f - V.swing_kp[r] * (tgtv[r] - hh[r]);
+        const float dh[3] = {0.f, 0.f, V.desired_height};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float a = (dR[r] * u[0] + dR[3 + r] * u[1]) + dR[6 + r] * u[2];
+            const float b = (Rwb[r][0] * dh[0] + Rwb[r][1] * dh[1]) + Rwb[r][2] * dh[2];
+            const float off = (r < 2) ? ho[r] : 0.f;
+            tg[r] = (a + off) - b;
+        }
+        const float st[3] = {IN(8 + 3 * leg), IN(9 + 3 * leg), IN(10 + 3 * leg)};
+        const float inputPhase = IN(4 + leg);
+        float phase;
+        if (inputPhase <= 0.5f) phase = (float)(0.8 * sin((double)inputPhase * 3.14159265358979323846));
+        else phase = (float)(0.8 + ((double)inputPhase - 0.5) * 0.4);
+        float pw[3] = {0.f, 0.f, 0.f};
+        if (!((double)phase < 0.0 - 1e-3) && !((double)phase >= 0.0 + 1.0 + 1e-3)) {
+            pw[0] = (1 - phase) * st[0] + phase * tg[0];
+            pw[1] = (1 - phase) * st[1] + phase * tg[1];
+            const float mid = (tg[2] > st[2] ? tg[2] : st[2]) + 0.1f;
+            if (!(phase < 0.f)) {
+                const float d1 = mid - st[2], d2 = tg[2] - st[2];
+                const float d3 = (float)(0.25 - 0.5);
+                const float ca = (d1 - d2 * 0.5f) / d3;
+                const float cb = (float)(((double)d2 * 0.25 - (double)d1) / (double)d3);
+                pw[2] = (float)((double)ca * ((double)phase * (double)phase) + (double)(cb * phase) + (double)st[2]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { g_out[(size_t)(3 * leg + r) * N + i] = tg[r]; g_out[(size_t)(12 + 3 * leg + r) * N + i] = pw[r]; }
+        const float sh = D.hip_l * ((leg & 1) ? 1.f : -1.f);
+        const float x = pw[0] - D.hip_offset[3 * leg], y = pw[1] - D.hip_offset[3 * leg + 1], z = pw[2] - D.hip_offset[3 * leg + 2];
+        const float lu = D.upper_l, ll = D.lower_l;
+        const float tK = -acosf(((x * x + y * y + z * z) - (sh * sh + lu * lu + ll * ll)) / (2 * ll * lu));
+        const float l = sqrtf(lu * lu + ll * ll + 2 * lu * ll * cosf(tK));
+        const float tH = asinf(-x / l) - tK / 2;
+        const float c1 = sh * y - l * cosf(tH + tK / 2) * z;
+        const float s1 = l * cosf(tH + tK / 2) * y + sh * z;
+        const float tA = atan2f(s1, c1);
+        const float ang[3] = {tA, tH, tK};
+        // J^-1 * (the generator's zero velocity): zero, or NaN where the Jacobian is (an unreachable target), as the reference's product is
+        float J[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) leg_jacobian_column(j, tA, tH, tK, sh, lu, ll, J[0][j], J[1][j], J[2][j]);
+        const float det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        const float id = 1.f / det;
+        const float Ji[3][3] = {{(J[1][1] * J[2][2] - J[1][2] * J[2][1]) * id, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id},
+                                {(J[1][2] * J[2][0] - J[1][0] * J[2][2]) * id, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id},
+                                {(J[1][0] * J[2][1] - J[1][1] * J[2][0]) * id, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float a = ang[r];
+            if (a != a) a = IN(41 + 3 * leg + r);                         // unreachable target: keep the current angle (:415-418)
+            g_out[(size_t)(24 + 3 * leg + r) * N + i] = a;
+            g_out[(size_t)(36 + 3 * leg + r) * N + i] = Ji[r][0] * 0.f + Ji[r][1] * 0.f + Ji[r][2] * 0.f;
+        }
+    }
+#undef IN
+}
+
 }  // namespace qrgpu

@@ -33,6 +33,7 @@ extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, Mp
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
+__global__ void qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *g_in, float *g_out);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
                                     float *g_vmc_in);
@@ -670,6 +671,23 @@ int qrgpu_footholds_batch(qrgpu_ctx *c, int n, const qrgpu_foothold_desc *desc, 
     memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset)); memcpy(D.default_hip_position, desc->default_hip_position, sizeof(D.default_hip_position));
     D.hip_l = desc->hip_l; memcpy(D.swing_kp, desc->swing_kp, sizeof(D.swing_kp)); D.foot_clearance = desc->foot_clearance;
     hipLaunchKernelGGL(qr_foothold_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, d_fh_in, d_gait_state, d_gait_out, d_swing_in);
+    HIPCHK(c, hipGetLastError());
+    return QRGPU_OK;
+}
+
+int qrgpu_swing_velocity_batch(qrgpu_ctx *c, int n, const qrgpu_estimator_desc *desc, const qrgpu_swing_velocity_desc *vdesc, const float *d_swing_vel_in,
+                               float *d_out)
+{
+    if (!c || n <= 0 || n > c->max_batch || !desc || !vdesc || !d_swing_vel_in || !d_out) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    EstimatorDesc D;
+    memset(&D, 0, sizeof(D));
+    D.hip_l = desc->hip_l; D.upper_l = desc->upper_l; D.lower_l = desc->lower_l;
+    memcpy(D.hip_offset, desc->hip_offset, sizeof(D.hip_offset));
+    SwingVelDesc V;
+    memcpy(V.hip_pos_com, vdesc->hip_position_com, sizeof(V.hip_pos_com)); memcpy(V.stance_duration, vdesc->stance_duration, sizeof(V.stance_duration));
+    memcpy(V.swing_kp, vdesc->swing_kp, sizeof(V.swing_kp)); V.desired_height = vdesc->desired_height;
+    hipLaunchKernelGGL(qr_swing_velocity_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, D, V, d_swing_vel_in, d_out);
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
 }

@@ -70,6 +70,10 @@ class walk_gait_desc_struct(C.Structure):
                 ("state_switch", C.c_int * 4), ("state_ratio", C.c_float * 4)]
 
 
+class swing_velocity_desc_struct(C.Structure):
+    _fields_ = [("hip_position_com", C.c_float * 12), ("stance_duration", C.c_float * 4), ("swing_kp", C.c_float * 3), ("desired_height", C.c_float)]
+
+
 EPILOGUE_HIP_COMP, EPILOGUE_CLIP = 1, 2
 COMM_ID_BYTES = 128
 
@@ -92,7 +96,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",
            "qrgpu_memcpy_d2h", "qrgpu_mpc_frontend_batch", "qrgpu_set_lpt_schedule", "qrgpu_vmc_desc_default", "qrgpu_vmc_setup", "qrgpu_vmc_force_batch", "qrgpu_vmc_force1", "qrgpu_set_rescue_pass", "qrgpu_estimator_desc_default", "qrgpu_estimator_state_doubles",
-           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
+           "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_swing_velocity_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
@@ -148,6 +152,7 @@ def load_library():
     lib.qrgpu_walk_gait_desc_default.argtypes = [C.POINTER(walk_gait_desc_struct)]; lib.qrgpu_walk_gait_desc_default.restype = None
     lib.qrgpu_walk_gait_update_batch.argtypes = [vp, ip, C.POINTER(walk_gait_desc_struct), C.c_float, ip, ip, vp, vp, vp, vp, vp]
     lib.qrgpu_ground_update_batch.argtypes = [vp, ip, ip, vp, vp, vp, vp]
+    lib.qrgpu_swing_velocity_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), C.POINTER(swing_velocity_desc_struct), vp, vp]
     lib.qrgpu_swing_targets_batch.argtypes = [vp, ip, C.POINTER(estimator_desc_struct), vp, vp, vp, vp]
     lib.qrgpu_foothold_desc_default.argtypes = [C.POINTER(foothold_desc_struct)]; lib.qrgpu_foothold_desc_default.restype = None
     lib.qrgpu_footholds_batch.argtypes = [vp, ip, C.POINTER(foothold_desc_struct), vp, vp, vp, vp]
@@ -372,6 +377,20 @@ class Context:
         for i in range(3):
             d.swing_kp[i] = float(v[25 + i])
         self._chk(self._lib.qrgpu_footholds_batch(self._h, n, C.byref(d), _dp(fh_in), _dp(gait_state), _dp(gait_out), _dp(swing_in)))
+
+    def swing_velocity_batch(self, n, cfg20, vdesc20, swing_vel_in, out):
+        """Swing-leg action of the velocity mode (qr_swing_leg_controller.cpp:285-309, 408-424).  cfg20 = workload.estimator_cfg() (geometry
+        part), vdesc20 = workload.swing_velocity_cfg(): hip position + com offset[12], stanceDuration[4], swingKp[3], desiredHeight - clearance."""
+        d = estimator_desc_struct()
+        cfg20 = np.asarray(cfg20, np.float32)
+        d.hip_l, d.upper_l, d.lower_l = (float(v) for v in cfg20[:3])
+        for i in range(12): d.hip_offset[i] = float(cfg20[7 + i])
+        v = swing_velocity_desc_struct(); vd = np.asarray(vdesc20, np.float32)
+        for i in range(12): v.hip_position_com[i] = float(vd[i])
+        for i in range(4): v.stance_duration[i] = float(vd[12 + i])
+        for i in range(3): v.swing_kp[i] = float(vd[16 + i])
+        v.desired_height = float(vd[19])
+        self._chk(self._lib.qrgpu_swing_velocity_batch(self._h, n, C.byref(d), C.byref(v), _dp(swing_vel_in), _dp(out)))
 
     def swing_targets_batch(self, n, cfg20, swing_in, wbc_cmd=None, foot_target_world=None, qdes=None):
         """Swing-leg targets (qr_swing_leg_controller.cpp:362-424, ADVANCED_TROT).  cfg20 = workload.estimator_cfg() (geometry part)."""

@@ -443,6 +443,49 @@ def make_swing_batch(n, robot="a1", seed=0x5E):
     return x
 
 
+def swing_velocity_cfg(robot="a1", stance_duration=0.3, swing_kp=(0.03, 0.03, 0.03), desired_height=0.27, foot_clearance=0.01, com_offset=(0.0, 0.0, 0.0)):
+    """Packed float32[20] for the velocity-mode swing action: GetDefaultHipPosition() + comOffset [12], stanceDuration[4] (trot: 0.3),
+    swingKp.trot[3], desiredHeight - footClearance (user_parameters.yaml)."""
+    r = ROBOTS[robot]
+    hp = np.asarray(r["default_hip_position"], f32).reshape(4, 3) + np.asarray(com_offset, f32)
+    return np.array([*hp.reshape(12), *([stance_duration] * 4), *swing_kp, desired_height - foot_clearance], dtype=f32)
+
+
+def make_swing_velocity_batch(n, robot="a1", seed=0x5F):
+    """Synthetic inputs of the velocity-mode swing kernel, AoS [n][53] (layout: include/qrgpu.h swing_vel_in)."""
+    rng = np.random.default_rng(seed)
+    r = ROBOTS[robot]
+    x = np.zeros((n, 53), f32)
+    pair = rng.integers(0, 4, n)
+    flags = np.zeros((n, 4), f32)
+    flags[pair == 0] = (1, 0, 0, 1); flags[pair == 1] = (0, 1, 1, 0); flags[pair == 2] = (0, 0, 0, 0); flags[pair == 3] = (1, 1, 1, 1)
+    x[:, 0:4] = flags
+    ph = rng.uniform(0, 1, (n, 4)).astype(f32)
+    ph[: n // 16] = 0.0; ph[n // 16: n // 8] = 1.0; ph[n // 8: n // 8 + 8] = 0.5
+    x[:, 4:8] = ph
+    hip = np.asarray(r["hip_offset"], f32)
+    side = np.array([-1, 1, -1, 1], f32) * r["hip_l"]
+    for leg in range(4):
+        base = hip[leg] + np.array([0, side[leg], -0.26], f32)
+        x[:, 8 + 3 * leg:11 + 3 * leg] = base + 0.03 * rng.standard_normal((n, 3))
+    x[:, 20:23] = rng.uniform(-0.6, 0.6, (n, 3)); x[:, 22] *= 0.2
+    x[:, 23] = rng.uniform(-1, 1, n)
+    x[:, 24:27] = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.3, 0.3, n), np.zeros(n)], 1)
+    x[:, 27] = rng.uniform(-1, 1, n)
+    rpy = np.stack([0.08 * rng.standard_normal(n), 0.08 * rng.standard_normal(n), rng.uniform(-np.pi, np.pi, n)], 1)
+    q = _quat_from_rpy(rpy)
+    x[:, 37:41] = q
+    # dR = baseRInControlFrame = groundRMat' * baseRMat with the control frame at the base's heading: the base's roll / pitch remain
+    rp = rpy.copy(); rp[:, 2] = 0
+    qq = _quat_from_rpy(rp).astype(np.float64)
+    e0, e1, e2, e3 = qq.T
+    x[:, 28:37] = np.stack([1 - 2 * (e2 * e2 + e3 * e3), 2 * (e1 * e2 - e0 * e3), 2 * (e1 * e3 + e0 * e2), 2 * (e1 * e2 + e0 * e3), 1 - 2 * (e1 * e1 + e3 * e3),
+                            2 * (e2 * e3 - e0 * e1), 2 * (e1 * e3 - e0 * e2), 2 * (e2 * e3 + e0 * e1), 1 - 2 * (e1 * e1 + e2 * e2)], 1)
+    x[:, 41:53] = np.tile(np.array([0.0, 0.9, -1.8], f32), (n, 4))
+    x[-1, 8:11] = (3.0, 0.0, -0.3); x[-1, 0] = 1; x[-1, 4] = 0.0       # an unreachable lift-off point at phase 0: NaN angles fall back to the current ones
+    return x
+
+
 def foothold_cfg(robot="a1", swing_kp=(0.16, 0.16, 0.16), foot_clearance=0.01):
     """Packed float32[29]: hip_offset[12], default_hip_position[12], hip_l, swing_kp[3], foot_clearance
     (robot_params.hip_offset / default_hip_positions, user_parameters.yaml swingKp.advanced_trot / footClearance)."""

@@ -58,7 +58,7 @@ def test_all_kernels_present(pkg):
     """Every kernel of the path and of the SURVEY 8f rows is in the gfx950 code object."""
     data = open(pkg._build.build(), "rb").read()
     for k in (b"qr_mpc_kernel", b"qr_wbc_kernel", b"qr_vmc_kernel", b"qr_frontend_kernel", b"qr_estimator_kernel", b"qr_pack_state_kernel",
-              b"qr_swing_kernel", b"qr_gait_kernel", b"qr_foothold_kernel", b"qr_lpt_order_kernel", b"qr_ground_kernel", b"qr_walk_gait_kernel"):
+              b"qr_swing_kernel", b"qr_gait_kernel", b"qr_foothold_kernel", b"qr_lpt_order_kernel", b"qr_ground_kernel", b"qr_walk_gait_kernel", b"qr_swing_velocity_kernel"):
         assert k in data, k
 
 

@@ -92,3 +92,53 @@ def test_foothold_heuristic_properties(pkg, oracle):
     o = oracle.footholds(desc, z)
     for leg in range(4):
         assert np.allclose(o[24 + 3 * leg:27 + 3 * leg], [ho[leg, 0], ho[leg, 1] + hl * side[leg], -(0.28 - clr)], atol=1e-7)
+
+
+def test_swing_velocity_mode_properties(pkg, oracle):
+    """Velocity-mode swing action (qr_swing_leg_controller.cpp:285-309): the Raibert target, the warped phase, the parabola, the IK."""
+    W = pkg.workload
+    cfg = W.estimator_cfg("a1"); geom, ho = cfg[:3], cfg[7:19]
+    vd = W.swing_velocity_cfg("a1")
+    x = W.make_swing_velocity_batch(160, seed=3)
+    for i in range(160):
+        o = oracle.swing_velocity(geom, ho, vd, x[i])
+        dR = x[i, 28:37].reshape(3, 3).astype(np.float64)
+        w_, a, b, c = x[i, 37:41].astype(np.float64)
+        Rbw = np.array([[1 - 2 * (b * b + c * c), 2 * (a * b - w_ * c), 2 * (a * c + w_ * b)],
+                        [2 * (a * b + w_ * c), 1 - 2 * (a * a + c * c), 2 * (b * c - w_ * a)],
+                        [2 * (a * c - w_ * b), 2 * (b * c + w_ * a), 1 - 2 * (a * a + b * b)]])        # baseRMat
+        for leg in range(4):
+            sl = slice(3 * leg, 3 * leg + 3)
+            if x[i, leg] == 0:
+                assert np.isnan(o[0:12][sl]).all() and np.isnan(o[24:36][sl]).all()
+                continue
+            hp = vd[0:12][sl].astype(np.float64)
+            tw = np.array([-hp[1], hp[0], 0.0])
+            hh = dR @ (x[i, 20:23].astype(np.float64) + float(x[i, 23]) * tw); hh[2] = 0
+            tv = x[i, 24:27].astype(np.float64) + float(x[i, 27]) * tw
+            tgt = dR.T @ (hh * float(vd[12 + leg]) / 2 - vd[16:19].astype(np.float64) * (tv - hh)) + np.array([hp[0], hp[1], 0]) - Rbw.T @ np.array([0, 0, float(vd[19])])
+            np.testing.assert_allclose(o[0:12][sl], tgt, atol=3e-6)
+            p = float(x[i, 4 + leg])
+            ph = 0.8 * np.sin(p * np.pi) if p <= 0.5 else 0.8 + (p - 0.5) * 0.4
+            st = x[i, 8:20][sl].astype(np.float64)
+            pb = o[12:24][sl].astype(np.float64)
+            np.testing.assert_allclose(pb[:2], (1 - ph) * st[:2] + ph * tgt[:2], atol=3e-6)
+            mid = max(st[2], tgt[2]) + 0.1
+            np.testing.assert_allclose(pb[2], np.polyval(np.polyfit([0, 0.5, 1], [st[2], mid, tgt[2]], 2), ph), atol=3e-6)
+            if p == 0.0:
+                np.testing.assert_allclose(pb, st, atol=1e-6)                                  # lift-off point at the start of the swing
+            if p == 1.0:
+                np.testing.assert_allclose(pb, tgt, atol=3e-6)                                 # the warp ends at 0.8 + 0.5 * 0.4 = 1: on the target
+            ang = o[24:36][sl]
+            if i == 159 and leg == 0:
+                assert np.array_equal(ang[1:], x[i, 41:53][sl][1:])                           # unreachable: NaN angles replaced by the current ones
+                continue
+            qfull = x[i, 41:53].copy(); qfull[sl] = ang
+            fk = oracle.foot_positions(geom, ho, qfull).reshape(4, 3)[leg]
+            np.testing.assert_allclose(fk, pb, atol=5e-6)
+            assert np.all(o[36:48][sl] == 0)
+    # a standing robot with no command: the target lies under the hip, desiredHeight - footClearance below the base
+    y = np.zeros(53, np.float32); y[0:4] = 1; y[4:8] = 1.0; y[28] = y[32] = y[36] = 1; y[37] = 1; y[41:53] = np.tile([0.0, 0.9, -1.8], 4)
+    y[8:20] = (ho.reshape(4, 3) + np.array([0, 0, -0.26], np.float32)).reshape(12)
+    o = oracle.swing_velocity(geom, ho, vd, y)
+    np.testing.assert_allclose(o[0:12].reshape(4, 3), np.column_stack([vd[0:12].reshape(4, 3)[:, :2], np.full(4, -0.26)]), atol=1e-6)
