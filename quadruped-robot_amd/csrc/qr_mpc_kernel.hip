@@ -38,6 +38,9 @@ namespace qrgpu {
 
 #define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
 #ifndef QR_MAIN_WAVES_PER_SIMD
+#ifndef QR_RCP_PIVOT
+#define QR_RCP_PIVOT fast_rcp1
+#endif
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
 #endif
 #ifndef QR_HESS_VALU
@@ -747,7 +750,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     const double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
                     const double det = p00 * c00 + p01 * c01 + p02 * c02;
                     if (!(det > 0.0) || !(p00 > 0.0)) sMisc[1] = 1;                  // -> QRGPU_ST_MPC_NOTSPD, picked up by thread 0 after the sweep
-                    const double id = fast_rcp(det);
+                    const double id = QR_RCP_PIVOT(det);
                     double *d = pn + 9 * kk;
                     d[0] = c00 * id; d[1] = c01 * id; d[2] = c02 * id; d[4] = c11 * id; d[5] = c12 * id; d[8] = c22 * id;
                 } else {
@@ -995,7 +998,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 double *nxt = colp + ((p & 1) ^ 1) * QMAX;
                 const double d = cur[p];
                 if (!(d > 1e-11 * diag0[p])) { ok = false; break; }          // (the same value in every thread: a uniform exit)
-                const double ip = fast_rcp(d);
+                const double ip = QR_RCP_PIVOT(d);
 #pragma unroll
                 for (int m = 0; m < NE; ++m) {
                     if (QR_AS_THREADS * m < ne) {                              // (uniform; threads past the last element work on a zero at (0, 0))

@@ -14,6 +14,15 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
+// 1/x by v_rcp_f64 (4.6e-8 relative, scratch/ubench/rcp.hip) + one Newton step: 2.2e-15 relative -- for the pivots of a sweep, whose
+// reciprocal sits on the dependent chain of every step
+__device__ __forceinline__ double fast_rcp1(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
 {
