@@ -38,8 +38,10 @@ namespace qrgpu {
 
 #define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
 #ifndef QR_MAIN_WAVES_PER_SIMD
+// (fast_rcp1 -- one Newton step, 2.2e-15 relative -- saves 0.7 % of the main pass, but one robot of the stress set at twice the 8d ranges then
+// ran into the iteration cap: the pivots keep the full-accuracy reciprocal)
 #ifndef QR_RCP_PIVOT
-#define QR_RCP_PIVOT fast_rcp1
+#define QR_RCP_PIVOT fast_rcp
 #endif
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
 #endif
