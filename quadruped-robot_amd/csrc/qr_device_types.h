@@ -74,6 +74,7 @@ struct MpcLaunch {
     // scratch instead ([robot][tri(QR_QH)] doubles, L2-resident), MAXB = 9 variants only
     double *sinv_spill;
     double warm_uthr;           // rows enter the next tick's guess only when their multiplier exceeds this fraction of the solve's largest (0 = all)
+    int *started;               // planned list launch only: bumped by each of its workgroups as it starts (the gate in front of the main pass waits for them)
     int no_block_drop;          // diagnostic (QRGPU_NO_BLOCK_DROP=1): a warm start's wrong rows leave one downdate round at a time
     int no_wcache;              // diagnostic (QRGPU_NO_WCACHE=1): always take the z = w - M (N_A r) form
     // warm start (speed only): [robot][QR_WARM_STRIDE] bytes: the 6-bit active-row mask of each of the <= 64 original leg-steps at the end of the

@@ -1586,6 +1586,7 @@ __global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST && !BIG) ? (NTHR >= 384 
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
+    if (P.started && threadIdx.x == 0) atomicAdd(P.started, 1);        // (planned list launches: see qr_gate_kernel)
     if constexpr (LIST) {
         const bool planned = P.rescue_mode == 2;
         if (!planned && blockIdx.x < 8) {
@@ -1652,6 +1653,17 @@ template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);   
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
+
+// Holds the stream it is launched on until the `expected` workgroups of the planned list launch (side stream) have started, or max_ticks of
+// the 100 MHz clock have passed, whichever comes first; then clears the counter.  A listed robot needs a whole CU: left to the dispatcher, the
+// main pass's thousand workgroups fill every CU first and the listed robot starts 80-160 us late -- which is then the end of the launch.
+__global__ void qr_gate_kernel(int *counter, int expected, long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)

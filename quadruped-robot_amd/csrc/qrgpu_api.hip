@@ -34,6 +34,7 @@ __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *g_in, float *g_out);
+__global__ void qr_gate_kernel(int *counter, int expected, long long max_ticks);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
                                     float *g_vmc_in);
@@ -183,6 +184,18 @@ void qrgpu_model_desc_default(qrgpu_model_desc *d)
     d->kp_foot = 500.f; d->kd_foot = 10.f; d->weight_fb = 0.1f; d->weight_fr = 1.f; d->mu = 0.4f;
 }
 
+// The side stream carries the planned list launch -- a few workgroups that each need a whole CU -- beside the main pass.  Highest priority,
+// so that they are placed while the CUs are still empty: at default priority the main pass's workgroups fill every CU first and a listed
+// robot starts 80-160 us late, which is then the end of the launch (QRGPU_SIDE_PRIORITY=0 for the default priority).
+static hipError_t create_side_stream(hipStream_t *s)
+{
+    static const int want = [] { const char *e = getenv("QRGPU_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
+    int least = 0, greatest = 0;
+    if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
 {
     if (!out || max_batch <= 0 || horizon_max <= 0 || horizon_max > QRGPU_MAX_HORIZON) return QRGPU_ERR_BAD_ARG;
@@ -208,7 +221,8 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 4)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
         hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_pre_hint, c->h_pre_count, 0) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_started, sizeof(int)) != hipSuccess || hipMemset(c->d_started, 0, sizeof(int)) != hipSuccess ||
+        create_side_stream(&c->side_stream) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
@@ -241,6 +255,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
+    if (c->d_started) hipFree(c->d_started);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
 }
@@ -384,6 +399,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.skip = nullptr;
     P.big_nls = c->big_nls;
     P.lds_main = P.lds_bytes;
+    P.started = nullptr;
     if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
         HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 4 * sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
@@ -422,6 +438,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         MpcLaunch L = P;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = c->lds_per_cu;
+        static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
+        const bool gate = gate_on && planned_mode != 1;
+        L.started = gate ? c->d_started : nullptr;
+        int gate_expect = 0;
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
         hipStream_t ls = planned_mode == 1 ? c->stream : c->side_stream;
@@ -445,10 +465,15 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             }
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel((const void *)qr_mpc_kernel<2, true, false, 512>, dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
-        } else
-        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, ls, L, io);
+            gate_expect = g3;
+        } else {
+            L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
+            hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, ls, L, io);
+        }
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
+        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, gate_expect, (long long)3000); HIPCHK(c, hipGetLastError()); }
     }
     {
         TimerScope ts(c, 0);
