@@ -376,7 +376,11 @@ def main():
     # ---- the timed region: K steps split over the draws -------------------------------------------------------------------
     share = [args.steps // D + (1 if d < args.steps % D else 0) for d in range(D)]
     ctx.enable_timing(True)
-    draw_s = [timed(share[d], args.warmup, d) for d in range(D)]
+    draw_s, draw_flags, draw_itmax = [], [], []
+    for d in range(D):
+        draw_s.append(timed(share[d], args.warmup, d))
+        st_d = d_status.cpu().numpy().astype(np.int64)          # (outside the timed region: the last step's status words of this draw)
+        draw_flags.append(int(((st_d & 0xff0000ff) != 0).sum())); draw_itmax.append(int(((st_d >> 8) & 0xffff).max()))
     if world > 1:
         own = d_tau_all[rank]
         if not torch.equal(own, d_tau2[(nstep[0] - 1) & 1]):
@@ -500,6 +504,7 @@ def main():
                        "rank_batches": "every rank draws the same populations (control)" if args.same_seed_ranks else "every rank draws its own populations",
                        "parallelism": "robots sharded over %d GPU(s); qrgpu_allgather_tau (RCCL, context-owned stream) overlapped with the next tick" % world,
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
+                       "status_flags_nonzero_per_draw": draw_flags, "max_active_set_changes_per_draw": draw_itmax,
                        "dispatch": "longest-first from the previous step's per-robot solve time (a prediction: consecutive steps see different batches)",
                        **side},
             "roofline": roof,

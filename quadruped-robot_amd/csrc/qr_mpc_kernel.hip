@@ -43,6 +43,9 @@ namespace qrgpu {
 #ifndef QR_RCP_PIVOT
 #define QR_RCP_PIVOT fast_rcp
 #endif
+#ifndef QR_REFRESH_EVERY
+#define QR_REFRESH_EVERY 100
+#endif
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
 #endif
 #ifndef QR_HESS_VALU
@@ -1182,6 +1185,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         // one optimum, whatever set the solve starts from.
         bool need_rebuild = false;
         int refac = 0;                                    // re-factorisations spent on a failed exit check (at most two)
+        int iter_at_rebuild = 0;                          // (periodic refresh of S^-1, below)
         unsigned char *warm = (P.warm && nls > 0) ? P.warm + (size_t)rid * QR_WARM_STRIDE : nullptr;
         if (warm && warm[QR_WARM_STRIDE - 1] == (unsigned char)h) {
             const unsigned long long cur = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
@@ -1387,6 +1391,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 }
                 break;
             }
+            // S^-1 is kept by bordered updates and downdates; a solve that is still going after a hundred of them (the healthy ones end long
+            // before) gets it rebuilt from the working set as it stands, and again every hundred changes after that: a wandering solve
+            // (1 678 changes seen with the three-limb Hessian at h = 16) is one whose S^-1 has drifted
+            if (iter - iter_at_rebuild >= QR_REFRESH_EVERY && q > 0) { iter_at_rebuild = iter; need_rebuild = true; continue; }
             const int kp = __builtin_amdgcn_readfirstlane(first_lane(bs == smin));
             const int tp = __builtin_amdgcn_readlane(bt, kp);
             double c0, c1, c2;
