@@ -38,10 +38,11 @@ namespace qrgpu {
 
 #define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
 #ifndef QR_MAIN_WAVES_PER_SIMD
-// (fast_rcp1 -- one Newton step, 2.2e-15 relative -- saves 0.7 % of the main pass, but one robot of the stress set at twice the 8d ranges then
-// ran into the iteration cap: the pivots keep the full-accuracy reciprocal)
+// Pivot reciprocals of both sweeps: v_rcp_f64 + one Newton step (2.2e-15 relative, scratch/ubench/rcp.hip) -- 0.7 % of the main pass.  (Before
+// the periodic refresh of S^-1 existed, one robot of the stress set at twice the 8d ranges wandered into the iteration cap with it; with the
+// refresh the stress run is the same with either form: 21 overflow flags at twice the ranges, none inside them, largest count 202 / 204.)
 #ifndef QR_RCP_PIVOT
-#define QR_RCP_PIVOT fast_rcp
+#define QR_RCP_PIVOT fast_rcp1
 #endif
 #ifndef QR_REFRESH_EVERY
 #define QR_REFRESH_EVERY 100
