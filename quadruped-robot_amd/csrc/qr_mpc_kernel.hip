@@ -37,7 +37,6 @@
 namespace qrgpu {
 
 #define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
-#ifndef QR_MAIN_WAVES_PER_SIMD
 // Pivot reciprocals of both sweeps: v_rcp_f64 + one Newton step (2.2e-15 relative, scratch/ubench/rcp.hip) -- 0.7 % of the main pass.  (Before
 // the periodic refresh of S^-1 existed, one robot of the stress set at twice the 8d ranges wandered into the iteration cap with it; with the
 // refresh the stress run is the same with either form: 21 overflow flags at twice the ranges, none inside them, largest count 202 / 204.)
@@ -47,6 +46,7 @@ namespace qrgpu {
 #ifndef QR_REFRESH_EVERY
 #define QR_REFRESH_EVERY 100
 #endif
+#ifndef QR_MAIN_WAVES_PER_SIMD
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
 #endif
 #ifndef QR_HESS_VALU
@@ -1168,9 +1168,17 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         int q = 0, iter = 0;
 #ifdef QR_GI_STAMPS      // sub-phase cycle accounting of wave 0 (build.py: QRGPU_GI_STAMPS=1)
         long long cs_t[6] = {0, 0, 0, 0, 0, 0}, cs_0 = clock64();
+#ifdef QR_GI_STAMPS_FINE  // (the stretch from B3 to the next row's pick in four parts, slots 0-3; the pick in 4, the rest of the change in 5;
+                          //  scratch/diag_change_fine.py.  A stamp waits for the wave's outstanding LDS traffic: ~150 cycles each)
+#define CS_STAMP(i) do { const long long t_ = clock64(); cs_t[(i) == 0 ? 4 : 5] += t_ - cs_0; cs_0 = t_; } while (0)
+#define CS_FINE(i) do { const long long t_ = clock64(); cs_t[i] += t_ - cs_0; cs_0 = t_; } while (0)
+#else
 #define CS_STAMP(i) do { const long long t_ = clock64(); cs_t[i] += t_ - cs_0; cs_0 = t_; } while (0)
+#define CS_FINE(i) do { } while (0)
+#endif
 #else
 #define CS_STAMP(i) do { } while (0)
+#define CS_FINE(i) do { } while (0)
 #endif
         unsigned amask = 0, xmask = 0;
         unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
@@ -1361,6 +1369,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (done) break;
                 if (need_rebuild) continue;               // (a block drop: solve on what is left)
             }
+            CS_FINE(1);
             double bs = INF; int bt = 0;
             {
                 const double s[6] = {im * x0 + x2, -im * x0 + x2, im * x1 + x2, -im * x1 + x2, x2, fmaxk - x2};
@@ -1368,7 +1377,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
                 for (int t = 0; t < 6; ++t) { const bool take = !((blocked >> t) & 1u) && s[t] < bs; bs = take ? s[t] : bs; bt = take ? t : bt; }
             }
+            CS_FINE(2);
             const double smin = wave_min_d(bs);
+            CS_FINE(3);
             if (!(smin < -tol)) {
                 double be = 0.0;                          // excluded rows hold, active rows are tight (see the four-wave loop below)
                 if (own && (xmask | amask)) {
@@ -1484,6 +1495,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 uq -= t * rq;
                 if (hi) uq2 -= t * rq2;
                 up += t;
+                CS_FINE(0);
                 if (P.flops) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 21.0 * (double)nls + 12.0 * (double)q;
                 if (full) {
                     if (fastz) {
