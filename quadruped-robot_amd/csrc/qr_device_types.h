@@ -66,6 +66,7 @@ struct MpcLaunch {
     int *pre_list;
     unsigned char *skip;
     int big_nls;                // 0 = no class rule
+    int big_margin;             // a solve that ends within this many rows of what the main pass's LDS holds puts its robot on the planned list
     int lds_main;               // the main pass's LDS allotment (bytes), for the `big` decision of a solve that runs in a list launch
     // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
     const int *lpt_cost_in;

@@ -1580,7 +1580,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 int qcm = 0;
                 if (remm > 0) { qcm = (int)((__builtin_sqrt(8.0 * (double)remm + 1.0) - 1.0) * 0.5); while (tri(qcm) > remm) --qcm; }
                 if (qcm > 64) qcm = 64;
-                big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + 6 >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
+                big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
             }
             P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8);
         }

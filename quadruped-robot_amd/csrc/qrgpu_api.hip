@@ -398,6 +398,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.pre_hint = planned ? c->d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
+    { static const int bm = [] { const char *e = getenv("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = bm; }
     P.lds_main = P.lds_bytes;
     P.started = nullptr;
     if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
@@ -426,7 +427,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
     // the planned launch (and its two stream events) is only worth issuing when the last plan listed somebody: the list's length comes back
     // through pinned memory without a sync.  A stale zero just means the main pass solves everybody (P.skip stays null): consistent either way.
-    if (planned && c->plan_n != n) { c->h_pre_count[0] = c->h_pre_count[1] = 0; }
+    if (planned && c->plan_n != n) { c->h_pre_count[0] = c->h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); c->plan_sync_left = ps; }
     const bool have_plan = planned && c->plan_n == n && c->h_pre_count[c->rescue_parity] > 0;
     // QRGPU_PLANNED_MODE: 0 = planned list on the context's side stream (fork / join events), 1 = planned list and main pass on the SAME
     // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
@@ -457,7 +458,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
             // hands a longer list's tail to the trailing launch)
             L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
-            int g3 = c->h_pre_count[c->rescue_parity];
+            static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
+            int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
             g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
             if (c->configured_rescue[1] < c->lds_per_cu) {
                 HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<2, true, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
@@ -504,6 +506,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         c->rescue_parity ^= 1;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
+    // The list's length reaches the host through pinned memory, unsynchronised: a caller that queues ticks faster than the GPU runs them
+    // decides on a count several ticks old -- and on nothing at all for the first ticks of a new batch, whose listed robots then go through
+    // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
+    // The first two calls after a history reset (one per parity) therefore end with a stream sync.
+    if (planned && c->plan_sync_left > 0) { --c->plan_sync_left; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     else if (lpt) {
         hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
         HIPCHK(c, hipGetLastError());
@@ -997,6 +1004,17 @@ int qrgpu_enable_timing(qrgpu_ctx *c, int on)
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->timing = on != 0;
     c->ev_used[0] = c->ev_used[1] = 0;
+    if (on) {
+        // the event pairs of the first launches are made here, not inside the caller's timed steps (TimerScope still grows the pool beyond them)
+        HIPCHK(c, hipSetDevice(c->device));
+        for (int k = 0; k < 2; ++k)
+            while (c->ev[k].size() < 512) {
+                hipEvent_t a, b;
+                HIPCHK(c, hipEventCreate(&a));
+                HIPCHK(c, hipEventCreate(&b));
+                c->ev[k].push_back({a, b});
+            }
+    }
     return QRGPU_OK;
 }
 

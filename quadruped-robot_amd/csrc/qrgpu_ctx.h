@@ -42,6 +42,7 @@ struct qrgpu_ctx {
     int *h_pre_count = nullptr;   // pinned: the planned list's length as of the last call (copied back without a sync; stale by a call or two at worst)
     bool planned = true;
     int big_nls = 0;
+    int plan_sync_left = 0;        // calls after a history reset that still end with a stream sync (so that the host sees the first plans' lengths)
     int *d_started = nullptr;                 // workgroups of the planned list launch that have started (qr_gate_kernel)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
