@@ -49,6 +49,17 @@ namespace qrgpu {
 #ifndef QR_MAIN_WAVES_PER_SIMD
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
 #endif
+// The executed-arithmetic counters (qrgpu_enable_flop_count) cost the main pass four live fp64 accumulators and 2.4 % of its time even when the
+// pointer is null (0.2242 -> 0.2189 ms with them compiled out), so the kernels exist twice: this file compiles them without the counters,
+// qr_mpc_kernel_fl.hip includes it with QR_FLOPS_BUILD and gets the same kernels under the name qr_mpc_kernel_fl with the counters in;
+// the host launches those only while counting is switched on.
+#ifdef QR_FLOPS_BUILD
+#define qr_mpc_kernel qr_mpc_kernel_fl
+#define mpc_solve_robot mpc_solve_robot_fl
+#define QR_PFLOPS P.flops
+#else
+#define QR_PFLOPS ((double *)nullptr)
+#endif
 #ifndef QR_HESS_VALU
 #define QR_HESS_VALU 0           // 1: K4 as hand-written fmaf chains on the VALU (round 1), kept for A/B runs; 0: v_mfma_f32_16x16x4_f32
 #endif
@@ -292,11 +303,13 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
 }
+#ifndef QR_FLOPS_BUILD
 __global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
 {
     __shared__ int hist[2048];
     lpt_order_chunk(blockIdx.x, n, cost, order, hist);
 }
+#endif
 
 // Global-memory arguments of one MPC launch (SoA, [field][robot]; see include/qrgpu.h)
 struct MpcIO {
@@ -517,7 +530,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     const float dtm = dt * minv;
     const float two_alpha = 2.f * C.alpha;
 
-    // Executed-arithmetic accounting (P.flops, off unless asked for): what the workgroup actually computes, by formula from the sizes the
+    // Executed-arithmetic accounting (QR_PFLOPS, off unless asked for): what the workgroup actually computes, by formula from the sizes the
     // solve sees -- [0] fp32 vector flops (operand generation, gradient), [1] fp32 matrix flops issued (2 * 16 * 16 * 4 per
     // v_mfma_f32_16x16x4_f32), [2] fp64 flops of the sweep and x0, [3] fp64 flops of the active set (rebuilds included).  mul and add count 1
     // each, fma 2.  Wave 0 keeps the sums (uniform) and stores them at the end.
@@ -857,7 +870,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) return;
     if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
-    if (P.flops) {
+    if (QR_PFLOPS) {
         const int NTf = (ns + 15) >> 4;
         double steps = 0.0;                              // tile x horizon-step pairs of the lower tile triangle
         for (int Rf = 0; Rf < NTf; ++Rf) steps += (double)(Rf + 1) * (double)(h - (sLs[(16 * Rf * 21846) >> 16] >> 2));
@@ -1253,7 +1266,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const long long tr0 = clock64();
 #endif
                 const bool ok = rebuild(q);
-                if (P.flops) fl_as += 17.5 * (double)q * (double)q + 1.5 * (double)q * (double)q * (double)q + 15.0 * (double)q * (double)nls;   // S, sweep of S, W_A
+                if (QR_PFLOPS) fl_as += 17.5 * (double)q * (double)q + 1.5 * (double)q * (double)q * (double)q + 15.0 * (double)q * (double)nls;   // S, sweep of S, W_A
 #if defined(QR_DIAG_REFAC)
                 if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 8] += ok ? 1 : 100; io.dbgT[(size_t)rid * 16 + 10] = clock64() - tr0; io.dbgT[(size_t)rid * 16 + 11] = q; }
                 const long long tr1 = clock64();
@@ -1286,7 +1299,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     double rq, rq2 = 0.0;
                     { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                     if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
-                    if (P.flops) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 8.0 * (double)q;
+                    if (QR_PFLOPS) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 8.0 * (double)q;
                     // u = -r; the most negative multiplier beyond rounding leaves
                     const double umax = -wave_min_d(hi ? (rq < rq2 ? rq : rq2) : rq);          // max u (>= 0 when any row is held properly)
                     const double worst = -wave_min_d(hi ? (-rq < -rq2 ? -rq : -rq2) : -rq);    // max r = -min u
@@ -1496,7 +1509,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (hi) uq2 -= t * rq2;
                 up += t;
                 CS_FINE(0);
-                if (P.flops) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 21.0 * (double)nls + 12.0 * (double)q;
+                if (QR_PFLOPS) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 21.0 * (double)nls + 12.0 * (double)q;
                 if (full) {
                     if (fastz) {
                         if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
@@ -1569,7 +1582,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         mpc_outputs(lane, rid, n, xz, R, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
         if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
         if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-        if (lane == 0 && P.flops) { double *fo = P.flops + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
+        if (lane == 0 && QR_PFLOPS) { double *fo = QR_PFLOPS + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
         if (lane == 0 && P.cost) {
             const long long c = (clock64() - t_begin) >> 12;
             int big = 0;
@@ -1675,6 +1688,7 @@ template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);  
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
 
+#ifndef QR_FLOPS_BUILD
 // Holds the stream it is launched on until the `expected` workgroups of the planned list launch (side stream) have started, or max_ticks of
 // the 100 MHz clock have passed, whichever comes first; then clears the counter.  A listed robot needs a whole CU: left to the dispatcher, the
 // main pass's thousand workgroups fill every CU first and the listed robot starts 80-160 us late -- which is then the end of the launch.
@@ -1700,5 +1714,7 @@ __global__ void qr_selftest_kernel(double *out)
     out[128 + lane] = (double)fl;
     out[192 + lane] = rd;
 }
+
+#endif
 
 }  // namespace qrgpu

@@ -30,6 +30,14 @@ extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, Mpc
 extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
+// the same kernels with the executed-arithmetic counters compiled in (qr_mpc_kernel_fl.hip)
+template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
+extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<4, false, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<4, true, true, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -48,6 +56,27 @@ __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
                               const float *g_fr, int type_ready, int epilogue);
+}
+
+// MPC kernel variants: 0 = <5, BIG, ., 512> (h <= 16), 1 = <9, BIG, ., 256> (h <= 16, A/B), 2 = <4, ., ., 256> (h <= 11, A/B), 3 = <2, ., ., 512> (h <= 11
+// main pass), 4 = <4, BIG, LIST, 256> (list launches), 5 = <2, BIG, ., 512> (planned list, one robot per workgroup); fl: the counting build
+static const void *mpc_fn(int var, bool fl)
+{
+    switch (var) {
+    case 0: return fl ? (const void *)qr_mpc_kernel_fl<5, true, false, 512> : (const void *)qr_mpc_kernel<5, true, false, 512>;
+    case 1: return fl ? (const void *)qr_mpc_kernel_fl<9, true, false, 256> : (const void *)qr_mpc_kernel<9, true, false, 256>;
+    case 2: return fl ? (const void *)qr_mpc_kernel_fl<4, false, false, 256> : (const void *)qr_mpc_kernel<4, false, false, 256>;
+    case 3: return fl ? (const void *)qr_mpc_kernel_fl<2, false, false, 512> : (const void *)qr_mpc_kernel<2, false, false, 512>;
+    case 4: return fl ? (const void *)qr_mpc_kernel_fl<4, true, true, 256> : (const void *)qr_mpc_kernel<4, true, true, 256>;
+    default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
+    }
+}
+static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
+{
+    if (c->configured_lds[fl][var] >= bytes) return QRGPU_OK;
+    HIPCHK(c, hipFuncSetAttribute(mpc_fn(var, fl), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    c->configured_lds[fl][var] = bytes;
+    return QRGPU_OK;
 }
 
 static int mpc_main_wgs()
@@ -411,17 +440,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
     const int var = small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0);
-    const void *fn = var == 2 ? (const void *)qr_mpc_kernel<4, false, false, 256>
-                   : var == 3 ? (const void *)qr_mpc_kernel<2, false, false, 512>
-                   : var == 0 ? (const void *)qr_mpc_kernel<5, true, false, 512> : (const void *)qr_mpc_kernel<9, true, false, 256>;
-    if (c->configured_lds[var] < P.lds_bytes) {
-        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
-        c->configured_lds[var] = P.lds_bytes;
-    }
-    if (rescue && c->configured_rescue[0] < c->lds_per_cu) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<4, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
-        c->configured_rescue[0] = c->lds_per_cu;
-    }
+    const bool fl = P.flops != nullptr;            // (the kernels with the counters compiled in: only while counting is on)
+    const void *fn = mpc_fn(var, fl);
+    { const int rc_ = mpc_ensure_lds(c, var, fl, P.lds_bytes); if (rc_) return rc_; }
+    if (rescue) { const int rc_ = mpc_ensure_lds(c, 4, fl, c->lds_per_cu); if (rc_) return rc_; }
     MpcIO io;
     io.type_id = d_type; io.g_state = d_state; io.g_traj = d_traj; io.g_gait = d_gait; io.g_q = d_q; io.g_force = d_force; io.g_tau = d_tau;
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
@@ -461,16 +483,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
             int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
             g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
-            if (c->configured_rescue[1] < c->lds_per_cu) {
-                HIPCHK(c, hipFuncSetAttribute((const void *)qr_mpc_kernel<2, true, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_per_cu));
-                c->configured_rescue[1] = c->lds_per_cu;
-            }
+            { const int rc_ = mpc_ensure_lds(c, 5, fl, c->lds_per_cu); if (rc_) return rc_; }
             void *largs[2] = {(void *)&L, (void *)&io};
-            HIPCHK(c, hipExtLaunchKernel((const void *)qr_mpc_kernel<2, true, false, 512>, dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
+            HIPCHK(c, hipExtLaunchKernel(mpc_fn(5, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
-            hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(pgrid), dim3(256), (size_t)L.lds_bytes, ls, L, io);
+            void *largs[2] = {(void *)&L, (void *)&io};
+            HIPCHK(c, hipExtLaunchKernel(mpc_fn(4, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -500,7 +520,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         int rgrid = 64 < n ? 64 : n;
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
-        hipLaunchKernelGGL((qr_mpc_kernel<4, true, true, 256>), dim3(rgrid), dim3(256), (size_t)R.lds_bytes, c->stream, R, io);
+        void *rargs[2] = {(void *)&R, (void *)&io};
+        HIPCHK(c, hipExtLaunchKernel(mpc_fn(4, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, c->stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
         if (planned) c->plan_n = n;        // (the length of the list just planned reaches h_pre_count by itself)
         c->rescue_parity ^= 1;

@@ -29,8 +29,7 @@ struct qrgpu_ctx {
     int *d_st1 = nullptr;
     int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
-    int configured_lds[4] = {0, 0, 0, 0};     // dynamic-LDS limit already set on this context's device, per kernel variant
-    int configured_rescue[2] = {0, 0};
+    int configured_lds[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};     // dynamic-LDS limit already set on this context's device, per kernel variant ([1]: the counting build)
     double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
     int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
     int rescue_parity = 0;
