@@ -53,12 +53,20 @@ namespace qrgpu {
 // pointer is null (0.2242 -> 0.2189 ms with them compiled out), so the kernels exist twice: this file compiles them without the counters,
 // qr_mpc_kernel_fl.hip includes it with QR_FLOPS_BUILD and gets the same kernels under the name qr_mpc_kernel_fl with the counters in;
 // the host launches those only while counting is switched on.
+// The same goes for the inspection outputs (the dense H and g of qrgpu_mpc_assemble_batch, the cycle stamps of qrgpu_debug_cycles): the host
+// picks the instrumented kernels for a launch that asks for any of them.
 #ifdef QR_FLOPS_BUILD
 #define qr_mpc_kernel qr_mpc_kernel_fl
 #define mpc_solve_robot mpc_solve_robot_fl
 #define QR_PFLOPS P.flops
+#define QR_DBGT io.dbgT
+#define QR_DBGH io.dbgH
+#define QR_DBGG io.dbgG
 #else
 #define QR_PFLOPS ((double *)nullptr)
+#define QR_DBGT ((long long *)nullptr)
+#define QR_DBGH ((float *)nullptr)
+#define QR_DBGG ((float *)nullptr)
 #endif
 #ifndef QR_HESS_VALU
 #define QR_HESS_VALU 0           // 1: K4 as hand-written fmaf chains on the VALU (round 1), kept for A/B runs; 0: v_mfma_f32_16x16x4_f32
@@ -363,11 +371,11 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #if defined(QR_TRACE) || defined(QR_DIAG_REFAC)
 #define QR_TS(i) do { } while (0)
 #else
-#define QR_TS(i) do { if (io.dbgT && tid == 0) io.dbgT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
+#define QR_TS(i) do { if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
 #endif
     QR_TS(0);
 #if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
-    if (io.dbgT && tid == 0) io.dbgT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
+    if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
 #endif
     // ---------------- phase 0: inputs ----------------
     if (tid < 28) sSt[tid] = io.g_state[(size_t)tid * n + rid];
@@ -551,7 +559,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             ba[sl] = a; bb[sl] = b;
 #if QR_HESS_VALU
             const Blk Hb = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
-                                      io.dbgH ? io.dbgH + (size_t)rid * NV * NV : nullptr, NV);
+                                      QR_DBGH ? QR_DBGH + (size_t)rid * NV * NV : nullptr, NV);
             // parked in its final M slot: keeps the 18 VGPRs per block out of the build's register budget
             double *dst = Mb + pid * 9;
 #pragma unroll
@@ -577,7 +585,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         const int NT = (ns + 15) >> 4, NTL = tri(NT);
         const int g = lane >> 4, lc = lane & 15;
         const float w2q0 = 2.f * C.weights[g], w2q1 = 2.f * C.weights[4 + g], w2q2 = 2.f * C.weights[8 + g];
-        float *Hd = io.dbgH ? io.dbgH + (size_t)rid * NV * NV : nullptr;
+        float *Hd = QR_DBGH ? QR_DBGH + (size_t)rid * NV * NV : nullptr;
         // lane constants of one side (row tile or column tile): the leg-step behind index e = 16 * tile + lc and its operand recipe
         auto side = [&](int tile, int &ia, float &al0, float &al1, float &k1, float &k2) {
             const int e = 16 * tile + lc;
@@ -700,7 +708,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             }
         }
 #if defined(QR_DIAG_REFAC)
-        if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 4] = clock64() - th0; io.dbgT[(size_t)rid * 16 + 5] = th_loop; io.dbgT[(size_t)rid * 16 + 6] = NTL; }
+        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 4] = clock64() - th0; QR_DBGT[(size_t)rid * 16 + 5] = th_loop; QR_DBGT[(size_t)rid * 16 + 6] = NTL; }
 #endif
     }
 #endif
@@ -725,7 +733,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             acc = __builtin_fmaf(dw, vr[9 + j], acc);
         }
         gl[e] = (double)acc;
-        if (io.dbgG) io.dbgG[(size_t)rid * NV + 3 * ls + j] = acc;
+        if (QR_DBGG) QR_DBGG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
     for (int c = tid; c < 6 * nls; c += NTHR) sPos[c] = -1;
     QR_TS(2);
@@ -852,7 +860,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
 #ifdef QR_SWEEP_STAMPS
         VS_STAMP(3);
-        if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 8] = vs_t[0]; io.dbgT[(size_t)rid * 16 + 9] = vs_t[1]; io.dbgT[(size_t)rid * 16 + 10] = vs_t[2]; io.dbgT[(size_t)rid * 16 + 11] = vs_t[3]; io.dbgT[(size_t)rid * 16 + 12] = 0; }
+        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 8] = vs_t[0]; QR_DBGT[(size_t)rid * 16 + 9] = vs_t[1]; QR_DBGT[(size_t)rid * 16 + 10] = vs_t[2]; QR_DBGT[(size_t)rid * 16 + 11] = vs_t[3]; QR_DBGT[(size_t)rid * 16 + 12] = 0; }
 #endif
         __syncthreads();           // everybody is done with the panels before M overwrites them
 #pragma unroll
@@ -1035,7 +1043,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             }
 #if defined(QR_DIAG_REFAC)
             const long long tb2 = clock64();
-            if (io.dbgT && tid == 0) { io.dbgT[(size_t)rid * 16 + 2] = tb1 - tb0; io.dbgT[(size_t)rid * 16 + 3] = tb2 - tb1; }
+            if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 2] = tb1 - tb0; QR_DBGT[(size_t)rid * 16 + 3] = tb2 - tb1; }
 #endif
             if (ok) {
 #pragma unroll
@@ -1268,7 +1276,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const bool ok = rebuild(q);
                 if (QR_PFLOPS) fl_as += 17.5 * (double)q * (double)q + 1.5 * (double)q * (double)q * (double)q + 15.0 * (double)q * (double)nls;   // S, sweep of S, W_A
 #if defined(QR_DIAG_REFAC)
-                if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 8] += ok ? 1 : 100; io.dbgT[(size_t)rid * 16 + 10] = clock64() - tr0; io.dbgT[(size_t)rid * 16 + 11] = q; }
+                if (QR_DBGT && lane == 0) { QR_DBGT[(size_t)rid * 16 + 8] += ok ? 1 : 100; QR_DBGT[(size_t)rid * 16 + 10] = clock64() - tr0; QR_DBGT[(size_t)rid * 16 + 11] = q; }
                 const long long tr1 = clock64();
 #endif
                 if (!ok) {
@@ -1338,7 +1346,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                             for (int t = 0; t < 6; ++t) { const int ps = sPos[6 * kme + t]; if (ps >= 0) { amask |= 1u << t; posk |= (unsigned long long)(ps & 0xff) << (8 * t); } }
                         }
 #if defined(QR_DIAG_REFAC)
-                        if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 13] += nneg;
+                        if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 13] += nneg;
 #endif
                         need_rebuild = true;
                         break;
@@ -1352,7 +1360,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                         break;
                     }
 #if defined(QR_DIAG_REFAC)
-                    if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 13] += 1;
+                    if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 13] += 1;
 #endif
                     // position lpos leaves: the same bookkeeping as a drop of the loop below (the workers downdate S^-1 between D1 and D3)
                     {
@@ -1377,7 +1385,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     if (q == 0) { x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2]; uq = 0.0; uq2 = 0.0; break; }
                 }
 #if defined(QR_DIAG_REFAC)
-                if (io.dbgT && lane == 0) io.dbgT[(size_t)rid * 16 + 9] += clock64() - tr1;
+                if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 9] += clock64() - tr1;
 #endif
                 if (done) break;
                 if (need_rebuild) continue;               // (a block drop: solve on what is left)
@@ -1405,7 +1413,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 }
                 const double bemin = wave_min_d(be);
 #if defined(QR_DIAG_REFAC)
-                if (io.dbgT && lane == 0) { io.dbgT[(size_t)rid * 16 + 12] = __double_as_longlong(bemin); }
+                if (QR_DBGT && lane == 0) { QR_DBGT[(size_t)rid * 16 + 12] = __double_as_longlong(bemin); }
 #endif
                 if (bemin < -1e-4) {
                     // S^-1 has drifted (hundreds of bordered updates / downdates) or a row was set aside wrongly: rebuild it from the working
@@ -1486,12 +1494,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const bool degenerate = !(t < INF);
                 const bool full = !degenerate && indep && t == t2;
 #if defined(QR_DIAG_REFAC)
-                if (io.dbgT && lane == 0 && full) { const double ratio = zc / delta; double *mr = (double *)&io.dbgT[(size_t)rid * 16 + 15]; if (iter <= 2 || ratio < *mr) *mr = ratio; }
+                if (QR_DBGT && lane == 0 && full) { const double ratio = zc / delta; double *mr = (double *)&QR_DBGT[(size_t)rid * 16 + 15]; if (iter <= 2 || ratio < *mr) *mr = ratio; }
 #endif
                 const bool over = full && q >= qcap;
                 const int flags = (degenerate || over) ? 0 : (full ? F_FULL : F_DROP);
 #ifdef QR_TRACE
-                if (io.dbgT && lane == 0 && iter <= 7) { io.dbgT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); io.dbgT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
+                if (QR_DBGT && lane == 0 && iter <= 7) { QR_DBGT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); QR_DBGT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
 #endif
                 if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
                 CS_STAMP(4);
@@ -1599,12 +1607,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
         QR_TS(6);
 #if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
-        if (lane == 0 && io.dbgT) io.dbgT[(size_t)rid * 16 + 13] = wall_clock64();
+        if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 13] = wall_clock64();
 #endif
 #ifndef QR_TRACE
-        if (lane == 0 && io.dbgT) { io.dbgT[(size_t)rid * 16 + 7] = ns; io.dbgT[(size_t)rid * 16 + 14] = q; }
+        if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; QR_DBGT[(size_t)rid * 16 + 14] = q; }
 #ifdef QR_GI_STAMPS
-        if (lane == 0 && io.dbgT) for (int i = 0; i < 6; ++i) io.dbgT[(size_t)rid * 16 + 8 + i] = cs_t[i];
+        if (lane == 0 && QR_DBGT) for (int i = 0; i < 6; ++i) QR_DBGT[(size_t)rid * 16 + 8 + i] = cs_t[i];
 #endif
 #endif
     }

@@ -440,7 +440,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
     const int var = small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0);
-    const bool fl = P.flops != nullptr;            // (the kernels with the counters compiled in: only while counting is on)
+    // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
+    const bool fl = P.flops != nullptr || dH != nullptr || dG != nullptr || c->d_dbg_cycles != nullptr;
     const void *fn = mpc_fn(var, fl);
     { const int rc_ = mpc_ensure_lds(c, var, fl, P.lds_bytes); if (rc_) return rc_; }
     if (rescue) { const int rc_ = mpc_ensure_lds(c, 4, fl, c->lds_per_cu); if (rc_) return rc_; }
