@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libqrgpu.so")
-SOURCES = ["qr_mpc_kernel.hip", "qr_mpc_kernel_fl.hip", "qr_wbc_kernel.hip", "qr_frontend_kernel.hip", "qr_vmc_kernel.hip", "qr_estimator_kernel.hip", "qrgpu_api.hip", "qrgpu_comm.hip"]
+SOURCES = ["qr_mpc_kernel.hip", "qr_mpc_kernel_fl.hip", "qr_wbc_kernel.hip", "qr_wbc_kernel_dbg.hip", "qr_frontend_kernel.hip", "qr_vmc_kernel.hip", "qr_estimator_kernel.hip", "qrgpu_api.hip", "qrgpu_comm.hip"]
 # The fp32 MPC assembly must execute exactly the written fmaf chain (bit-identical to the CPU oracle, see
 # DESIGN.md "bit-exact assembly"): those functions carry `#pragma clang fp contract(off)`; everything else
 # (fp64 sweep / active set / WBC) is free to fuse multiply-adds.  NB plain -ffp-contract=fast would IGNORE those pragmas.

@@ -597,6 +597,9 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
 //   wave 0: Jacobians, composite inertias, H, G -> A^-1                    -> prioritized acceleration recursion -> relaxation QP -> torques
 //   wave 1: velocities, foot kinematics, Jcdqd, Coriolis -> the task set   -> K12 kinematic projection (when asked for) -> q_des, qd_des
 // One workgroup barrier after the load, one where the two meet; everything else is wave-local (wsync).
+#ifdef QR_WBC_DBG_BUILD
+#define qr_wbc_kernel qr_wbc_kernel_dbg
+#endif
 __global__ __launch_bounds__(128, 2)
 void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restrict__ type_id,
                    const float *__restrict__ g_state, const float *__restrict__ g_cmd, float *__restrict__ g_prev,
@@ -605,6 +608,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */,
                    int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */)
 {
+#ifndef QR_WBC_DBG_BUILD      // (the timed path's kernel carries neither the inspection outputs nor the cycle stamps: 2.5 % of its time; qr_wbc_kernel_dbg.hip
+    dbgT = nullptr; g_dbg = nullptr;      //  compiles this file once more with them in, as qr_wbc_kernel_dbg, for the launches that ask for either)
+#endif
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
 #define QW_TS1(i) do { if (dbgT && threadIdx.x == 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);

@@ -56,6 +56,9 @@ __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
                               const float *g_fr, int type_ready, int epilogue);
+__global__ void qr_wbc_kernel_dbg(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
+                                  float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
+                                  const float *g_fr, int type_ready, int epilogue);
 }
 
 // MPC kernel variants: 0 = <5, BIG, ., 512> (h <= 16), 1 = <9, BIG, ., 256> (h <= 16, A/B), 2 = <4, ., ., 256> (h <= 11, A/B), 3 = <2, ., ., 512> (h <= 11
@@ -552,7 +555,8 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     if (rc) return rc;
     {
         TimerScope ts(c, 1);
-        hipLaunchKernelGGL(qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
+        // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
+        hipLaunchKernelGGL((d_dbg || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
                            ready_mask(c->wbc_ready), epilogue);
     }
