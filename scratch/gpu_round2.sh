@@ -14,6 +14,7 @@ echo bench done
 timeout -k 10 600 python bench.py --mixed --horizon 16 > $OUT/bench_config4_f32.json 2> $OUT/bench_config4_f32.err
 timeout -k 10 600 python bench.py --mixed --horizon 16 --hessian bf16x3 > $OUT/bench_config4_bf16x3.json 2> $OUT/bench_config4_bf16x3.err
 timeout -k 10 600 python bench.py --robots 8192 --no-side > $OUT/bench_8192.json 2> $OUT/bench_8192.err
+timeout -k 10 600 python bench.py --robots 256 --mode mpc --no-side > $OUT/bench_config1.json 2> $OUT/bench_config1.err
 echo side benches done
 B="python3 bench.py --steps 96 --warmup 4 --no-cpu-baseline --no-side"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- $B > $OUT/prof_bench.json 2> $OUT/prof.err

@@ -22,7 +22,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
     d[d["k"] == "mpc_main"].head(40).drop(columns=["k"]).to_csv("profiles/%s_pmc_%s_sample.csv" % (pre, c0), index=False)
 json.dump(summ, open("profiles/%s_pmc_summary.json" % pre, "w"), indent=1)
 for a, b in (("bench.json", "bench.json"), ("bench_config4_f32.json", "bench_config4_f32.json"), ("bench_config4_bf16x3.json", "bench_config4_bf16x3.json"),
-             ("bench_8192.json", "bench_8192_robots.json"), ("prof_bench.json", "bench_under_rocprofv3.json"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log")):
+             ("bench_8192.json", "bench_8192_robots.json"), ("bench_config1.json", "bench_config1_256_mpc_only.json"), ("prof_bench.json", "bench_under_rocprofv3.json"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log")):
     p = os.path.join(src, a)
     if os.path.exists(p): shutil.copy(p, "profiles/%s_%s" % (pre, b))
 st = pd.read_csv(ks)
