@@ -531,16 +531,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         c->rescue_parity ^= 1;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
-    // The list's length reaches the host through pinned memory, unsynchronised: a caller that queues ticks faster than the GPU runs them
-    // decides on a count several ticks old -- and on nothing at all for the first ticks of a new batch, whose listed robots then go through
-    // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
-    // The first two calls after a history reset (one per parity) therefore end with a stream sync.
-    if (planned && c->plan_sync_left > 0) { --c->plan_sync_left; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     else if (lpt) {
         hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
         HIPCHK(c, hipGetLastError());
         c->lpt_n = n;
     }
+    // The list's length reaches the host through pinned memory, unsynchronised: a caller that queues ticks faster than the GPU runs them
+    // decides on a count several ticks old -- and on nothing at all for the first ticks of a new batch, whose listed robots then go through
+    // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
+    // The first two calls after a history reset (one per parity) therefore end with a stream sync.
+    if (planned && c->plan_sync_left > 0) { --c->plan_sync_left; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     return QRGPU_OK;
 }
 
