@@ -362,11 +362,13 @@ def main():
         for _ in range(warmup):
             step()
         fence()
+        if cur.get("ktime"): ctx.enable_timing(cur["ktime"])
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         el = time.perf_counter() - t0
+        if cur.get("ktime"): ctx.enable_timing(-1)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -375,8 +377,13 @@ def main():
 
     # ---- the timed region: K steps split over the draws -------------------------------------------------------------------
     share = [args.steps // D + (1 if d < args.steps % D else 0) for d in range(D)]
-    ctx.enable_timing(True)
+    # HIP events around the two kernels of every 4th step (on the context's stream).  Around every step they cost 17 us of a 0.29 ms step
+    # (3.50 against 3.72 M ticks/s with none: QRGPU_BENCH_KERNEL_TIMING=0 / 1 / N for the A/B); every 4th keeps that under 1.5 %
+    # -- and only around timed steps (the warm-up steps of a draw start cold)
+    ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "4" if args.steps >= 40 else "2"))
+    ctx.enable_timing(0)
     draw_s, draw_flags, draw_itmax = [], [], []
+    cur["ktime"] = ktime
     for d in range(D):
         draw_s.append(timed(share[d], args.warmup, d))
         st_d = d_status.cpu().numpy().astype(np.int64)          # (outside the timed region: the last step's status words of this draw)
@@ -387,7 +394,9 @@ def main():
             raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
     mpc_ms, mpc_cnt = ctx.get_timing(0)
     wbc_ms, wbc_cnt = ctx.get_timing(1)
+    if not mpc_cnt and not wbc_cnt: mpc_ms = wbc_ms = float("nan")            # (QRGPU_BENCH_KERNEL_TIMING=0)
     ctx.enable_timing(False)
+    cur["ktime"] = 0
     status = d_status.cpu().numpy()
     rates = [world * n * share[d] / draw_s[d] for d in range(D)]
     value = float(np.median(rates))
@@ -486,6 +495,7 @@ def main():
                                     "what": "SURVEY.md 8(d)'s dense count (12h x 13h x 12h GEMM, n^3/3 factorisation, 4 n^2 per change) over the same kernel time: "
                                             "a yardstick against that accounting, not work the kernel does (swing variables are eliminated, zero terms skipped)"},
                 "traffic": None, "kernel_ms": dom_ms, "kernel_launches": mpc_cnt, "other_kernel_ms": wbc_ms,
+                "kernel_ms_is": "mean over the launches bracketed by HIP events on the launching stream: every %d-th timed step" % ktime,
                 "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         what = "full MPC+WBC tick (K1-K14: kinematic projection on, motor tail on)"
         out = {

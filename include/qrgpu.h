@@ -428,7 +428,10 @@ int qrgpu_mpc_flop_counts(qrgpu_ctx *ctx, double out[4]);
 /* ---- plumbing ------------------------------------------------------------------ */
 int  qrgpu_sync(qrgpu_ctx *ctx);                       /* hipStreamSynchronize on the context stream */
 /* Mean device time (ms) of the kernels launched by the last `calls` batched calls,
- * measured with hipEvents on the context stream; kernel: 0 = MPC, 1 = WBC. */
+ * measured with hipEvents on the context stream; kernel: 0 = MPC, 1 = WBC.
+ * on = 0: off; 1: events around every launch; N > 1: around every N-th launch of a kernel (an event
+ * pair costs a 0.3 ms tick about 4 us per kernel; the mean is over the bracketed launches);
+ * -1: pause (the next on > 0 carries on with what was measured so far; on = 0 forgets it). */
 int  qrgpu_enable_timing(qrgpu_ctx *ctx, int on);
 int  qrgpu_get_timing(qrgpu_ctx *ctx, int kernel, double *mean_ms, int *count);
 void *qrgpu_malloc(qrgpu_ctx *ctx, unsigned long long bytes);   /* hipMalloc on the context device */

@@ -105,6 +105,7 @@ struct TimerScope {
     qrgpu_ctx *c; int k; bool on;
     TimerScope(qrgpu_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->timing)
     {
+        if (on && ctx->timing_every > 1 && (ctx->ev_calls[kernel]++ % (unsigned)ctx->timing_every) != 0) on = false;
         if (!on) return;
         if (c->ev_used[k] == c->ev[k].size()) {
             hipEvent_t a, b;
@@ -1028,8 +1029,15 @@ int qrgpu_sync(qrgpu_ctx *c)
 int qrgpu_enable_timing(qrgpu_ctx *c, int on)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
+    if (on < 0) { c->timing = false; c->timing_paused = true; return QRGPU_OK; }     // pause: what was measured so far is kept
+    const bool resume = on > 0 && c->timing_paused;
     c->timing = on != 0;
-    c->ev_used[0] = c->ev_used[1] = 0;
+    c->timing_paused = false;
+    c->timing_every = on > 1 ? on : 1;
+    if (!resume) {
+        c->ev_calls[0] = c->ev_calls[1] = 0;
+        c->ev_used[0] = c->ev_used[1] = 0;
+    }
     if (on) {
         // the event pairs of the first launches are made here, not inside the caller's timed steps (TimerScope still grows the pool beyond them)
         HIPCHK(c, hipSetDevice(c->device));

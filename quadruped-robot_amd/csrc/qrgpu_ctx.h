@@ -71,6 +71,9 @@ struct qrgpu_ctx {
     bool ev_gather_pending[2] = {false, false};
     // timing
     bool timing = false;
+    bool timing_paused = false;
+    int timing_every = 1;          // events bracket every timing_every-th launch of a kernel (qrgpu_enable_timing(ctx, N))
+    unsigned ev_calls[2] = {0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
     size_t ev_used[2] = {0, 0};
 };

@@ -465,7 +465,8 @@ class Context:
         self._chk(self._lib.qrgpu_comm_sync(self._h))
 
     def enable_timing(self, on=True):
-        self._chk(self._lib.qrgpu_enable_timing(self._h, 1 if on else 0))
+        """False: off; True: HIP events around every kernel launch; an int N > 1: around every N-th launch of a kernel; -1: pause."""
+        self._chk(self._lib.qrgpu_enable_timing(self._h, int(on) if on is not True else 1))
 
     def get_timing(self, kernel):
         ms = C.c_double(0); cnt = C.c_int(0)

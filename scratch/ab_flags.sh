@@ -12,8 +12,7 @@ print('flags [$f]: %.3f M, mpc %.4f ms, wbc %.4f ms' % (d['value'] / 1e6, d['roo
   done
 done <<'F'
 
--mllvm -amdgpu-enable-max-ilp-scheduling-strategy
--mllvm -amdgpu-schedule-relaxed-occupancy=true
--mllvm -amdgpu-schedule-metric-bias=100
--mllvm -amdgpu-use-aa-in-codegen=true
+-mllvm -amdgpu-sched-strategy=max-ilp
+-mllvm -amdgpu-sched-strategy=iterative-ilp
+-mllvm -amdgpu-sched-strategy=max-memory-clause
 F
