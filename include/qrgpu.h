@@ -156,7 +156,10 @@ int  qrgpu_set_warm_start(qrgpu_ctx *ctx, int on);
  * rows of the main pass's LDS allotment -- is solved in the NEXT call with the same n by a list launch of its own (whole CU's LDS, 96
  * working-set positions), issued at the start of the call on a second stream of the context beside the main launch, which skips it: the
  * batch no longer waits for a re-solve after the main launch.  big_nls > 0 additionally sends every robot with at least that many stance
- * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling only: which launch solves a robot does not change its result. */
+ * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling only: which launch solves a robot does not change its result.
+ * The host learns the list's length through pinned memory without a sync; so that a caller which queues calls faster than the GPU runs
+ * them still gets its first plans, the first two batched calls after the history was reset (a new n, qrgpu_set_lpt_schedule) end with a
+ * hipStreamSynchronize on the context's stream.  Every later call stays asynchronous. */
 int  qrgpu_set_planned_list(qrgpu_ctx *ctx, int on, int big_nls);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
