@@ -8,7 +8,7 @@ import gpu_helpers as G
 pkg = load_pkg(); pkg._build.build()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ctx = pkg.Context(0, max(n, 4096), 16)
-h = 10
+h = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 G.setup_a1(ctx, pkg, h)
 lib = ctx._lib
 lib.qrgpu_debug_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -30,7 +30,7 @@ for lpt in (True, False):
     tot = (t6 - t0).sum()
     ts = t0.min() + (np.arange(24) + 0.5) / 24 * span
     inflight = [(int(((t0 <= t) & (t6 > t)).sum())) for t in ts]
-    print("lpt %s: robots %d, span %.1f us, mean solve %.1f us, max solve %.1f us, average robots in flight %.0f (512 slots), in flight over time: %s" % (
+    print("lpt %s: robots %d, span %.1f us, mean solve %.1f us, max solve %.1f us, average robots in flight %.0f (512 slots at h <= 11, 256 at h = 16), in flight over time: %s" % (
         lpt, good.sum(), span / 100, (t6 - t0).mean() / 100, (t6 - t0).max() / 100, tot / span, inflight))
     order = np.argsort(t0)
     print("   start times (us) of robots 0, 256, 511, 512, 600, 768, 1023 in start order:", [round((t0[order[k]] - t0.min()) / 100, 1) for k in (0, 256, 511, 512, 600, 768, min(1023, len(order) - 1))])
