@@ -278,6 +278,30 @@ def test_dispatch_order_does_not_change_results(gpu_ctx, pkg):
     assert np.array_equal(third["force"], ref2["force"]) and np.array_equal(third["status"], ref2["status"])
 
 
+def test_instrumented_kernels_give_the_same_bits(pkg):
+    """libqrgpu.so holds the MPC (and WBC) kernels twice, compiled from one source: lean for the timed path, instrumented (executed-arithmetic
+    counters, inspection stores, cycle stamps) for the calls that ask for those.  Same robots, same history: the two must agree bit for bit,
+    here through the full tick, h = 10 (main pass + list launches) and h = 16, and the counters must have counted."""
+    for h, kind in ((10, "a1"), (16, "a1")):
+        n = 256
+        outs = []
+        for counted in (False, True):
+            ctx = pkg.Context(0, 1024, 16)            # a context of its own: the same (empty) history on both sides
+            G.setup_a1(ctx, pkg, h)
+            ctx.enable_flop_count(counted)
+            seq = pkg.make_batch_sequence(n, h, kind, seed=0x77, steps=3)
+            for b in seq:
+                o = G.run_tick(ctx, pkg, b, want_qdes=True)
+            outs.append(o)
+            if counted:
+                fl = ctx.mpc_flop_counts()
+                assert fl["fp64_sweep"] > 0 and fl["fp32_matrix"] > 0 and fl["fp64_active_set"] > 0
+            del ctx
+        a, b_ = outs
+        for k in ("tau", "status", "qdes"):
+            assert np.array_equal(a[k], b_[k]), (h, k)
+
+
 def test_warm_start_over_a_coherent_sequence(gpu_ctx, pkg, oracle):
     """Warm start (default on): a robot slot's solve starts from the working set its previous solve ended with, realigned to the scrolling
     contact table.  Over a temporally coherent sequence the answers must be those of a cold start (one optimum; 1e-7 of the force scale
