@@ -382,6 +382,8 @@ def main():
     # -- and only around timed steps (the warm-up steps of a draw start cold)
     ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "4" if args.steps >= 40 else "2"))
     ctx.enable_timing(0)
+    if ktime:
+        ctx.enable_timing(ktime); ctx.enable_timing(-1)        # the event pool is made here, paused: nothing of it inside a draw's barrier-to-barrier region
     draw_s, draw_flags, draw_itmax = [], [], []
     cur["ktime"] = ktime
     for d in range(D):
