@@ -377,10 +377,11 @@ def main():
 
     # ---- the timed region: K steps split over the draws -------------------------------------------------------------------
     share = [args.steps // D + (1 if d < args.steps % D else 0) for d in range(D)]
-    # HIP events around the two kernels of every 4th step (on the context's stream).  Around every step they cost 17 us of a 0.29 ms step
-    # (3.50 against 3.72 M ticks/s with none: QRGPU_BENCH_KERNEL_TIMING=0 / 1 / N for the A/B); every 4th keeps that under 1.5 %
+    # HIP events around the two kernels of every 8th step (every 4th / 2nd in shorter runs; on the context's stream).  Around every step they
+    # cost 17 us of a 0.29 ms step (3.50 against 3.73 M ticks/s with none: QRGPU_BENCH_KERNEL_TIMING=0 / 1 / N for the A/B; every 4th 3.65, every
+    # 8th 3.69 M)
     # -- and only around timed steps (the warm-up steps of a draw start cold)
-    ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "4" if args.steps >= 40 else "2"))
+    ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "8" if args.steps >= 160 else "4" if args.steps >= 40 else "2"))
     ctx.enable_timing(0)
     if ktime:
         ctx.enable_timing(ktime); ctx.enable_timing(-1)        # the event pool is made here, paused: nothing of it inside a draw's barrier-to-barrier region
