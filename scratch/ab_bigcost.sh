@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measurement: the QRGPU_BIG_COST switch it drives was removed again with the experiment -- DESIGN.md 8)
 # planned list extended to last tick's longest solves: QRGPU_BIG_COST in 4096-cycle ticks (0 = off)
 mkdir -p gpurun_out/ab_bigcost
 for bc in 0 70 62 56 50; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measurement: needs scratch/patches/r02_block_downdate.patch applied -- DESIGN.md 8)
 # block downdate (a block drop followed by a sweep of S^-1 over the leaving rows) against the from-scratch solve of what stays
 mkdir -p gpurun_out/ab_downdate
 for nd in 1 0 1 0; do
