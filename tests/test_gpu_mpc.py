@@ -278,6 +278,35 @@ def test_dispatch_order_does_not_change_results(gpu_ctx, pkg):
     assert np.array_equal(third["force"], ref2["force"]) and np.array_equal(third["status"], ref2["status"])
 
 
+def test_kernel_timing_sampling_and_pause(gpu_ctx, pkg):
+    """qrgpu_enable_timing(ctx, N): HIP events around every N-th launch of a kernel; -1 pauses and a later N carries on; 0 forgets."""
+    h, n = 10, 64
+    G.setup_a1(gpu_ctx, pkg, h)
+    b = pkg.make_batch(n, h, "a1", seed=0x33)
+    try:
+        gpu_ctx.enable_timing(2)
+        for _ in range(4):
+            G.run_tick(gpu_ctx, pkg, b)
+        ms, cnt = gpu_ctx.get_timing(0)
+        assert cnt == 2 and 0.0 < ms < 50.0
+        assert gpu_ctx.get_timing(1)[1] == 2
+        gpu_ctx.enable_timing(-1)
+        for _ in range(2):
+            G.run_tick(gpu_ctx, pkg, b)
+        assert gpu_ctx.get_timing(0)[1] == 2                  # paused: nothing new, nothing lost
+        gpu_ctx.enable_timing(2)
+        for _ in range(2):
+            G.run_tick(gpu_ctx, pkg, b)
+        assert gpu_ctx.get_timing(0)[1] == 3                  # carried on: launches 5 and 6 of the count, one of them bracketed
+        gpu_ctx.enable_timing(True)
+        gpu_ctx.enable_timing(False)
+        gpu_ctx.enable_timing(True)                           # off in between: a fresh start
+        G.run_tick(gpu_ctx, pkg, b)
+        assert gpu_ctx.get_timing(0)[1] == 1
+    finally:
+        gpu_ctx.enable_timing(False)
+
+
 def test_instrumented_kernels_give_the_same_bits(pkg):
     """libqrgpu.so holds the MPC (and WBC) kernels twice, compiled from one source: lean for the timed path, instrumented (executed-arithmetic
     counters, inspection stores, cycle stamps) for the calls that ask for those.  Same robots, same history: the two must agree bit for bit,
