@@ -845,12 +845,17 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                         for (int j = 0; j < 3; ++j)
                             A[sl].m[3 * i + j] = __builtin_fma(-D[3 * i + 2], Cb[3 * j + 2], __builtin_fma(-D[3 * i + 1], Cb[3 * j + 1], __builtin_fma(-D[3 * i], Cb[3 * j], A[sl].m[3 * i + j])));     // three chained fma, no separate mul / sub
                 } else {
-                    // pivot row / column: A_xk = D (x > k), A_kx = D' (x < k), A_kk = -P^-1
-                    const bool piv = (a == k && b == k), tr = (a == k);
+                    // pivot row / column: A_xk = D (x > k), A_kx = D' (x < k): the diagonal as it is, one select per off-diagonal pair ...
+                    const bool tr = (a == k);
+                    A[sl].m[0] = D[0]; A[sl].m[4] = D[4]; A[sl].m[8] = D[8];
+                    A[sl].m[1] = tr ? D[3] : D[1]; A[sl].m[3] = tr ? D[1] : D[3];
+                    A[sl].m[2] = tr ? D[6] : D[2]; A[sl].m[6] = tr ? D[2] : D[6];
+                    A[sl].m[5] = tr ? D[7] : D[5]; A[sl].m[7] = tr ? D[5] : D[7];
+                    // ... and A_kk = -P^-1 in the one lane that owns it (every other wave skips the branch)
+                    if (a == k && b == k) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) A[sl].m[3 * i + j] = piv ? -Pi[3 * i + j] : (tr ? D[3 * j + i] : D[3 * i + j]);
+                        for (int i = 0; i < 9; ++i) A[sl].m[i] = -Pi[i];
+                    }
                 }
                 // this block is final for step k: if it lies in the next pivot's column, publish it now (the other panel: its readers
                 // passed this step's barrier), so the copy overlaps the remaining blocks instead of being a phase of its own
