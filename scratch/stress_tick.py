@@ -14,7 +14,7 @@ ctx = pkg.Context(0, n, 16)
 worst_f = worst_t = 0.0; nflag = 0; nbad = 0; total = 0
 for robot, h in (("a1", 10), ("lite3", 10), ("a1", 5)):
     ctx.mpc_setup_packed(0, pkg.mpc_cfg(robot), h); ctx.wbc_setup_packed(0, pkg.model_desc(robot))
-    for seed in (11, 12, 13):
+    for seed in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (11, 12, 13)):
         for ex in (0.3, 1.0, 2.0):
             b = pkg.make_batch(n, h, robot, seed=seed * 100 + int(ex * 10), excite=ex)
             with G.cold_start(ctx):
