@@ -12,7 +12,7 @@ ctx = pkg.Context(0, n, 16)
 for r, t in (("a1", 0), ("lite3", 1)):
     ctx.mpc_setup_packed(t, pkg.mpc_cfg(r), h); ctx.wbc_setup_packed(t, pkg.model_desc(r))
 tot_flag = tot_bad = 0
-for seed in (21, 22):
+for seed in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (21, 22)):
     for ex in (0.3, 1.0):
         ba = pkg.make_batch(n // 2, h, "a1", seed=seed * 10 + 1, excite=ex); bl = pkg.make_batch(n // 2, h, "lite3", seed=seed * 10 + 2, excite=ex)
         def il(a, c):
