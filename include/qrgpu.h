@@ -386,7 +386,11 @@ int qrgpu_pack_state_batch(qrgpu_ctx *ctx, int n, const float com_offset[3], con
  * qrgpu_allgather_tau takes either that context-owned communicator (nccl_comm = NULL) or the caller's own ncclComm_t.  It is asynchronous:
  * the gather waits for the work queued on the context's compute stream so far, runs on a stream of the context's own, and the next
  * tick may be issued at once.  `slot` (0 / 1) names the torque buffer being read for double buffering: call qrgpu_allgather_fence(slot)
- * before queueing work that overwrites that buffer, qrgpu_comm_sync to wait on the host for every gather issued so far. */
+ * before queueing work that overwrites that buffer, qrgpu_comm_sync to wait on the host for every gather issued so far.
+ * A consumer of d_tau_all queued on the context's compute stream waits for the gather with qrgpu_allgather_wait(slot) (a stream-side wait,
+ * no host block; it leaves the fence of that slot due).  The gather of tick i + 1 starts as soon as tick i + 1's torques are complete: a
+ * consumer of tick i's d_tau_all that is queued AFTER qrgpu_allgather_tau of tick i + 1 would race with it, so either queue the consumer
+ * first or give d_tau_all two buffers by slot as well. */
 #define QRGPU_COMM_ID_BYTES 128
 int qrgpu_comm_unique_id(unsigned char id[QRGPU_COMM_ID_BYTES]);
 int qrgpu_comm_init_rank(qrgpu_ctx *ctx, const unsigned char id[QRGPU_COMM_ID_BYTES], int nranks, int rank);
@@ -395,6 +399,7 @@ int qrgpu_comm_destroy(qrgpu_ctx *ctx);
 int qrgpu_allgather_tau(qrgpu_ctx *ctx, void *nccl_comm /* ncclComm_t, or NULL = the context's */, const float *d_tau /* [12][n_local] */,
                         int n_local, float *d_tau_all /* [nranks][12][n_local] */, int slot);
 int qrgpu_allgather_fence(qrgpu_ctx *ctx, int slot);
+int qrgpu_allgather_wait(qrgpu_ctx *ctx, int slot);
 int qrgpu_comm_sync(qrgpu_ctx *ctx);
 
 /* ---- single-robot host-pointer API (what the drop-in C++ adapters call) ------ */

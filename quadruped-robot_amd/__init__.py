@@ -11,5 +11,5 @@ from . import shard                     # noqa: F401
 from . import ticklog                   # noqa: F401
 from . import replay                    # noqa: F401
 from .qrgpu import (Context, QrgpuError, MissingExtension, lib_path, load_library,   # noqa: F401
-                    MPCInterface, WbcLocomotionController, model_desc_struct)
+                    MPCInterface, WbcLocomotionController, model_desc_struct, status_flags, status_iterations)
 from .workload import make_batch, make_batch_sequence, mpc_cfg, model_desc, to_soa, ROBOTS    # noqa: F401

@@ -1702,15 +1702,17 @@ template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);  
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
 
 #ifndef QR_FLOPS_BUILD
-// Holds the stream it is launched on until the `expected` workgroups of the planned list launch (side stream) have started, or max_ticks of
-// the 100 MHz clock have passed, whichever comes first; then clears the counter.  A listed robot needs a whole CU: left to the dispatcher, the
+// Holds the stream it is launched on until every workgroup of the planned list launches issued so far (side stream) has started, or
+// max_ticks of the 100 MHz clock have passed, whichever comes first.  A listed robot needs a whole CU: left to the dispatcher, the
 // main pass's thousand workgroups fill every CU first and the listed robot starts 80-160 us late -- which is then the end of the launch.
-__global__ void qr_gate_kernel(int *counter, int expected, long long max_ticks)
+// The counter is cumulative and never cleared (`expected_total` is the host's running sum of the grids, compared as a wrapping difference):
+// a workgroup that starts after a gate has timed out is counted where it belongs instead of leaking into the next call's count.
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
-    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) < 0 && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(16);
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

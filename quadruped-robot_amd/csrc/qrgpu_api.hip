@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -74,11 +75,17 @@ static const void *mpc_fn(int var, bool fl)
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function (per device), not to a context: the cache is process-wide and the
+// limit is only ever raised, so that a second context asking for less cannot lower it under the first one's launches.
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
-    if (c->configured_lds[fl][var] >= bytes) return QRGPU_OK;
+    static std::mutex mu;
+    static int configured[16][2][6];          // [device][counting build][variant], zero-initialised
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = configured[c->device & 15][fl ? 1 : 0][var];
+    if (have >= bytes) return QRGPU_OK;
     HIPCHK(c, hipFuncSetAttribute(mpc_fn(var, fl), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    c->configured_lds[fl][var] = bytes;
+    have = bytes;
     return QRGPU_OK;
 }
 
@@ -411,8 +418,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         if (!c->d_sinv_spill) HIPCHK(c, hipMalloc(&c->d_sinv_spill, sizeof(double) * (size_t)c->max_batch * (size_t)(QR_QH * (QR_QH + 1) / 2)));
         P.sinv_spill = c->d_sinv_spill;
     }
-    // rescue pass for the four-wave variants (not for inspection launches or single-robot calls through the staging buffers)
-    const bool rescue = c->rescue && !dH && small;          // the h > 11 variant holds 96 rows itself
+    // Batches below 64 robots (the single-robot drop-in calls among them) have a CU per robot to themselves: they run the whole-CU eight-wave
+    // variant <2, BIG, ., 512> (96 working-set positions, the CU's whole LDS) as their main pass, so that nothing is left for a trailing
+    // list launch -- one launch instead of two on the single-robot path, and the ping-pong parity of the rescue / planned lists, which
+    // belongs to the batched calls' plan, is not touched by calls in between (a solve1 between two planned calls used to flip it
+    // and the next planned call read the counters of the plan before last).  QRGPU_TINY_WHOLE_CU=0: the old two-launch form.
+    static const int tiny_whole_cu = [] { const char *e = getenv("QRGPU_TINY_WHOLE_CU"); return e ? atoi(e) : 1; }();
+    const bool tiny = small && n < 64 && !dH && tiny_whole_cu != 0;
+    if (tiny) P.lds_bytes = c->lds_per_cu;
+    // rescue pass for the h <= 11 main pass (not for inspection launches or tiny batches)
+    const bool rescue = c->rescue && !dH && small && !tiny;          // the h > 11 variant holds 96 rows itself
     P.rescue_mode = 0;
     P.rescue_count = rescue ? c->d_rescue : nullptr;
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
@@ -443,7 +458,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0);
+    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0));
     // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
     const bool fl = P.flops != nullptr || dH != nullptr || dG != nullptr || c->d_dbg_cycles != nullptr;
     const void *fn = mpc_fn(var, fl);
@@ -492,6 +507,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(5, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
+            c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
             void *largs[2] = {(void *)&L, (void *)&io};
@@ -500,14 +516,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
-        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, gate_expect, (long long)3000); HIPCHK(c, hipGetLastError()); }
+        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000); HIPCHK(c, hipGetLastError()); }
     }
     {
         TimerScope ts(c, 0);
         const dim3 grid(8 * ((n + 7) / 8));
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
-        const int threads = (var == 3 || var == 0) ? 512 : 256;
+        const int threads = (var == 3 || var == 0 || var == 5) ? 512 : 256;
         HIPCHK(c, hipExtLaunchKernel(fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
@@ -528,7 +544,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         void *rargs[2] = {(void *)&R, (void *)&io};
         HIPCHK(c, hipExtLaunchKernel(mpc_fn(4, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, c->stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
-        if (planned) c->plan_n = n;        // (the length of the list just planned reaches h_pre_count by itself)
+        // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
+        // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
+        c->plan_n = planned ? n : 0;
         c->rescue_parity ^= 1;
     }
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
@@ -541,7 +559,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // decides on a count several ticks old -- and on nothing at all for the first ticks of a new batch, whose listed robots then go through
     // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
     // The first two calls after a history reset (one per parity) therefore end with a stream sync.
-    if (planned && c->plan_sync_left > 0) { --c->plan_sync_left; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    // (Not while the stream is being captured into a graph: a sync is illegal there, and a replayed graph has a fixed launch shape anyway.)
+    if (planned && c->plan_sync_left > 0) {
+        --c->plan_sync_left;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+        if (cap == hipStreamCaptureStatusNone) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return QRGPU_OK;
 }
 

@@ -155,6 +155,16 @@ int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
     return QRGPU_OK;
 }
 
+int qrgpu_allgather_wait(qrgpu_ctx *c, int slot)
+{
+    // device-side wait for a CONSUMER of d_tau_all queued on the compute stream: no host block, and the pending flag stays (the fence
+    // in front of the next overwrite of the source buffer is still due)
+    if (!c || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
+    if (!c->comm_stream || !c->ev_gather_pending[slot]) return QRGPU_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
+    return QRGPU_OK;
+}
+
 int qrgpu_comm_sync(qrgpu_ctx *c)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;

@@ -29,7 +29,6 @@ struct qrgpu_ctx {
     int *d_st1 = nullptr;
     int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
-    int configured_lds[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};     // dynamic-LDS limit already set on this context's device, per kernel variant ([1]: the counting build)
     double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
     int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
     int rescue_parity = 0;
@@ -42,7 +41,8 @@ struct qrgpu_ctx {
     bool planned = true;
     int big_nls = 0;
     int plan_sync_left = 0;        // calls after a history reset that still end with a stream sync (so that the host sees the first plans' lengths)
-    int *d_started = nullptr;                 // workgroups of the planned list launch that have started (qr_gate_kernel)
+    int *d_started = nullptr;                 // workgroups of planned list launches that have started, ever (qr_gate_kernel); never cleared
+    int started_total = 0;                    // what that counter reaches once every planned launch issued so far has started (wraps like the counter)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)

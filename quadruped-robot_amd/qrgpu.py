@@ -22,9 +22,20 @@ _LIB = None
 
 ERRORS = {0: "OK", 1: "NO_DEVICE", 2: "BAD_ARG", 3: "NOT_SETUP", 4: "LAUNCH", 5: "ALLOC", 6: "COMM"}
 ST_FLAG_MASK, ST_BAD_TYPE = 0xff0000ff, 0x01000000
+
 ST_MPC_MAXITER, ST_MPC_INFEAS, ST_MPC_OVERFLOW, ST_MPC_NOTSPD = 0x1, 0x2, 0x4, 0x8
 ST_WBC_MAXITER, ST_WBC_INFEAS = 0x10, 0x20
 FB_DEBUG_FLOATS = 324 + 18 + 18 + 216 + 12 + 12 + 12
+
+
+def status_flags(status):
+    """Flag bits of a status word / array (include/qrgpu.h: bits 0-7 and 24-31; 0 = converged)."""
+    return np.asarray(status).astype(np.int64) & ST_FLAG_MASK
+
+
+def status_iterations(status):
+    """MPC active-set iteration count of a status word / array (bits 8-23)."""
+    return (np.asarray(status).astype(np.int64) >> 8) & 0xffff
 
 
 class QrgpuError(RuntimeError):
@@ -99,7 +110,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_swing_velocity_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
-           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
+           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode"]
 
 
@@ -138,6 +149,7 @@ def load_library():
     lib.qrgpu_comm_destroy.argtypes = [vp]
     lib.qrgpu_allgather_tau.argtypes = [vp, vp, vp, ip, vp, ip]
     lib.qrgpu_allgather_fence.argtypes = [vp, ip]
+    lib.qrgpu_allgather_wait.argtypes = [vp, ip]
     lib.qrgpu_comm_sync.argtypes = [vp]
     lib.qrgpu_mpc_assemble_batch.argtypes = [vp, ip] + [vp] * 6
     lib.qrgpu_vmc_desc_default.argtypes = [C.POINTER(vmc_desc_struct)]; lib.qrgpu_vmc_desc_default.restype = None
@@ -460,6 +472,10 @@ class Context:
 
     def allgather_fence(self, slot=0):
         self._chk(self._lib.qrgpu_allgather_fence(self._h, int(slot)))
+
+    def allgather_wait(self, slot=0):
+        """Make the compute stream wait for the gather of `slot` (for a consumer of tau_all queued there); the slot's fence stays due."""
+        self._chk(self._lib.qrgpu_allgather_wait(self._h, int(slot)))
 
     def comm_sync(self):
         self._chk(self._lib.qrgpu_comm_sync(self._h))

@@ -8,6 +8,7 @@ are the MPC's J^T f) and per force component.
 import numpy as np
 
 from . import ticklog
+from .qrgpu import status_flags
 
 GAIN_NAMES = ("kp_body_pos", "kd_body_pos", "kp_body_ori", "kd_body_ori", "kp_foot", "kd_foot", "weight_fb", "weight_fr", "mu")
 
@@ -40,8 +41,8 @@ def replay(ctx, log, stateful=False, first=0, count=None, to_soa=None):
             ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"])
             ctx.sync()
             force, tau, status = d["force"].download().T, d["tau"].download().T, d["status"].download()
-            bad = ((status & 0xff) != 0) | ((t["status"] & 0xff) != 0)
-            flagged += int(((status & 0xff) != 0).sum()); rec_flagged += int(((t["status"] & 0xff) != 0).sum())
+            bad = (status_flags(status) != 0) | (status_flags(t["status"]) != 0)
+            flagged += int((status_flags(status) != 0).sum()); rec_flagged += int((status_flags(t["status"]) != 0).sum())
             ok = ~bad
             ef = np.abs(force - t["force"]) / np.maximum(1.0, np.abs(t["force"]).max(axis=1, keepdims=True))
             stance = np.repeat(t["wbc_cmd"][:, 63:67] != 0, 3, axis=1)

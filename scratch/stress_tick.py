@@ -26,13 +26,13 @@ for robot, h in (("a1", 10), ("lite3", 10), ("a1", 5)):
                                                  b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=32)
             line = []
             for name, o in (("cold", o1), ("stale", ws), ("warm", we)):
-                flags = (o["status"] & 0xff) != 0
+                flags = G.flags(o["status"]) != 0
                 ok = ~flags & (st == 0)
                 ef = (np.abs(o["force"] - f).max(1) / np.maximum(1.0, np.abs(f).max(1)))[ok]
                 et = (np.abs(o["tau"] - tau) / np.maximum(1.0, np.abs(tau))).max(1)[ok]
                 bad = int((ef > 1e-5).sum() + (et > 1e-4).sum())
                 worst_f = max(worst_f, ef.max()); worst_t = max(worst_t, et.max()); nflag += int(flags.sum()); nbad += bad; total += n
                 line.append("%s: flagged %d %s, force %.1e, torque %.1e, over tol %d, iters mean %.1f max %d" % (
-                    name, flags.sum(), dict(zip(*[x.tolist() for x in np.unique(o["status"][flags] & 0xff, return_counts=True)])) if flags.any() else "", ef.max(), et.max(), bad, ((o["status"] >> 8) & 0xffff).mean(), ((o["status"] >> 8) & 0xffff).max()))
+                    name, flags.sum(), dict(zip(*[x.tolist() for x in np.unique(G.flags(o["status"][flags]), return_counts=True)])) if flags.any() else "", ef.max(), et.max(), bad, ((o["status"] >> 8) & 0xffff).mean(), ((o["status"] >> 8) & 0xffff).max()))
             print("%-5s h=%2d seed %d excite %.1f (oracle nonzero %d, cold runs bit-identical %s) | %s" % (robot, h, seed, ex, (st != 0).sum(), det, " | ".join(line)), flush=True)
 print("TOTAL %d robot-ticks: flagged %d, over tolerance %d, worst force %.2e, worst torque %.2e" % (total, nflag, nbad, worst_f, worst_t))

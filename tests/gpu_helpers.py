@@ -3,6 +3,17 @@ import contextlib
 
 import numpy as np
 
+ST_FLAG_MASK = 0xff0000ff          # include/qrgpu.h QRGPU_ST_FLAG_MASK: bits 0-7 and 24-31 (BAD_TYPE) are flags, 8-23 the MPC iteration count
+
+
+def flags(status):
+    """Flag bits of a status word / array; 0 = converged and usable."""
+    return np.asarray(status).astype(np.int64) & ST_FLAG_MASK
+
+
+def iterations(status):
+    return (np.asarray(status).astype(np.int64) >> 8) & 0xffff
+
 
 @contextlib.contextmanager
 def cold_start(ctx):
@@ -24,6 +35,9 @@ def run_mpc(ctx, pkg, b, with_tau=True, type_id=None):
     d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])),
              gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), q=ctx.alloc((12, n)).upload(S(b["fb_state"][:, 13:25])),
              force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
+    # poisoned outputs: a robot that no launch solves shows as NaN forces and an all-ones flag word, not as whatever the allocator left there
+    d["force"].upload(np.full((12, n), np.nan, np.float32)); d["tau"].upload(np.full((12, n), np.nan, np.float32))
+    d["status"].upload(np.full((n,), 0x7f0000ff, np.int32))
     tid = ctx.alloc((n,), np.int32).upload(type_id) if type_id is not None else None
     ctx.mpc_solve_batch(n, d["state"], d["traj"], d["gait"], d["q"], d["force"], d["tau"] if with_tau else None, d["status"], tid)
     ctx.sync()

@@ -41,6 +41,17 @@ def test_allgather_tau_single_rank(pkg, oracle):
         _, tau_o, st, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"],
                                                b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
         assert np.all(np.abs(got.T - tau_o) <= G.tau_tol(tau_o, 1e-4))
+        # a consumer on the compute stream: qrgpu_allgather_wait makes that stream wait for the gather (no host-side comm sync), and
+        # the slot's fence is still due afterwards
+        tau_all.upload(np.full((1, 12, n), np.nan, np.float32))
+        ctx.allgather_fence(1)
+        d["prev"].upload(S(b["prev_ori_vel"]))
+        ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], tau[1], d["status"])
+        ctx.allgather_tau(tau[1], n, tau_all, 1)
+        ctx.allgather_wait(1)
+        ctx.sync()                                                   # compute stream only
+        assert np.array_equal(tau_all.download()[0], tau[1].download())
+        ctx.allgather_fence(1)
         ctx.comm_destroy()
         with pytest.raises(pkg.QrgpuError, match="NOT_SETUP"):
             ctx.allgather_tau(tau[0], n, tau_all, 0)

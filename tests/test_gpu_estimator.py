@@ -4,6 +4,8 @@ Reference: qr_robot_velocity_estimator.cpp:77-133, qr_robot.cpp:62-72; Kalman st
 Bar: leg kinematics within 2e-6 (device sinf/cosf vs libm), everything downstream within 1e-5 absolute (velocities of order 1 m/s);
 the filters themselves replay the reference's operations exactly."""
 import numpy as np
+
+import gpu_helpers as G
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -85,6 +87,6 @@ def test_sensor_to_torque_pipeline_stays_on_device(gpu_ctx, pkg, oracle):
     # torques: GPU tick on the GPU-packed state against the oracle tick on that same state (the estimator difference is tested above)
     f_o, tau_o, st_o, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), mpc_g, b["traj"], b["gait"], fb_g,
                                                b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
-    ok = ((status & 0xff) == 0) & (st_o == 0)
+    ok = (G.flags(status) == 0) & (st_o == 0)
     assert ok.sum() >= n - 2
     assert np.all(np.abs(tau[ok] - tau_o[ok]) <= 1e-4 * np.maximum(1.0, np.abs(tau_o[ok])))

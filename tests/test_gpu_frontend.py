@@ -4,6 +4,8 @@ MPCStanceLegController::SetupCommand / Run / UpdateMPC (qr_mpc_stance_leg_contro
 Bar: bit-exact float32, except the three outputs that carry std::sin (height / pitch compensation: bodyHeight, rpyComp[1]),
 where libm and the device library may differ in the last bit of a double sine -> at most 1 float ulp."""
 import numpy as np
+
+import gpu_helpers as G
 import pytest
 
 from gpu_helpers import setup_a1, tau_tol
@@ -110,7 +112,7 @@ def test_frontend_sequence_feeds_tick(gpu_ctx, pkg, oracle):
     gpu_ctx.tick_batch(n, d["state"], d_traj, d_gait, d["fb"], d_cmd, d["prev"], d["force"], d["tau"], d["status"])
     gpu_ctx.sync()
     tau = d["tau"].download().T; status = d["status"].download()
-    assert np.all((status & 0xff) == 0), np.unique(status & 0xff)
+    assert np.all(G.flags(status) == 0), np.uniqueG.flags(status)
     f_o, tau_o, st_o, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
                                                g_traj, g_gait, b["fb_state"], g_cmd, b["prev_ori_vel"].copy(), nthreads=4)
     assert np.all(st_o == 0)

@@ -22,7 +22,7 @@ def test_mpc_golden(gpu_ctx, pkg):
         b = dict(n=n, horizon=h, mpc_state=np.stack([r["mpc_state"] for r in rs]), traj=np.stack([r["traj"] for r in rs]),
                  gait=np.stack([r["gait"] for r in rs]), fb_state=fb)
         out = G.run_mpc(gpu_ctx, pkg, b)
-        assert np.all((out["status"] & 0xff) == 0), (robot, h, out["status"] & 0xff)
+        assert np.all(G.flags(out["status"]) == 0), (robot, h, G.flags(out["status"]))
         for i, r in enumerate(rs):
             scale = max(1.0, np.abs(r["f_qpoases_sym"]).max())
             # reference qpOASES on the symmetric data, converged: same unique optimum
@@ -57,7 +57,7 @@ def test_mpc_vs_reference_solver_as_called(gpu_ctx, pkg):
         b = dict(n=n, horizon=h, mpc_state=np.stack([r["mpc_state"] for r in rs]), traj=np.stack([r["traj"] for r in rs]),
                  gait=np.stack([r["gait"] for r in rs]), fb_state=fb)
         out = G.run_mpc(gpu_ctx, pkg, b)
-        assert np.all((out["status"] & 0xff) == 0), (robot, h)
+        assert np.all(G.flags(out["status"]) == 0), (robot, h)
         for i, r in enumerate(rs):
             nwsr, rc = int(r["qpoases_as_called_nwsr"][0]), int(r["qpoases_as_called_nwsr"][1])
             if rc != 0 or nwsr >= 100:

@@ -4,6 +4,8 @@ MPC every 15th tick and on each of the first 50 (qr_mpc_stance_leg_controller.cp
 (qr_wbc_locomotion_controller.cpp:111,133), Fr_des = the latest MPC forces (:408) -- against the oracle driven the same way.
 The state stream is synthetic (the reference ships no recorded data)."""
 import numpy as np
+
+import gpu_helpers as G
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +29,7 @@ def test_single_robot_replay(pkg, oracle):
             s = stream["mpc_state"][k]
             if k % 15 == 0 or k < 50:
                 mpc.SolveMPCKernel(s[0:3], s[3:6], s[6:10], s[10:13], s[13:25], s[25:28], stream["traj"][k], stream["gait"][k])
-                assert (mpc.status & 0xff) == 0
+                assert G.flags(mpc.status) == 0
                 f_gpu = np.array([mpc.GetMPCSolution(i) for i in range(12)])
                 u, st, rc = oracle.mpc_solve(cfg, h, s, stream["traj"][k], stream["gait"][k])
                 assert rc == 0

@@ -6,6 +6,8 @@ torques within 1e-4 * max(1, |tau|) (north_star tolerance); the 'QuadProg++ retu
 import os
 
 import numpy as np
+
+import gpu_helpers as G
 import pytest
 
 from gpu_helpers import tau_tol
@@ -37,7 +39,7 @@ def test_vmc_parity(gpu_ctx, pkg, oracle, n, sloped, excite):
     gpu_ctx.vmc_setup_packed(0, cfg, geom)
     vin, q = W.make_vmc_batch(n, sloped=sloped, excite=excite, seed=n)
     g = _run(gpu_ctx, pkg, vin, q)
-    flags = g["status"] & 0xff
+    flags = G.flags(g["status"])
     assert np.all((flags & ~0x80) == 0), np.unique(flags)
     n_inf = 0
     for i in range(n):
@@ -107,7 +109,7 @@ def test_vmc_world_frame_parity(gpu_ctx, pkg, oracle):
     n = 800
     vin, q, ratio = W.make_vmc_world_batch(n, seed=23)
     g = _run_world(gpu_ctx, pkg, vin, q, ratio)
-    flags = g["status"] & 0xff
+    flags = G.flags(g["status"])
     assert np.all((flags & ~0x80) == 0), np.unique(flags)
     n_inf = 0
     for i in range(n):

@@ -136,7 +136,7 @@ def test_full_tick(gpu_ctx, pkg, oracle):
     G.setup_a1(gpu_ctx, pkg, 10)
     b = pkg.make_batch(128, 10, "a1", seed=0xA4)
     out = G.run_tick(gpu_ctx, pkg, b)
-    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
     f, tau, st, sec, prev = oracle.tick_batch(1, pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
                                               b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
     assert np.all(st == 0)
@@ -157,7 +157,7 @@ def test_full_tick_h16_mixed_a1_lite3(gpu_ctx, pkg, oracle):
     b["n"] = n
     tid = pkg.shard.interleave_types(n, 2)
     out = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
-    assert np.all((out["status"] & 0xff) == 0), np.unique(out["status"] & 0xff)
+    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
     for i in range(n):
         robot = "a1" if tid[i] == 0 else "lite3"
         u, st, rc = oracle.mpc_solve(pkg.mpc_cfg(robot), h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
@@ -186,7 +186,7 @@ def test_full_tick_1024_with_projection_and_motor_tail(gpu_ctx, pkg, oracle):
         out = G.run_tick(gpu_ctx, pkg, b, want_qdes=True)
     finally:
         gpu_ctx.set_torque_epilogue(False, False)
-    assert np.all((out["status"] & 0xff) == 0) and np.all(st == 0)
+    assert np.all(G.flags(out["status"]) == 0) and np.all(st == 0)
     assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max())
     assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
     assert np.abs(out["tau"]).max() <= 23.0
