@@ -425,6 +425,13 @@ int qrgpu_mpc_assemble_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const 
 #define QRGPU_FB_DEBUG_FLOATS (324 + 18 + 18 + 216 + 12 + 12 + 12)
 int qrgpu_fb_debug_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_fb_state, float *d_out);
 
+/* One WBC tick as qrgpu_wbc_run_batch computes it (K12 skipped), plus the solution of its relaxation QP:
+ * d_qp [n][QRGPU_WBC_QP_FLOATS] = qpz[18] (z_fb[6], z_f[3 * contacts], zero padded; qr_wholebody_impulse_ctrl.cpp:113) and
+ * extraData->optimalFr[12] = z_f + Fr_des (:216-218), stance feet in contact order, zero padded. */
+#define QRGPU_WBC_QP_FLOATS 30
+int qrgpu_wbc_inspect_batch(qrgpu_ctx *ctx, int n, const int *d_type_id, const float *d_fb_state, const float *d_wbc_cmd,
+                            float *d_prev_ori, float *d_tau, float *d_qp, int *d_status);
+
 /* ---- executed arithmetic of the batched MPC solve (measurement; off by default) ---------------------------------------------------
  * With counting on, every solve leaves what it actually computed, by formula from the sizes it saw (stance leg-steps, tile count,
  * working-set size of every change, rebuilds): out[0] fp32 vector flops, out[1] fp32 matrix flops issued (v_mfma_f32_16x16x4_f32),

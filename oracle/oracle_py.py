@@ -204,6 +204,37 @@ def wbc_run(model, state37, cmd67, prev_ori_vel=None, dtype=_f):
                 qp=dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])))
 
 
+def wbc_qp(model, state37, cmd67, prev_ori_vel=None, dtype=_f, z_in=None):
+    """The WBC tick with its relaxation QP laid open (qr_wholebody_impulse_ctrl.cpp:113, :129-206, :232-247): the QP as the oracle assembles it in
+    QuadProg++ layout (G [n,n], g0 [n], CE [n,p], ce0 [p], CI [n,m], ci0 [m]), the solver's z, and tau / optimalFr of the tick -- finished
+    with `z_in` instead of the oracle's own solution when that is given (the compiled QuadProg++'s).  prev_ori_vel is not modified."""
+    t = dtype
+    conv = _fp if t == _f else _dp
+    s = np.ascontiguousarray(state37, t); c = np.ascontiguousarray(cmd67, t)
+    prev = np.zeros(3, t) if prev_ori_vel is None else np.ascontiguousarray(prev_ori_vel, t)
+    dims = np.zeros(3, np.int32)
+    G = np.zeros(18 * 18); g0 = np.zeros(18); CE = np.zeros(18 * 6); ce0 = np.zeros(6); CI = np.zeros(18 * 24); ci0 = np.zeros(24); z = np.zeros(18)
+    tau = np.zeros(12, t); fr = np.zeros(12, t)
+    zi = np.ascontiguousarray(z_in, _d) if z_in is not None else None
+    fn = lib().qro_wbc_qp_f32 if t == _f else lib().qro_wbc_qp_f64
+    rc = fn(_fp(np.ascontiguousarray(model, _f)), conv(s), conv(c), conv(prev), _dp(zi) if zi is not None else None, _ip(dims), _dp(G), _dp(g0), _dp(CE),
+            _dp(ce0), _dp(CI), _dp(ci0), _dp(z), conv(tau), conv(fr))
+    n, p, m = (int(x) for x in dims)
+    return dict(n=n, p=p, m=m, G=G[:n * n].reshape(n, n).copy(), g0=g0[:n].copy(), CE=CE[:n * p].reshape(n, p).copy(), ce0=ce0[:p].copy(),
+                CI=CI[:n * m].reshape(n, m).copy(), ci0=ci0[:m].copy(), z=z[:n].copy(), tau=tau, fr=fr, rc=rc)
+
+
+def tick_from_forces(geom, model, fb_state37, wbc_cmd67, prev_ori_vel, f12, mode=1, epilogue=0, wbc_fp64=False, want_qdes=False):
+    """One robot's tick behind the MPC solve from given first-step forces: K7 torque map, abad compensation, WBC fed with Fr_des := f12,
+    stance / swing merge, clip (qr_oracle_capi.cpp tick_tail).  -> tau[12] float32, prev (updated copy) (, qdes[24])"""
+    prev = np.ascontiguousarray(prev_ori_vel, _f).copy()
+    tau = np.zeros(12, _f); qdes = np.zeros(24, _f)
+    lib().qro_tick_from_forces(_fp(np.ascontiguousarray(geom, _f)), _fp(np.ascontiguousarray(model, _f)), _fp(np.ascontiguousarray(fb_state37, _f)),
+                               _fp(np.ascontiguousarray(wbc_cmd67, _f)), _fp(prev), _dp(np.ascontiguousarray(f12, _d)), int(mode), int(epilogue),
+                               int(bool(wbc_fp64)), _fp(tau), _fp(qdes))
+    return (tau, prev, qdes) if want_qdes else (tau, prev)
+
+
 def pinv(A, thr):
     A = np.ascontiguousarray(A, _f)
     out = np.zeros((A.shape[1], A.shape[0]), _f)

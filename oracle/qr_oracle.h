@@ -189,9 +189,17 @@ template <typename T> struct WbcOut {
     T qddot[18];
     int qp_status; QpStats qp;
 };
+// The relaxation QP exactly as MakeTorque hands it to solve_quadprog (qr_wholebody_impulse_ctrl.cpp:113), QuadProg++ convention, the
+// matrices row-major [n][p] / [n][m] as qpCE[j][i] / qpCI[j][i] are filled (:141-147, :161-166).  When `z_in` is set the tick is finished
+// with that solution instead of the oracle's own solver's (tests: the compiled QuadProg++ of oracle/_ref).
+struct WbcQpIO {
+    int n = 0, p = 0, m = 0;
+    std::vector<double> G, g0, CE, ce0, CI, ci0, z;
+    const double *z_in = nullptr;
+};
 // prev_ori_vel: in/out, TK::desiredVel of the orientation task from the previous call (quirk 4).
 template <typename T> void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd,
-                                   T prev_ori_vel[3], WbcOut<T> &out);
+                                   T prev_ori_vel[3], WbcOut<T> &out, WbcQpIO *qpio = nullptr);
 
 
 // ---------------------------------------------------------------------------

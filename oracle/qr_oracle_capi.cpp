@@ -94,6 +94,63 @@ int wbc_run_c(const float *model, const T *state, const T *cmd, T *prev_ori_vel,
     return o.qp_status;
 }
 
+// The part of one robot's tick behind the MPC solve: K7 torque map of the forces `u` (first horizon step), the +-0.9 N m abad compensation,
+// the WBC tick fed with Fr_des := u, the stance / swing merge and the +-23 N m clip.  legCmd[motor].tua (a double, qrMotorCommand) as
+// qrFSMStateLocomotion::Run leaves it (QS/fsm/qr_fsm_state_locomotion.cpp:131-156): hybridAction's tua, then +-0.9 on every abad motor
+// (:141-151), then -- full tick -- UpdateLegCMD overwrites the stance legs (qr_wbc_locomotion_controller.cpp:205-219), then the clip of
+// CheckForceFeedForward (QS/fsm/qr_safety_checker.cpp:48-66).  WT: the arithmetic of the WBC (float as the reference computes; double
+// for the kernel-side comparison).  Returns the WBC QP's status << 4.
+template <typename WT>
+int tick_tail(const LegGeom &g, const ModelDesc &md, const float *fs /*fb_state37*/, const float *cmd_in /*wbc_cmd67*/, float *prev3,
+              const double *u /*12 forces*/, int mode, int epilogue, float *tau12_out, float *qdes24_out)
+{
+    int rc = 0;
+    float tau[12];
+    mpc_force_to_torque(g, fs, fs + 13, u, tau);
+    double tua[12];
+    for (int k = 0; k < 12; ++k) {
+        tua[k] = (double)tau[k];
+        if ((epilogue & 1) && k % 3 == 0) { float comp = 0.9f * (float)std::pow(-1.0, (double)((k / 3 + 1) % 2)); tua[k] += comp; }
+    }
+    if (mode == 1) {
+        float cmd[67];
+        memcpy(cmd, cmd_in, sizeof(cmd));
+        for (int k = 0; k < 12; ++k) cmd[51 + k] = (float)u[k];          // wbcData.Fr_des[leg] = f.col(leg) (:408)
+        WT sw[37], cw[67], pw[3];
+        for (int k = 0; k < 37; ++k) sw[k] = (WT)fs[k];
+        for (int k = 0; k < 67; ++k) cw[k] = (WT)cmd[k];
+        for (int k = 0; k < 3; ++k) pw[k] = (WT)prev3[k];
+        WbcOut<WT> o;
+        wbc_run(md, unpack_state(sw), unpack_cmd(cw), pw, o);
+        for (int k = 0; k < 3; ++k) prev3[k] = (float)pw[k];
+        for (int l = 0; l < 4; ++l)
+            if (cmd[63 + l] != 0.f) for (int j = 0; j < 3; ++j) tua[3 * l + j] = (double)(float)o.tau[3 * l + j];
+        if (qdes24_out) for (int k = 0; k < 12; ++k) { qdes24_out[k] = (float)o.qdes[k]; qdes24_out[12 + k] = (float)o.qddes[k]; }
+        rc = o.qp_status << 4;
+    }
+    if (epilogue & 2) for (int k = 0; k < 12; ++k) { if (tua[k] > 23) tua[k] = 23; else if (tua[k] < -23) tua[k] = -23; }
+    for (int k = 0; k < 12; ++k) tau12_out[k] = (float)tua[k];
+    return rc;
+}
+
+// The WBC tick with its relaxation QP laid open: the QP as assembled (QuadProg++ layout), our solver's z or -- with z_in -- the tick
+// finished with an externally computed z (the compiled QuadProg++ of oracle/_ref in tests/golden/make_golden.py).  prev is not modified.
+template <typename T>
+int wbc_qp_c(const float *model, const T *state, const T *cmd, const T *prev_in, const double *z_in, int *dims, double *G, double *g0, double *CE,
+             double *ce0, double *CI, double *ci0, double *z_out, T *tau, T *fr)
+{
+    WbcOut<T> o;
+    WbcQpIO io;
+    io.z_in = z_in;
+    T prev[3] = {prev_in[0], prev_in[1], prev_in[2]};
+    wbc_run(unpack_model(model), unpack_state(state), unpack_cmd(cmd), prev, o, &io);
+    if (dims) { dims[0] = io.n; dims[1] = io.p; dims[2] = io.m; }
+    auto put = [](double *dst, const std::vector<double> &v) { if (dst) memcpy(dst, v.data(), sizeof(double) * v.size()); };
+    put(G, io.G); put(g0, io.g0); put(CE, io.CE); put(ce0, io.ce0); put(CI, io.CI); put(ci0, io.ci0); put(z_out, io.z);
+    for (int i = 0; i < 12; ++i) { if (tau) tau[i] = o.tau[i]; if (fr) fr[i] = o.fr[i]; }
+    return o.qp_status;
+}
+
 }  // namespace
 
 extern "C" {
@@ -183,6 +240,24 @@ void qro_lu_inverse_f32(int n, const float *A, float *out)
     memcpy(out, inv.d.data(), sizeof(float) * n * n);
 }
 
+int qro_wbc_qp_f32(const float *model, const float *state, const float *cmd, const float *prev, const double *z_in, int *dims, double *G, double *g0,
+                   double *CE, double *ce0, double *CI, double *ci0, double *z_out, float *tau, float *fr)
+{ return wbc_qp_c<float>(model, state, cmd, prev, z_in, dims, G, g0, CE, ce0, CI, ci0, z_out, tau, fr); }
+int qro_wbc_qp_f64(const float *model, const double *state, const double *cmd, const double *prev, const double *z_in, int *dims, double *G, double *g0,
+                   double *CE, double *ce0, double *CI, double *ci0, double *z_out, double *tau, double *fr)
+{ return wbc_qp_c<double>(model, state, cmd, prev, z_in, dims, G, g0, CE, ce0, CI, ci0, z_out, tau, fr); }
+
+// One robot's tick from given first-step MPC forces (tests: the forces the compiled qpOASES returns when called as the reference calls it).
+// wbc_fp64: 0 = the WBC in float (the reference's arithmetic), 1 = in double.  prev3: in/out.
+int qro_tick_from_forces(const float *geom3, const float *model, const float *fb_state37, const float *wbc_cmd67, float *prev3, const double *f12,
+                         int mode, int epilogue, int wbc_fp64, float *tau12_out, float *qdes24_out)
+{
+    LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2];
+    ModelDesc md = unpack_model(model);
+    return wbc_fp64 ? tick_tail<double>(g, md, fb_state37, wbc_cmd67, prev3, f12, mode, epilogue, tau12_out, qdes24_out)
+                    : tick_tail<float>(g, md, fb_state37, wbc_cmd67, prev3, f12, mode, epilogue, tau12_out, qdes24_out);
+}
+
 // ---------------------------------------------------------------------------
 // Batched full tick on host threads: the CPU baseline bench.py reports.
 // One tick per robot = MPC (K1-K7) then WBC (K8-K14) fed with that MPC's Fr_des
@@ -208,31 +283,9 @@ double qro_tick_batch(int nrobots, int nthreads, int mode, const float *cfg, int
             mpc_assemble(c, in, a);
             QpStats st;
             int rc = mpc_solve_qp(a, in.gait, horizon, u.data(), &st);
-            const float *fs = fb_state37 + 37 * i;
-            float tau[12];
-            mpc_force_to_torque(g, fs, fs + 13, u.data(), tau);
             for (int k = 0; k < 12; ++k) force12_out[12 * i + k] = (float)u[k];
-            // legCmd[motor].tua (a double, qrMotorCommand) as qrFSMStateLocomotion::Run leaves it (QS/fsm/qr_fsm_state_locomotion.cpp:131-156):
-            // hybridAction's tua, then +-0.9 on every abad motor (:141-151), then -- full tick -- UpdateLegCMD overwrites the stance legs
-            // (qr_wbc_locomotion_controller.cpp:205-219), then the +-23 clip of CheckForceFeedForward (QS/fsm/qr_safety_checker.cpp:48-66)
-            double tua[12];
-            for (int k = 0; k < 12; ++k) {
-                tua[k] = (double)tau[k];
-                if ((epilogue & 1) && k % 3 == 0) { float comp = 0.9f * (float)std::pow(-1.0, (double)((k / 3 + 1) % 2)); tua[k] += comp; }
-            }
-            if (mode == 1) {
-                float cmd[67];
-                memcpy(cmd, wbc_cmd67 + 67 * i, sizeof(cmd));
-                for (int k = 0; k < 12; ++k) cmd[51 + k] = (float)u[k];          // wbcData.Fr_des[leg] = f.col(leg) (:408)
-                WbcOut<float> o;
-                wbc_run(md, unpack_state(fs), unpack_cmd(cmd), prev_ori_vel3 + 3 * i, o);
-                for (int l = 0; l < 4; ++l)
-                    if (cmd[63 + l] != 0.f) for (int j = 0; j < 3; ++j) tua[3 * l + j] = (double)o.tau[3 * l + j];
-                if (qdes24_out) for (int k = 0; k < 12; ++k) { qdes24_out[24 * i + k] = o.qdes[k]; qdes24_out[24 * i + 12 + k] = o.qddes[k]; }
-                rc |= o.qp_status << 4;
-            }
-            if (epilogue & 2) for (int k = 0; k < 12; ++k) { if (tua[k] > 23) tua[k] = 23; else if (tua[k] < -23) tua[k] = -23; }
-            for (int k = 0; k < 12; ++k) tau12_out[12 * i + k] = (float)tua[k];
+            rc |= tick_tail<float>(g, md, fb_state37 + 37 * i, wbc_cmd67 + 67 * i, prev_ori_vel3 + 3 * i, u.data(), mode, epilogue, tau12_out + 12 * i,
+                                   qdes24_out ? qdes24_out + 24 * i : nullptr);
             if (status_out) status_out[i] = rc;
         }
     };

@@ -35,7 +35,7 @@ template <typename T> void weightedInverse(const Mat<T> &J, const Mat<T> &Winv, 
 }  // namespace
 
 template <typename T>
-void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd, T prev_ori_vel[3], WbcOut<T> &out)
+void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd, T prev_ori_vel[3], WbcOut<T> &out, WbcQpIO *qpio)
 {
     // ---- UpdateModel (:138-168)
     FBResult<T> fb;
@@ -217,7 +217,13 @@ void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd, T 
             ci0[i] = -(double)ci0m[i];
         }
     }
-    out.qp_status = qp_solve_gi(dimOpt, G.data(), g0.data(), p, CE.data(), ce0.data(), m, CI.data(), ci0.data(), z.data(), nullptr, &out.qp);
+    if (qpio && qpio->z_in) {        // finish the tick with somebody else's solution of this QP
+        for (int i = 0; i < dimOpt; ++i) z[i] = qpio->z_in[i];
+        out.qp_status = 0; out.qp = QpStats();
+    } else {
+        out.qp_status = qp_solve_gi(dimOpt, G.data(), g0.data(), p, CE.data(), ce0.data(), m, CI.data(), ci0.data(), z.data(), nullptr, &out.qp);
+    }
+    if (qpio) { qpio->n = dimOpt; qpio->p = p; qpio->m = m; qpio->G = G; qpio->g0 = g0; qpio->CE = CE; qpio->ce0 = ce0; qpio->CI = CI; qpio->ci0 = ci0; qpio->z = z; }
 
     for (int i = 0; i < 6; ++i) qddot_pre[i] += (T)z[i];             // :117-119
 
@@ -233,7 +239,7 @@ void wbc_run(const ModelDesc &md, const FBState<T> &st, const WbcCmd<T> &cmd, T 
     for (int i = 0; i < 18; ++i) out.qddot[i] = qddot_pre[i];
 }
 
-template void wbc_run<float>(const ModelDesc &, const FBState<float> &, const WbcCmd<float> &, float *, WbcOut<float> &);
-template void wbc_run<double>(const ModelDesc &, const FBState<double> &, const WbcCmd<double> &, double *, WbcOut<double> &);
+template void wbc_run<float>(const ModelDesc &, const FBState<float> &, const WbcCmd<float> &, float *, WbcOut<float> &, WbcQpIO *);
+template void wbc_run<double>(const ModelDesc &, const FBState<double> &, const WbcCmd<double> &, double *, WbcOut<double> &, WbcQpIO *);
 
 }  // namespace qro

@@ -341,7 +341,7 @@ __device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6]
 __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, const int n, const WbcConst &K, const int nc, const unsigned cpack, const bool bad_type,
                                                  const real *A, const real *JC, const real *qdd, const real *Cv, const real *Gv, const real *cm, real *W, int *sI,
                                                  float *__restrict__ g_tau, int *__restrict__ g_status, const int merge_tau, const int status_or, const int epilogue,
-                                                 long long *__restrict__ dbgT)
+                                                 long long *__restrict__ dbgT, float *__restrict__ g_qp)
 {
 #define QW_TSF(i) do { if (dbgT && (threadIdx.x & 63) == 0 && threadIdx.x < 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     int qp_iters = 0;
@@ -567,6 +567,13 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
 
     QW_TSF(8);
     if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + 10] = qp_iters;
+    // inspection (qrgpu_wbc_inspect_batch, instrumented build only): the QP's solution z (qpz, :113) and extraData->optimalFr = z_f + Fr_des (:216-218),
+    // stance feet in contact order, zero padded
+    if (g_qp) {
+        float *o = g_qp + (size_t)rid * 30;
+        if (lane < 18) o[lane] = (lane < nz) ? (float)qx[lane] : 0.f;
+        if (lane < 12) o[18 + lane] = (lane < dimFr) ? (float)(qx[6 + lane] + cm[51 + 3 * CLEG(lane / 3) + lane % 3]) : 0.f;
+    }
     // ---------------- GetSolution (:210-228) + store ----------------
     // qddot[0:6] += z[0:6];  tau = (A qddot + C + G - Jc^T (Fr_des + z_f))[6:18]
     if (lane < 12) {
@@ -606,10 +613,11 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    float *__restrict__ g_tau, float *__restrict__ g_qdes, int *__restrict__ g_status,
                    float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT,
                    const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */,
-                   int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */)
+                   int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */,
+                   float *__restrict__ g_qp /* [n][30] inspection: the relaxation QP's z[18] and optimalFr[12], or null */)
 {
 #ifndef QR_WBC_DBG_BUILD      // (the timed path's kernel carries neither the inspection outputs nor the cycle stamps: 2.5 % of its time; qr_wbc_kernel_dbg.hip
-    dbgT = nullptr; g_dbg = nullptr;      //  compiles this file once more with them in, as qr_wbc_kernel_dbg, for the launches that ask for either)
+    dbgT = nullptr; g_dbg = nullptr; g_qp = nullptr;      //  compiles this file once more with them in, as qr_wbc_kernel_dbg, for the launches that ask for either)
 #endif
 #define QW_TS(i) do { if (dbgT && threadIdx.x == 0) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
 #define QW_TS1(i) do { if (dbgT && threadIdx.x == 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
@@ -1229,7 +1237,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (t < nt - 1) npre_update(T2); else wsync();
     }
 
-    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or, epilogue, dbgT);
+    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or, epilogue, dbgT, g_qp);
 }
 
 }  // namespace qrgpu

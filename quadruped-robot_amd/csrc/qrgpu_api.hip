@@ -56,10 +56,10 @@ __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
-                              const float *g_fr, int type_ready, int epilogue);
+                              const float *g_fr, int type_ready, int epilogue, float *g_qp);
 __global__ void qr_wbc_kernel_dbg(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                                   float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
-                                  const float *g_fr, int type_ready, int epilogue);
+                                  const float *g_fr, int type_ready, int epilogue, float *g_qp);
 }
 
 // MPC kernel variants: 0 = <5, BIG, ., 512> (h <= 16), 1 = <9, BIG, ., 256> (h <= 16, A/B), 2 = <4, ., ., 256> (h <= 11, A/B), 3 = <2, ., ., 512> (h <= 11
@@ -570,7 +570,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 }
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
-                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0)
+                      float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
+                      float *d_qp = nullptr)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -581,9 +582,9 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     {
         TimerScope ts(c, 1);
         // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
-        hipLaunchKernelGGL((d_dbg || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
+        hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
-                           ready_mask(c->wbc_ready), epilogue);
+                           ready_mask(c->wbc_ready), epilogue, d_qp);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -618,6 +619,13 @@ int qrgpu_fb_debug_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float 
 {
     if (!d_out) return QRGPU_ERR_BAD_ARG;
     return launch_wbc(c, n, d_type_id, d_fb_state, nullptr, nullptr, nullptr, nullptr, nullptr, d_out, 0, 0);
+}
+
+int qrgpu_wbc_inspect_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_fb_state, const float *d_wbc_cmd,
+                            float *d_prev_ori, float *d_tau, float *d_qp, int *d_status)
+{
+    if (!d_qp) return QRGPU_ERR_BAD_ARG;
+    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, nullptr, d_status, nullptr, 0, 0, nullptr, 0, d_qp);
 }
 
 void qrgpu_estimator_desc_default(qrgpu_estimator_desc *d)

@@ -111,7 +111,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
-           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode"]
+           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch"]
 
 
 def load_library():
@@ -141,6 +141,7 @@ def load_library():
     lib.qrgpu_wbc_setup.argtypes = [vp, ip, C.POINTER(model_desc_struct)]
     lib.qrgpu_mpc_solve_batch.argtypes = [vp, ip] + [vp] * 8
     lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
+    lib.qrgpu_wbc_inspect_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 11
     lib.qrgpu_set_torque_epilogue.argtypes = [vp, ip]
     lib.qrgpu_comm_unique_id.argtypes = [C.c_char_p]
@@ -301,6 +302,11 @@ class Context:
     def wbc_run_batch(self, n, fb_state, wbc_cmd, prev_ori, tau, qdes=None, status=None, type_id=None):
         self._chk(self._lib.qrgpu_wbc_run_batch(self._h, n, _dp(type_id), _dp(fb_state), _dp(wbc_cmd), _dp(prev_ori), _dp(tau),
                                                 _dp(qdes), _dp(status)))
+
+    def wbc_inspect_batch(self, n, fb_state, wbc_cmd, prev_ori, tau, qp, status=None, type_id=None):
+        """wbc_run_batch plus the relaxation QP's solution: qp [n][30] = qpz[18], optimalFr[12] (instrumented kernel)."""
+        self._chk(self._lib.qrgpu_wbc_inspect_batch(self._h, n, _dp(type_id), _dp(fb_state), _dp(wbc_cmd), _dp(prev_ori), _dp(tau),
+                                                    _dp(qp), _dp(status)))
 
     def tick_batch(self, n, mpc_state, traj, gait, fb_state, wbc_cmd, prev_ori, force, tau, status=None, type_id=None, qdes=None):
         """qdes [24][n]: desiredJPos / desiredJVel of the kinematic projection (K12); None skips that projection."""

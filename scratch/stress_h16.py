@@ -39,6 +39,6 @@ for seed in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else 
         efw = (np.abs(ow["force"] - f).max(1) / np.maximum(1.0, np.abs(f).max(1)))[okw]; etw = (np.abs(ow["tau"] - tau) / np.maximum(1.0, np.abs(tau))).max(1)[okw]
         badw = int((efw > 1e-5).sum() + (etw > 1e-4).sum()); tot_flag += int(fw.sum()); tot_bad += badw
         print("h=16 seed %d excite %.1f: cold flagged %d %s (oracle nonzero %d), max rel force err %.2e, torque %.2e, over tol %d, iters max %d | warm flagged %d, force %.2e, torque %.2e, over tol %d, iters mean %.1f (cold %.1f)"
-              % (seed, ex, flags.sum(), np.uniqueG.flags(o["status"][flags]), (st != 0).sum(), ef.max(), et.max(), bad, ((o["status"] >> 8) & 0xffff).max(),
+              % (seed, ex, flags.sum(), np.unique(G.flags(o["status"][flags])), (st != 0).sum(), ef.max(), et.max(), bad, ((o["status"] >> 8) & 0xffff).max(),
                  fw.sum(), efw.max(), etw.max(), badw, ((ow["status"] >> 8) & 0xffff).mean(), ((o["status"] >> 8) & 0xffff).mean()), flush=True)
 print("TOTAL flagged %d over tolerance %d" % (tot_flag, tot_bad))

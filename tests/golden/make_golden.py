@@ -27,14 +27,19 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 def mpc_cases():
     rows = []
     # (the first five groups are round 1's 30 rows, unchanged; the h = 16 / full-range groups after them include rows on which the
-    # reference's qpOASES runs into its nWSR = 100 cap: qpoases_as_called_nwsr[0] == 100 or init_rc != 0 -- kept, and marked)
-    for robot, h, n, seed, excite in (("a1", 10, 12, 1001, 1.0), ("a1", 10, 6, 1002, 0.3), ("a1", 5, 4, 1003, 1.0),
-                                      ("a1", 16, 4, 1004, 0.3), ("lite3", 10, 4, 1005, 1.0),
-                                      ("a1", 16, 14, 1006, 1.0), ("lite3", 16, 6, 1007, 1.0), ("a1", 5, 4, 1008, 0.3), ("a1", 10, 8, 1009, 1.0)):
+    # reference's qpOASES runs into its nWSR = 100 cap: qpoases_as_called_nwsr[0] == 100 or init_rc != 0 -- kept, and marked.  The last
+    # group (round 3) is robots 0..23 of bench.py's own first batch -- make_batch(1024, seed = 0xA1 + 2, excite = 1.0), the 24 robots its
+    # config.parity_vs_reference_as_called figure is taken on -- so that the committed table covers what the bench line reports.)
+    groups = [("a1", 10, 12, 1001, 1.0, None), ("a1", 10, 6, 1002, 0.3, None), ("a1", 5, 4, 1003, 1.0, None),
+              ("a1", 16, 4, 1004, 0.3, None), ("lite3", 10, 4, 1005, 1.0, None),
+              ("a1", 16, 14, 1006, 1.0, None), ("lite3", 16, 6, 1007, 1.0, None), ("a1", 5, 4, 1008, 0.3, None), ("a1", 10, 8, 1009, 1.0, None),
+              ("a1", 10, 1024, 0xA1 + 2, 1.0, 24)]
+    for robot, h, n, seed, excite, take in groups:
         b = W.make_batch(n, h, robot, seed=seed, excite=excite)
         cfg = W.mpc_cfg(robot)
+        md = W.model_desc(robot)
         A = O.mpc_constraint_matrix(h)
-        for i in range(n):
+        for i in range(n if take is None else take):
             H, g, ub = O.mpc_assemble(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
             u, st, rc = O.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
             assert rc == 0
@@ -42,45 +47,76 @@ def mpc_cases():
             x_ref, info = O.ref_qpoases_mpc(Hd, gd, A, np.zeros(20 * h), ub, nWSR=100)          # as the reference calls it
             x_avg, info_avg = O.ref_qpoases_mpc(0.5 * (Hd + Hd.T), gd, A, np.zeros(20 * h), ub, nWSR=2000)   # converged, symmetric data
             x_t, info_t = O.ref_qpoases_mpc(Hd.T.copy(), gd, A, np.zeros(20 * h), ub, nWSR=2000)
+            # the same call on the same QP assembled by the OTHER fp32 route (Pade expm + repeated products as qr_mpc_interface.cpp:257-293
+            # evaluates them, restated in mpc_assemble_literal): a few ulps away in H and g, as another Eigen build of the reference would be
+            Hl, gl, _ = O.mpc_assemble(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i], literal=True)
+            x_lit, info_lit = O.ref_qpoases_mpc(Hl.astype(np.float64), gl.astype(np.float64), A, np.zeros(20 * h), ub, nWSR=100)
             assert info_avg["init_rc"] == 0
-            geom = W.model_desc(robot)[:3]
-            tau = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], u[:12])
-            tau_called = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], x_ref[:12])
-            tau_t = O.mpc_force_to_torque(geom, b["fb_state"][i, 0:4], b["fb_state"][i, 13:25], x_t[:12])
+            geom = md[:3]
+            fbs, cmd, prev = b["fb_state"][i], b["wbc_cmd"][i], b["prev_ori_vel"][i]
+            tq = lambda f12: O.mpc_force_to_torque(geom, fbs[0:4], fbs[13:25], f12)
+            # the metric's own quantity: the K14 torque of the FULL tick (MPC forces -> WBC with Fr_des := forces -> stance / swing merge,
+            # abad compensation, clip; qr_mpc_interface.cpp:428-438 -> qr_wbc_locomotion_controller.cpp:108-135 -> qr_fsm_state_locomotion.cpp:141-151),
+            # the WBC in float as the reference computes it
+            tk = lambda f12: O.tick_from_forces(geom, md, fbs, cmd, prev, f12, 1, 3)[0]
             rows.append(dict(robot=robot, h=h, cfg=cfg, mpc_state=b["mpc_state"][i], traj=b["traj"][i], gait=b["gait"][i],
-                             q=b["fb_state"][i, 13:25], quat=b["fb_state"][i, 0:4],
+                             q=fbs[13:25], quat=fbs[0:4], fb_state=fbs, wbc_cmd=cmd, prev=prev, model=md,
                              g=g, H_checksum=np.array([H.astype(np.float64).sum(), np.abs(H.astype(np.float64)).sum(), np.trace(Hd)]),
                              H_first_block=H[:12, :12].copy(),
                              f_oracle=u[:12].copy(), u_oracle_norm=np.array([np.linalg.norm(u)]),
                              f_qpoases_as_called=x_ref[:12].copy(), qpoases_as_called_nwsr=np.array([info["nWSR"], info["init_rc"]]),
                              f_qpoases_sym=x_avg[:12].copy(), u_qpoases_sym=x_avg.copy(), u_oracle=u.copy(),
-                             f_qpoases_transposed=x_t[:12].copy(), tau_oracle=tau, n_active=np.array([st["n_active"]]),
-                             tau_qpoases_as_called=tau_called, tau_qpoases_transposed=tau_t, excite=np.array([excite])))
+                             f_qpoases_transposed=x_t[:12].copy(), tau_oracle=tq(u[:12]), n_active=np.array([st["n_active"]]),
+                             f_qpoases_literal=x_lit[:12].copy(), qpoases_literal_nwsr=np.array([info_lit["nWSR"], info_lit["init_rc"]]),
+                             tau_qpoases_as_called=tq(x_ref[:12]), tau_qpoases_transposed=tq(x_t[:12]), tau_qpoases_literal=tq(x_lit[:12]),
+                             tau_tick_oracle=tk(u[:12]), tau_tick_as_called=tk(x_ref[:12]), tau_tick_transposed=tk(x_t[:12]),
+                             tau_tick_literal=tk(x_lit[:12]),
+                             tau_tick_oracle64=O.tick_from_forces(geom, md, fbs, cmd, prev, u[:12], 1, 3, wbc_fp64=True)[0],
+                             excite=np.array([excite]), bench_batch=np.array([0 if take is None else 1])))
     return rows
 
 
 def wbc_cases():
     rows = []
     rng = np.random.default_rng(77)
-    for robot, n, seed in (("a1", 12, 2001), ("lite3", 4, 2002)):
+    # (groups three and four, round 3: Fr_des := the MPC's own first-step forces, as the tick feeds the WBC -- qr_mpc_stance_leg_controller.cpp:408 --
+    # at SURVEY 8d's full excitation: the MPC's pyramid (mu = 0.45) is wider than the WBC's (0.4), so 0-7 inequality rows end up active)
+    for robot, n, seed, from_mpc in (("a1", 12, 2001, False), ("lite3", 4, 2002, False), ("a1", 24, 2003, True), ("lite3", 8, 2004, True)):
         b = W.make_batch(n, 10, robot, seed=seed)
         md = W.model_desc(robot)
         for i in range(n):
             cmd = b["wbc_cmd"][i].copy()
-            if i % 3 == 1:       # Fr_des on the MPC pyramid edge -> WBC inequalities bind
+            if from_mpc:
+                u, _, rc = O.mpc_solve(W.mpc_cfg(robot), 10, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+                assert rc == 0
+                cmd[51:63] = u[:12]
+            elif i % 3 == 1:       # Fr_des on the MPC pyramid edge -> WBC inequalities bind
                 fr = cmd[51:63].reshape(4, 3)
                 fr[:, 0] = 0.45 * fr[:, 2]; fr[:, 1] = -0.3 * fr[:, 2]
                 cmd[51:63] = fr.reshape(12)
-            if i % 4 == 3:
+            if not from_mpc and i % 4 == 3:
                 cmd[63:67] = (1, 1, 1, 1); cmd[51:63] = np.tile(np.array([2.0, -1.0, 33.0], np.float32), 4)
             prev = rng.uniform(-0.3, 0.3, 3).astype(np.float32)
             r64 = O.wbc_run(md, b["fb_state"][i].astype(np.float64), cmd.astype(np.float64), prev.astype(np.float64), dtype=np.float64)
             r32 = O.wbc_run(md, b["fb_state"][i], cmd, prev, dtype=np.float32)
             fb = O.fb_compute(md, b["fb_state"][i].astype(np.float64), np.float64)
-            rows.append(dict(robot=robot, model=md, fb_state=b["fb_state"][i], wbc_cmd=cmd, prev=prev,
-                             tau64=r64["tau"], tau32=r32["tau"], qdes64=r64["qdes"], qddes64=r64["qddes"], fr64=r64["fr"],
-                             H=fb["H"], G=fb["G"], C=fb["C"], Jc=fb["Jc"], Jcdqd=fb["Jcdqd"], pGC=fb["pGC"],
-                             n_active=np.array([r64["qp"]["n_active"]])))
+            row = dict(robot=robot, model=md, fb_state=b["fb_state"][i], wbc_cmd=cmd, prev=prev,
+                       tau64=r64["tau"], tau32=r32["tau"], qdes64=r64["qdes"], qddes64=r64["qddes"], fr64=r64["fr"],
+                       H=fb["H"], G=fb["G"], C=fb["C"], Jc=fb["Jc"], Jcdqd=fb["Jcdqd"], pGC=fb["pGC"],
+                       n_active=np.array([r64["qp"]["n_active"]]))
+            # The relaxation QP exactly as the tick assembles it (SetCost / SetEqualityConstraint / SetInequalityConstraint,
+            # qr_wholebody_impulse_ctrl.cpp:129-167, 232-247) solved by the reference's QuadProg++ as :113 calls it, and the tick finished with
+            # that z (GetSolution :210-228): `32` = assembled in float as the reference computes (then promoted to double for the solver, as
+            # qpG / qpCE / qpCI are), `64` = the same formulas in double (what the kernel evaluates).  G is diagonal: no H <-> H^T question here.
+            for tag, dt in (("32", np.float32), ("64", np.float64)):
+                q = O.wbc_qp(md, b["fb_state"][i], cmd, prev, dtype=dt)
+                z, fval = O.ref_quadprog(q["G"], q["g0"], q["CE"], q["ce0"], q["CI"], q["ci0"])
+                assert np.isfinite(fval)
+                fin = O.wbc_qp(md, b["fb_state"][i], cmd, prev, dtype=dt, z_in=z)
+                row.update({"qp%s_G" % tag: q["G"], "qp%s_g0" % tag: q["g0"], "qp%s_CE" % tag: q["CE"], "qp%s_ce0" % tag: q["ce0"],
+                            "qp%s_CI" % tag: q["CI"], "qp%s_ci0" % tag: q["ci0"], "z_oracle%s" % tag: q["z"], "z_quadprogpp%s" % tag: z,
+                            "f_quadprogpp%s" % tag: np.array([fval]), "tau_quadprogpp%s" % tag: fin["tau"], "fr_quadprogpp%s" % tag: fin["fr"]})
+            rows.append(row)
     return rows
 
 
@@ -166,29 +202,51 @@ def save(name, rows):
 
 def parity_table(rows):
     """Worst deviation of the oracle (= the kernel to 2e-6) from the reference's solver exactly as the reference calls it, per horizon,
-    over the rows on which that call converged; beside it the reference's own H <-> H^T ambiguity on the same rows.  -> dict, also
-    written to parity_as_called.json (the table of DESIGN.md 2)."""
+    over the rows on which that call converged: first-step forces, the MPC-only J^T f torque, and -- the metric's own quantity -- the K14
+    torque of the full tick.  Beside it how far the reference's OWN answer moves on the same rows when it is handed H^T (the same matrix up
+    to the fp32 rounding of its assembly), or the QP assembled by its other fp32 route (`literal`: a few ulps of H and g, as another Eigen
+    build would give).  The rows of bench.py's own batch also appear as a group of their own ("h10_bench_batch").  -> dict, also written to
+    parity_as_called.json (the tables of DESIGN.md 2)."""
     import json
     tab = {}
+
+    def rel_t(a, b):
+        return float((np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))).max())
+
     for r in rows:
         h = int(r["h"])
-        t = tab.setdefault(h, dict(rows=0, converged=0, nwsr_cap_or_failed=0, max_rel_force=0.0, max_rel_torque=0.0, ambiguity_rel_force=0.0,
-                                   ambiguity_rel_torque=0.0, rows_above_1e_4_torque=0))
-        t["rows"] += 1
+        keys = ["h%d" % h] + (["h%d_bench_batch" % h] if int(r["bench_batch"][0]) else [])
         nwsr, rc = int(r["qpoases_as_called_nwsr"][0]), int(r["qpoases_as_called_nwsr"][1])
-        if rc != 0 or nwsr >= 100:
-            t["nwsr_cap_or_failed"] += 1
-            continue
-        t["converged"] += 1
-        fs = max(1.0, np.abs(r["f_qpoases_as_called"]).max())
-        ef = np.abs(r["f_oracle"] - r["f_qpoases_as_called"]).max() / fs
-        et = (np.abs(r["tau_oracle"] - r["tau_qpoases_as_called"]) / np.maximum(1.0, np.abs(r["tau_qpoases_as_called"]))).max()
-        af = np.abs(r["f_qpoases_transposed"] - r["f_qpoases_as_called"]).max() / fs
-        at = (np.abs(r["tau_qpoases_transposed"] - r["tau_qpoases_as_called"]) / np.maximum(1.0, np.abs(r["tau_qpoases_as_called"]))).max()
-        t["max_rel_force"] = max(t["max_rel_force"], float(ef)); t["max_rel_torque"] = max(t["max_rel_torque"], float(et))
-        t["ambiguity_rel_force"] = max(t["ambiguity_rel_force"], float(af)); t["ambiguity_rel_torque"] = max(t["ambiguity_rel_torque"], float(at))
-        t["rows_above_1e_4_torque"] += int(et > 1e-4)
-    out = {"h%d" % h: tab[h] for h in sorted(tab)}
+        for key in keys:
+            t = tab.setdefault(key, dict(rows=0, converged=0, nwsr_cap_or_failed=0, max_rel_force=0.0, max_rel_torque=0.0, max_rel_tick_torque=0.0,
+                                         ambiguity_rel_force=0.0, ambiguity_rel_torque=0.0, ambiguity_rel_tick_torque=0.0,
+                                         literal_route_rel_force=0.0, literal_route_rel_torque=0.0, literal_route_rel_tick_torque=0.0, literal_route_rows=0,
+                                         rows_above_1e_4_torque=0, rows_above_1e_4_tick_torque=0, reference_rows_above_1e_4_tick_torque_between_its_routes=0))
+            t["rows"] += 1
+            if rc != 0 or nwsr >= 100:
+                t["nwsr_cap_or_failed"] += 1
+                continue
+            t["converged"] += 1
+            fc = r["f_qpoases_as_called"]
+            fs = max(1.0, np.abs(fc).max())
+            ef = np.abs(r["f_oracle"] - fc).max() / fs
+            et = rel_t(r["tau_oracle"], r["tau_qpoases_as_called"])
+            ek = rel_t(r["tau_tick_oracle"], r["tau_tick_as_called"])
+            t["max_rel_force"] = max(t["max_rel_force"], float(ef)); t["max_rel_torque"] = max(t["max_rel_torque"], et)
+            t["max_rel_tick_torque"] = max(t["max_rel_tick_torque"], ek)
+            t["ambiguity_rel_force"] = max(t["ambiguity_rel_force"], float(np.abs(r["f_qpoases_transposed"] - fc).max() / fs))
+            t["ambiguity_rel_torque"] = max(t["ambiguity_rel_torque"], rel_t(r["tau_qpoases_transposed"], r["tau_qpoases_as_called"]))
+            t["ambiguity_rel_tick_torque"] = max(t["ambiguity_rel_tick_torque"], rel_t(r["tau_tick_transposed"], r["tau_tick_as_called"]))
+            t["rows_above_1e_4_torque"] += int(et > 1e-4); t["rows_above_1e_4_tick_torque"] += int(ek > 1e-4)
+            lw, lrc = int(r["qpoases_literal_nwsr"][0]), int(r["qpoases_literal_nwsr"][1])
+            if lrc == 0 and lw < 100:
+                t["literal_route_rows"] += 1
+                t["literal_route_rel_force"] = max(t["literal_route_rel_force"], float(np.abs(r["f_qpoases_literal"] - fc).max() / fs))
+                t["literal_route_rel_torque"] = max(t["literal_route_rel_torque"], rel_t(r["tau_qpoases_literal"], r["tau_qpoases_as_called"]))
+                lk = rel_t(r["tau_tick_literal"], r["tau_tick_as_called"])
+                t["literal_route_rel_tick_torque"] = max(t["literal_route_rel_tick_torque"], lk)
+                t["reference_rows_above_1e_4_tick_torque_between_its_routes"] += int(lk > 1e-4)
+    out = {k: tab[k] for k in sorted(tab)}
     json.dump(out, open(os.path.join(OUT, "parity_as_called.json"), "w"), indent=1)
     return out
 
@@ -215,6 +273,9 @@ def nwsr_cap_census(n=40):
 
 if __name__ == "__main__":
     assert O.ref() is not None, "oracle/_ref is required to generate fixtures"
+    if len(sys.argv) > 1 and sys.argv[1] == "wbc":
+        save("wbc_golden.npz", wbc_cases())
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mpc":          # only the MPC fixture and the artefacts derived from it
         rows = mpc_cases()
         save("mpc_golden.npz", rows)

@@ -87,6 +87,26 @@ def run_wbc(ctx, pkg, b, wbc_cmd=None, prev=None, want_qdes=True, type_id=None):
     return out
 
 
+def run_wbc_inspect(ctx, pkg, b, wbc_cmd=None, prev=None, type_id=None):
+    """qrgpu_wbc_inspect_batch: the WBC tick plus its relaxation QP's solution.  -> tau[n,12], z[n,18], fr[n,12] (optimalFr), status"""
+    n = b["n"]
+    S = pkg.to_soa
+    cmd = b["wbc_cmd"] if wbc_cmd is None else wbc_cmd
+    prev = b["prev_ori_vel"] if prev is None else prev
+    d = dict(state=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(cmd)), prev=ctx.alloc((3, n)).upload(S(prev)),
+             tau=ctx.alloc((12, n)), qp=ctx.alloc((n, 30)).upload(np.full((n, 30), np.nan, np.float32)), status=ctx.alloc((n,), np.int32))
+    tid = ctx.alloc((n,), np.int32).upload(type_id) if type_id is not None else None
+    ctx.wbc_inspect_batch(n, d["state"], d["cmd"], d["prev"], d["tau"], d["qp"], d["status"], tid)
+    ctx.sync()
+    qp = d["qp"].download()
+    out = dict(tau=d["tau"].download().T.copy(), z=qp[:, :18].copy(), fr=qp[:, 18:].copy(), status=d["status"].download())
+    for v in d.values():
+        v.free()
+    if tid is not None:
+        tid.free()
+    return out
+
+
 def run_fb_debug(ctx, pkg, b, type_id=None):
     n = b["n"]
     state = ctx.alloc((37, n)).upload(pkg.to_soa(b["fb_state"]))

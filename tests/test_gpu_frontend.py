@@ -112,7 +112,7 @@ def test_frontend_sequence_feeds_tick(gpu_ctx, pkg, oracle):
     gpu_ctx.tick_batch(n, d["state"], d_traj, d_gait, d["fb"], d_cmd, d["prev"], d["force"], d["tau"], d["status"])
     gpu_ctx.sync()
     tau = d["tau"].download().T; status = d["status"].download()
-    assert np.all(G.flags(status) == 0), np.uniqueG.flags(status)
+    assert np.all(G.flags(status) == 0), np.unique(G.flags(status))
     f_o, tau_o, st_o, _, _ = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
                                                g_traj, g_gait, b["fb_state"], g_cmd, b["prev_ori_vel"].copy(), nthreads=4)
     assert np.all(st_o == 0)

@@ -43,7 +43,7 @@ def test_mpc_parity(gpu_ctx, pkg, oracle, horizon, n, seed):
     G.setup_a1(gpu_ctx, pkg, horizon)
     b = pkg.make_batch(n, horizon, "a1", seed=seed)
     out = G.run_mpc(gpu_ctx, pkg, b)
-    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+    assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
     f, tau = _oracle_forces(oracle, pkg, b)
     fmax = np.abs(f).max(axis=1, keepdims=True)
     assert np.abs(out["force"] - f).max() <= 1e-5 * max(1.0, np.abs(f).max()), np.abs(out["force"] - f).max()
@@ -154,7 +154,7 @@ def test_beyond_64_rows_goes_through_the_list_pass(gpu_ctx, pkg, oracle):
     finally:
         gpu_ctx.set_rescue_pass(True)
     out = G.run_mpc(gpu_ctx, pkg, b)
-    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+    assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
     cfg = pkg.mpc_cfg("a1")
     big = 0
     for i in range(96):
@@ -206,7 +206,7 @@ def test_h16_beyond_64_rows_stays_in_the_multi_wave_loop(gpu_ctx, pkg, oracle):
     try:
         b = pkg.make_batch(n, h, "a1", seed=0xA1 + 2, excite=1.0)
         out = G.run_mpc(gpu_ctx, pkg, b)
-        assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+        assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
         it = G.iterations(out["status"])
         cfg = pkg.mpc_cfg("a1")
         cand = list(np.argsort(-it)[:24]) + list(range(0, n, 37))
@@ -241,7 +241,7 @@ def test_rescue_pass_lds_limited_robots(gpu_ctx, pkg, oracle):
         out = G.run_mpc(gpu_ctx, pkg, b)
         out2 = G.run_mpc(gpu_ctx, pkg, b)                 # second call: the ping-pong counters
     assert 0 < flagged.sum() <= 64, "the batch must exercise the overflow path"
-    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+    assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
     assert np.array_equal(out["force"], out2["force"]) and np.array_equal(out["status"], out2["status"])
     cfg = pkg.mpc_cfg("a1")
     for i in np.where(flagged)[0]:

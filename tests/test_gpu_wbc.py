@@ -136,7 +136,7 @@ def test_full_tick(gpu_ctx, pkg, oracle):
     G.setup_a1(gpu_ctx, pkg, 10)
     b = pkg.make_batch(128, 10, "a1", seed=0xA4)
     out = G.run_tick(gpu_ctx, pkg, b)
-    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+    assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
     f, tau, st, sec, prev = oracle.tick_batch(1, pkg.mpc_cfg("a1"), 10, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"],
                                               b["traj"], b["gait"], b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=4)
     assert np.all(st == 0)
@@ -157,7 +157,7 @@ def test_full_tick_h16_mixed_a1_lite3(gpu_ctx, pkg, oracle):
     b["n"] = n
     tid = pkg.shard.interleave_types(n, 2)
     out = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
-    assert np.all(G.flags(out["status"]) == 0), np.uniqueG.flags(out["status"])
+    assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
     for i in range(n):
         robot = "a1" if tid[i] == 0 else "lite3"
         u, st, rc = oracle.mpc_solve(pkg.mpc_cfg(robot), h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
@@ -194,8 +194,13 @@ def test_full_tick_1024_with_projection_and_motor_tail(gpu_ctx, pkg, oracle):
     swing = b["wbc_cmd"][:, 63:67] == 0
     comp = np.array([-0.9, 0.9, -0.9, 0.9], np.float32)
     assert np.array_equal(out["tau"][:, 0::3][swing], np.broadcast_to(comp, swing.shape)[swing])
-    # K12 outputs: the fp32 oracle's pseudo-inverses against the kernel's fp64 ones
+    # K12 outputs: against the oracle's tick in DOUBLE (the kernel's arithmetic) 1e-5 rad, as test_wbc_golden holds its 16 robots
+    # (the fp32 oracle's pseudo-inverses are only good for 2e-3 here)
     assert np.abs(out["qdes"] - qdes).max() <= 2e-3
+    md = pkg.model_desc("a1")
+    q64 = np.stack([oracle.tick_from_forces(md[:3], md, b["fb_state"][i], b["wbc_cmd"][i], b["prev_ori_vel"][i], f[i].astype(np.float64), 1, 3,
+                                            wbc_fp64=True, want_qdes=True)[2] for i in range(1024)])
+    assert np.abs(out["qdes"] - q64).max() <= 1e-5, np.abs(out["qdes"] - q64).max()
     assert np.array_equal(out["prev"], prev)
 
 

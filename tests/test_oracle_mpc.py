@@ -73,7 +73,7 @@ def test_golden_mpc_vs_reference_qpoases(oracle, pkg):
       * exactly as the reference calls it (fp32-asymmetric H, nWSR=100): agreement only within the
         reference's own ambiguity, measured by handing qpOASES H' instead of H."""
     rows = golden_io.load("mpc_golden.npz")
-    assert len(rows) == 62
+    assert len(rows) == 86          # 62 of rounds 1-2 + robots 0..23 of bench.py's own first batch (round 3)
     worst_sym, worst_called, worst_ambig = 0.0, 0.0, 0.0
     n_cap = 0
     for r in rows:
@@ -108,16 +108,40 @@ def test_golden_mpc_vs_reference_qpoases(oracle, pkg):
     assert n_cap == 5                   # rows of the fixture on which the reference's call ran into its nWSR = 100 cap (all at h = 16)
 
 
-def test_parity_table_matches_fixture(oracle):
-    """tests/golden/parity_as_called.json (the table of DESIGN.md 2) is what the fixture's rows give."""
+def test_parity_table_matches_fixture(oracle, pkg):
+    """tests/golden/parity_as_called.json (the tables of DESIGN.md 2) is what the fixture's rows give -- first-step forces, the MPC-only J^T f
+    torque and the full tick's K14 torque (the metric's own quantity), the latter recomputed here through the oracle's tick tail from the
+    stored forces -- and says what it is quoted for: against the reference's solver AS CALLED the 1e-4 relative torque of north_star is not
+    met (3.6e-2 on bench.py's own batch), and is not met by the reference against itself either: handed the same QP assembled by its other
+    fp32 route (a few ulps of H and g) its own full-tick torque moves by up to 4e-2, beyond 1e-4 on more rows than ours."""
     import json, os
     tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_as_called.json")))
     rows = golden_io.load("mpc_golden.npz")
-    for h in (5, 10, 16):
-        rs = [r for r in rows if int(r["h"]) == h and int(r["qpoases_as_called_nwsr"][1]) == 0 and int(r["qpoases_as_called_nwsr"][0]) < 100]
+    rel_t = lambda a, b: float((np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))).max())
+    for key, sel in (("h5", lambda r: int(r["h"]) == 5), ("h10", lambda r: int(r["h"]) == 10), ("h16", lambda r: int(r["h"]) == 16),
+                     ("h10_bench_batch", lambda r: int(r["bench_batch"][0]) == 1)):
+        rs = [r for r in rows if sel(r) and int(r["qpoases_as_called_nwsr"][1]) == 0 and int(r["qpoases_as_called_nwsr"][0]) < 100]
         wf = max(np.abs(r["f_oracle"] - r["f_qpoases_as_called"]).max() / max(1.0, np.abs(r["f_qpoases_as_called"]).max()) for r in rs)
-        assert abs(wf - tab["h%d" % h]["max_rel_force"]) <= 1e-12 and tab["h%d" % h]["converged"] == len(rs)
-    assert tab["h10"]["max_rel_force"] < 3.2e-4 and tab["h16"]["max_rel_force"] < 1.3e-3
+        assert abs(wf - tab[key]["max_rel_force"]) <= 1e-12 and tab[key]["converged"] == len(rs)
+        wk = 0.0
+        for r in rs:
+            geom, md = r["model"][:3], r["model"]
+            for name, f in (("tau_tick_oracle", r["f_oracle"]), ("tau_tick_as_called", r["f_qpoases_as_called"]), ("tau_tick_transposed", r["f_qpoases_transposed"])):
+                t, _ = oracle.tick_from_forces(geom, md, r["fb_state"], r["wbc_cmd"], r["prev"], f, 1, 3)
+                assert np.array_equal(t, r[name]), (key, name)
+            wk = max(wk, rel_t(r["tau_tick_oracle"], r["tau_tick_as_called"]))
+            # the full tick's torque in the kernel's arithmetic (WBC in double) is the float one to the fp32 oracle's own 1e-4 bar
+            assert np.all(np.abs(r["tau_tick_oracle64"] - r["tau_tick_oracle"]) <= 1e-4 * np.maximum(1.0, np.abs(r["tau_tick_oracle"])))
+        assert abs(wk - tab[key]["max_rel_tick_torque"]) <= 1e-12
+    assert tab["h10_bench_batch"]["rows"] == 24 and tab["h10_bench_batch"]["converged"] == 24
+    assert 2e-3 < tab["h10"]["max_rel_force"] < 3e-3 and tab["h16"]["max_rel_force"] < 1.3e-3      # (h = 10: bench.py's batch is the worst group, 2.6e-3)
+    # what the statement of DESIGN.md 2 rests on
+    for key in ("h10", "h16"):
+        t = tab[key]
+        assert t["max_rel_tick_torque"] > 1e-4                                          # north_star's bar is missed against the as-called answer ...
+        assert t["max_rel_tick_torque"] <= 0.55 * t["ambiguity_rel_tick_torque"]        # ... by half the reference's own H <-> H^T spread ...
+        assert t["literal_route_rel_tick_torque"] > 1e-2                                # ... and the reference misses it against itself by more,
+        assert t["reference_rows_above_1e_4_tick_torque_between_its_routes"] >= t["rows_above_1e_4_tick_torque"]    # on at least as many rows
 
 
 def test_live_qpoases_symmetric(ref, pkg):

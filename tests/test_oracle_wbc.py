@@ -76,7 +76,7 @@ def test_wbc_satisfies_floating_base_dynamics(oracle, pkg):
 
 def test_golden_wbc(oracle):
     rows = golden_io.load("wbc_golden.npz")
-    assert len(rows) == 16
+    assert len(rows) == 48
     active = 0
     for r in rows:
         w = oracle.wbc_run(r["model"], r["fb_state"].astype(np.float64), r["wbc_cmd"].astype(np.float64),
@@ -108,3 +108,43 @@ def test_motor_tail_of_the_tick(oracle, pkg):
     _, m0, _, _, _ = oracle.tick_batch(0, *args, b["prev_ori_vel"].copy())
     _, m1, _, _, _ = oracle.tick_batch(0, *args, b["prev_ori_vel"].copy(), epilogue=1)
     assert np.array_equal(m1, (m0.astype(np.float64) + comp).astype(np.float32))
+
+
+def test_relaxation_qp_as_called_vs_compiled_quadprogpp():
+    """wbc_golden.npz holds, per case, the relaxation QP exactly as the tick assembles it (qr_wholebody_impulse_ctrl.cpp:129-167, 232-247; float
+    and double assembly) with z from the reference's QuadProg++ called as :113 calls it, and tau / optimalFr of the tick finished with that z.
+    The oracle re-assembles the same QP bit for bit, its own solver lands on QuadProg++'s z (G is diagonal and positive: one optimum, no
+    H <-> H^T question), and so do its torques."""
+    import golden_io
+    import oracle_py as O
+    rows = golden_io.load("wbc_golden.npz")
+    assert len(rows) == 48
+    active = 0
+    for r in rows:
+        md = r["model"]
+        for tag, dt in (("32", np.float32), ("64", np.float64)):
+            q = O.wbc_qp(md, r["fb_state"], r["wbc_cmd"], r["prev"], dtype=dt)
+            for k in ("G", "g0", "CE", "ce0", "CI", "ci0"):
+                assert np.array_equal(q[k], r["qp%s_%s" % (tag, k)]), (tag, k)
+            assert np.allclose(np.diag(np.diag(q["G"])), q["G"]) and np.all(np.diag(q["G"]) > 0)
+            zs = max(1.0, np.abs(r["z_quadprogpp%s" % tag]).max())
+            assert np.abs(q["z"] - r["z_quadprogpp%s" % tag]).max() <= 1e-10 * zs
+            assert np.all(np.abs(q["tau"].astype(np.float64) - r["tau_quadprogpp%s" % tag]) <= 1e-6 * np.maximum(1.0, np.abs(r["tau_quadprogpp%s" % tag])))
+            assert np.all(np.abs(q["fr"].astype(np.float64) - r["fr_quadprogpp%s" % tag]) <= 1e-6 * np.maximum(1.0, np.abs(r["fr_quadprogpp%s" % tag])))
+            fin = O.wbc_qp(md, r["fb_state"], r["wbc_cmd"], r["prev"], dtype=dt, z_in=r["z_quadprogpp%s" % tag])
+            assert np.array_equal(fin["tau"], r["tau_quadprogpp%s" % tag]) and np.array_equal(fin["fr"], r["fr_quadprogpp%s" % tag])
+        active += int(r["n_active"][0]) > 0
+    assert active >= 24           # the MPC-fed cases end with up to 7 inequality rows active
+
+
+def test_live_quadprogpp_on_the_wbc_qp(ref, pkg):
+    """The same against the compiled QuadProg++ itself (oracle/_ref, build container only) on fresh tick-fed cases."""
+    O = ref
+    b = pkg.make_batch(16, 10, "a1", seed=2077)
+    md, cfg = pkg.model_desc("a1"), pkg.mpc_cfg("a1")
+    for i in range(16):
+        u, _, rc = O.mpc_solve(cfg, 10, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+        cmd = b["wbc_cmd"][i].copy(); cmd[51:63] = u[:12]
+        q = O.wbc_qp(md, b["fb_state"][i], cmd, b["prev_ori_vel"][i], dtype=np.float32)
+        z, fval = O.ref_quadprog(q["G"], q["g0"], q["CE"], q["ce0"], q["CI"], q["ci0"])
+        assert np.isfinite(fval) and np.abs(z - q["z"]).max() <= 1e-10 * max(1.0, np.abs(z).max())
