@@ -2,7 +2,8 @@
 """Headline benchmark: MPC+WBC control ticks/s over a batch of A1 robots (BASELINE.json configs[2]:
 1024 A1 instances, horizon 10, full MPC+WBC tick per robot), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: this process starts N rank processes itself and never
+                                                          touches a GPU; any rank failing makes it exit non-zero -- it never falls back to 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one qrgpu_tick_batch over this rank's 1024 robots -- K1-K14 of SURVEY.md 8(a): MPC, then WBC with the kinematic projection
@@ -17,9 +18,13 @@ sequence (the same robots 0.03 s later: workload.make_batch_sequence, 8 batches 
 and its share of the K timed steps, bracketed by barrier + synchronize; `value` is the MEDIAN over the draws of the draw's rate (max
 over ranks of its time), min / max / per-draw rates beside it.
 
-torch is plumbing only (device buffers, the launch stream, torch.distributed's CPU backend for the launcher's barrier / max-reduce
-and for handing rank 0's communicator id to the other ranks); the tick and the collective are behind the C ABI of include/qrgpu.h.
-Rank 0 prints ONE JSON line.
+No GPU array library is involved: device buffers, pinned host buffers, the stream, event timing and the collective are all behind the C
+ABI of include/qrgpu.h (qrgpu_malloc, qrgpu_host_alloc, qrgpu_enable_timing, qrgpu_mark, qrgpu_allgather_tau).  With N = 1 torch is
+not imported at all; with N > 1 torch.distributed's CPU backend (gloo) is the launcher's plumbing -- barrier, max-reduce of the draw
+times, handing rank 0's 128-byte communicator id to the other ranks.  Rank 0 prints ONE JSON line.
+
+  python bench.py --mode single     the drop-in boundary's single-robot latency (qrgpu_mpc_solve1 / qrgpu_wbc_run1, and both through the C++
+                                    adapters): p50 / p99 over 1000 calls at h = 5, 10, 16 beside the reference's solver on the same QPs
 """
 import argparse
 import importlib.util
@@ -119,22 +124,42 @@ def reference_solver(pkg, O, b, horizon, sample=24):
                                       "%d QPs of the bench batch, one thread (the port's time includes its fp32 assembly)" % idx.size)
 
 
-def side_mode(args, pkg, ctx, torch, dev, stream):
+class Dev:
+    """Device-buffer helpers over the package's own allocator (qrgpu_malloc / qrgpu_memcpy_*): what torch used to be asked for."""
+
+    def __init__(self, pkg, ctx):
+        self.pkg, self.ctx = pkg, ctx
+
+    def soa(self, a):
+        """robot-major host array [n][f] -> device array [f][n]"""
+        h = self.pkg.to_soa(a)
+        return self.ctx.alloc(h.shape, h.dtype).upload(h)
+
+    def zeros(self, shape, dtype=np.float32):
+        return self.ctx.alloc(shape, dtype).upload(np.zeros(shape, dtype))
+
+    def put(self, a):
+        a = np.ascontiguousarray(a)
+        return self.ctx.alloc(a.shape, a.dtype).upload(a)
+
+
+def side_mode(args, pkg, ctx):
     """The SURVEY 8f rows on one GPU: `vmc` = force-balance stance QP (ComputeContactForce), `frontend` = MPC front-end
-    (SetupCommand/Run/UpdateMPC).  A step = one batched call over --robots robots; kernel time by events on the launch stream."""
+    (SetupCommand/Run/UpdateMPC).  A step = one batched call over --robots robots; kernel time by marks on the launch stream."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     O.build()
     n, h = args.robots, args.horizon
-    T = lambda a: torch.from_numpy(pkg.to_soa(a)).to(dev)
+    D_ = Dev(pkg, ctx)
+    T = D_.soa
     W = pkg.workload
     if args.mode == "vmc":
         cfg, geom = W.vmc_cfg("a1"), pkg.model_desc("a1")[:3]
         ctx.vmc_setup_packed(0, cfg, geom)
         vin, q = W.make_vmc_batch(n, seed=0xB2)
         d_in, d_q = T(vin), T(q)
-        d_f, d_t = torch.empty((12, n), dtype=torch.float32, device=dev), torch.empty((12, n), dtype=torch.float32, device=dev)
-        d_s = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_f, d_t = D_.zeros((12, n)), D_.zeros((12, n))
+        d_s = D_.zeros((n,), np.int32)
         step = lambda: ctx.vmc_force_batch(n, d_in, d_q, d_f, d_t, d_s)
         cpu = lambda i: O.vmc_solve(cfg, geom, vin[i], q[i])
         alg_bytes = (37 + 12 + 12 + 12 + 1) * 4
@@ -144,10 +169,10 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
     elif args.mode == "estimator":
         cfg = W.estimator_cfg("a1")
         xs, stamps = W.make_estimator_sequence(n, 4, seed=0xE5)
-        d_in = T(xs[0]); d_tick = torch.from_numpy(stamps[0].astype(np.int64)).to(dev).to(torch.int32)
+        d_in = T(xs[0]); d_tick = D_.put(stamps[0].astype(np.int32))
         S_ = ctx.estimator_state_doubles(int(cfg[6]))
-        d_state = torch.zeros((S_, n), dtype=torch.float64, device=dev)
-        d_out = torch.zeros((EST_OUT_ROWS, n), dtype=torch.float32, device=dev)          # QRGPU_EST_OUT_ROWS of include/qrgpu.h
+        d_state = D_.zeros((S_, n), np.float64)
+        d_out = D_.zeros((EST_OUT_ROWS, n))          # QRGPU_EST_OUT_ROWS of include/qrgpu.h
         step = lambda: ctx.estimator_update_batch(n, cfg, d_in, d_tick, d_state, d_out)
         seq = np.repeat(xs[0][None, :1], 200, 0)[:, 0]
         cpu_all = lambda: O.estimator_run(cfg, seq, (1000 + 2 * np.arange(200)).astype(np.uint32))
@@ -159,8 +184,8 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
     else:
         vin, st = W.make_frontend_batch(n, seed=0xFE)
         d_in, d_st = T(vin), T(st)
-        d_traj = torch.zeros((12 * h, n), dtype=torch.float32, device=dev); d_gait = torch.zeros((4 * h, n), dtype=torch.float32, device=dev)
-        d_cmd = torch.zeros((67, n), dtype=torch.float32, device=dev); d_u = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_traj, d_gait = D_.zeros((12 * h, n)), D_.zeros((4 * h, n))
+        d_cmd, d_u = D_.zeros((67, n)), D_.zeros((n,), np.int32)
         step = lambda: ctx.mpc_frontend_batch(n, d_in, d_st, d_traj, d_gait, d_cmd, d_u)
         cpu = lambda i: O.mpc_frontend(h, 2, vin[i], st[i])
         alg_bytes = (64 + 8 + 8 + 16 * h + 19 + 1) * 4
@@ -168,16 +193,15 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
         alg_flop = 0
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.sync()
     t0 = time.perf_counter()
-    e0.record(stream)
+    ctx.mark(0)
     for _ in range(args.steps):
         step()
-    e1.record(stream)
-    torch.cuda.synchronize()
+    ctx.mark(1)
+    ctx.sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps
+    kernel_ms = ctx.mark_elapsed_ms(0, 1) / args.steps
     # CPU restatement, one thread, bounded sample
     m = min(n, 2000)
     c0 = time.perf_counter()
@@ -204,6 +228,163 @@ def side_mode(args, pkg, ctx, torch, dev, stream):
     return out
 
 
+def _pct(us):
+    us = np.sort(np.asarray(us, np.float64))
+    return dict(p50_us=float(us[us.size // 2]), p99_us=float(us[(us.size * 99) // 100]), mean_us=float(us.mean()), min_us=float(us[0]), calls=int(us.size))
+
+
+def single_mode(args, pkg):
+    """The drop-in boundary's real caller is ONE robot per process with a 1 ms tick budget at the reference's 500 Hz control rate (dt = 0.002 s;
+    the MPC re-solves every 15th tick, qr_mpc_stance_leg_controller.cpp:342; the WBC runs on every other of the remaining ticks,
+    qr_wbc_locomotion_controller.cpp:111).  Latency of qrgpu_mpc_solve1 and qrgpu_wbc_run1 -- host arrays in, one launch, host arrays out --
+    per call, p50 / p99 over `--steps` calls (>= 1000) at h = 5 (the reference's hard-coded planning horizon,
+    qr_mpc_stance_leg_controller.cpp:42), 10 and 16: (a) through the Python mirror of the reference interface (ctypes: a few us of
+    interpreter per call on top), (b) through the C++ adapters of include/qrgpu_adapters.hpp in a compiled program (tests/stubs/adapter_demo
+    --latency), which is what a maintainer's build would run.  Beside them the reference's own solver (qpOASES 3.2.0 from the reference tree, as
+    called) and the port's CPU tick on the same inputs, one thread."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build()
+    calls = max(1000, args.steps)
+    so = pkg._build.build()
+    exe = os.path.join(ROOT, "tests", "stubs", "adapter_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "stubs"),
+                           os.path.join(ROOT, "tests", "stubs", "adapter_demo.cpp"), "-o", exe, so, "-Wl,-rpath," + os.path.dirname(so)])
+    cfg, md = pkg.mpc_cfg("a1"), pkg.model_desc("a1")
+    res = {}
+    for h in (5, 10, 16):
+        ctx = pkg.Context(device_id=0, max_batch=1, horizon_max=16)
+        mpc = pkg.MPCInterface(ctx, 0)
+        mpc.SetupProblem(cfg[0], h, cfg[1], cfg[2], cfg[3], cfg[4:7], cfg[7:19], cfg[19])
+        ctx.wbc_setup_packed(0, md)
+        b = pkg.make_batch(16, h, "a1", seed=0x51 + h, excite=args.excite)
+        r = {}
+        # (a) Python mirror: 16 different robots round robin (a fresh QP every call; the warm start sees another robot's working set)
+        for kind in ("mpc", "wbc"):
+            us = []
+            prev = np.zeros(3, np.float32)
+            for it in range(calls + 20):
+                i = it % 16
+                s_ = b["mpc_state"][i]
+                t0 = time.perf_counter()
+                if kind == "mpc":
+                    mpc.SolveMPCKernel(s_[0:3], s_[3:6], s_[6:10], s_[10:13], s_[13:25].reshape(4, 3).T, s_[25:28], b["traj"][i], b["gait"][i])
+                else:
+                    ctx.wbc_run1(b["fb_state"][i], b["wbc_cmd"][i], prev)
+                dt_ = time.perf_counter() - t0
+                if it >= 20:
+                    us.append(1e6 * dt_)
+            r["python_%s" % kind] = _pct(us)
+        ctx.close()
+        # (b) the C++ adapters, robot 0's inputs on every call (the working set of the last call is this call's warm start, as on a real robot
+        # between two MPC ticks 0.03 s apart)
+        vals = [h] + list(cfg) + list(b["mpc_state"][0]) + list(b["traj"][0]) + list(b["gait"][0]) + list(b["fb_state"][0]) + list(b["wbc_cmd"][0])
+        inp = " ".join(repr(float(v)) if not isinstance(v, int) else str(v) for v in vals)
+        out = subprocess.run([exe, "--latency", str(calls)], input=inp.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if out.returncode != 0:
+            raise RuntimeError("adapter_demo failed: %s" % out.stderr.decode())
+        for line in out.stdout.decode().splitlines():
+            w = line.split()
+            if w and w[0] in ("latency_mpc_us", "latency_wbc_us"):
+                r["adapters_%s" % w[0][8:11]] = dict(p50_us=float(w[1]), p99_us=float(w[2]), mean_us=float(w[3]), min_us=float(w[4]), calls=calls)
+        # the CPU side on the same 16 QPs, one thread
+        A = O.mpc_constraint_matrix(h, float(cfg[1]))
+        t_ref = t_port = t_wbc = 0.0
+        capped = 0
+        for i in range(16):
+            H, g, ub = O.mpc_assemble(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+            if O.ref() is not None:
+                t0 = time.perf_counter()
+                x, info = O.ref_qpoases_mpc(H.astype(np.float64), g.astype(np.float64), A, np.zeros(20 * h), ub.astype(np.float64), 100)
+                t_ref += time.perf_counter() - t0
+                capped += int(info["nWSR"] >= 100 or info["init_rc"] != 0)
+            t0 = time.perf_counter()
+            O.mpc_solve(cfg, h, b["mpc_state"][i], b["traj"][i], b["gait"][i])
+            t_port += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            O.wbc_run(md, b["fb_state"][i], b["wbc_cmd"][i], dtype=np.float32)
+            t_wbc += time.perf_counter() - t0
+        r["cpu"] = dict(reference_qpoases_as_called_ms=(1e3 * t_ref / 16) if O.ref() is not None else None, reference_hit_nwsr_100=capped,
+                        port_mpc_assemble_solve_ms=1e3 * t_port / 16, port_wbc_tick_ms=1e3 * t_wbc / 16)
+        res["h%d" % h] = r
+    a10 = res["h10"]["adapters_mpc"]
+    out = {"metric": "single-robot MPC solve latency through the drop-in adapters, h = 10 (p50)", "value": a10["p50_us"], "unit": "us", "n_gpus": 1,
+           "steps": calls, "warmup": 20, "ms_per_step": a10["mean_us"] * 1e-3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 assembly / f64 QP+WBC", "data": "synthetic",
+           "config": {"workload": "ONE A1 robot per call through qrgpu_mpc_solve1 / qrgpu_wbc_run1 (host arrays in and out, one launch, synchronised): the reference's "
+                                  "own calling pattern", "calls": calls, "excite": args.excite,
+                      "staging": "zero copy: pinned, mapped host block read and written by the kernel in place" if os.environ.get("QRGPU_SINGLE_COPIES", "0") in ("", "0")
+                                 else "three hipMemcpyAsync per call (QRGPU_SINGLE_COPIES=1)",
+                      "latency": res,
+                      "tick_budget_us": 1000.0,
+                      "budget_note": "the reference's control tick is 2 ms of simulated time but its README quotes a 1 kHz-class loop; every figure here is to be read "
+                                     "against 1000 us per tick"},
+           "roofline": {"bound": "latency", "kernel": "qr_mpc_kernel<2,BIG,.,512> (one workgroup)", "achieved": None, "peak": None, "unit": "us", "frac": None, "traffic": None,
+                        "note": "one workgroup on one CU: the call is launch + one robot's dependent chain + completion; no throughput roof applies"}}
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters: this parent never initialises a GPU),
+    one per device, with the environment torch.distributed.run would give them; rank 0's stdout is this process's stdout.  Exit status: 0
+    only when every rank exited 0 -- a failed rank takes the others down and the run is a failure, never a silent 1-GPU run."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   QRGPU_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                deadline = time.time() + 20.0          # the others are probably stuck in a rendezvous with the dead rank
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    if rc:
+        print("bench.py: a rank process failed (exit %d): no result" % rc, file=sys.stderr)
+    return rc
+
+
+def predicted_weak_scaling(ctx, step, fence, reset, D, warmup, steps=32):
+    """With no 8-GPU node to measure on: the eight draws stand in for eight ranks (a rank's population is one more draw of the same
+    generator).  Per-step device times t_d(s) of every draw from marks on the stream (one event per step), then
+      per_step  = mean over steps s of  mean_d t_d(s) / max_d t_d(s)   -- the ranks meeting at every step (the torque gather of step s needs all of them)
+      whole_run = mean_d T_d / max_d T_d,  T_d = sum_s t_d(s)          -- the ranks only meeting at the end (gathers two steps behind the compute stream)
+    The real run sits between the two; x D is the predicted speed-up over one GPU.  The collective itself (48 KB per rank, on its own stream) is not priced."""
+    t = np.zeros((D, steps))
+    for d in range(D):
+        reset(d)
+        for _ in range(warmup):
+            step()
+        fence()
+        ctx.mark(0)
+        for s_ in range(steps):
+            step()
+            ctx.mark(1 + s_)
+        fence()
+        t[d] = [ctx.mark_elapsed_ms(s_, s_ + 1) for s_ in range(steps)]
+    per_step = float(np.mean(t.mean(0) / t.max(0)))
+    whole = float(t.sum(1).mean() / t.sum(1).max())
+    return dict(per_step_sync=per_step, whole_run=whole, draws=D, steps_per_draw=steps, step_ms_mean=float(t.mean()), step_ms_max=float(t.max()),
+                predicted_speedup_at_8=[8.0 * per_step, 8.0 * whole] if D == 8 else None,
+                what="eight draws as eight ranks, per-step device times from stream marks; efficiency if the ranks met at every step / only at the end "
+                     "(the run is in between); the all-gather itself is not priced")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,10 +399,10 @@ def main():
                     help="how consecutive steps move through a sequence: back and forth (every step a neighbour of the last; on the way back time runs backwards), or forward only with one jump back to the start per --seq steps")
     ap.add_argument("--same-seed-ranks", action="store_true",
                     help="control experiment: every rank draws the same populations (identical work per GPU) instead of its own")
-    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend", "estimator"],
-                    help="tick = the headline; vmc / frontend / estimator = the SURVEY 8f rows, single GPU")
+    ap.add_argument("--mode", default="tick", choices=["tick", "mpc", "wbc", "vmc", "frontend", "estimator", "single"],
+                    help="tick = the headline; vmc / frontend / estimator = the SURVEY 8f rows, single GPU; single = single-robot latency of the drop-in calls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (slot-order dispatch, K12 off, replayed batch, PCIe, 8f kernels)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (slot-order dispatch, K12 off, replayed batch, PCIe, 8f kernels, scaling prediction)")
     ap.add_argument("--trot-only", action="store_true", help="experiment: no all-stance / three-leg robots in the batch")
     ap.add_argument("--hessian", default="f32", choices=["f32", "bf16x3"],
                     help="K4 arithmetic: f32 = exact fp32 matrix instruction (default); bf16x3 = three-limb bf16 on the bf16 matrix cores (BASELINE.json configs[4])")
@@ -229,42 +410,65 @@ def main():
                     help="BASELINE.json configs[4] per GPU: A1 and Lite3 interleaved (type_id per robot), usually with --horizon 16; mode tick only")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
+        # a launcher's world size is the number of GPUs of this run; a mismatch is a mistake of the command line, not something to paper over
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world), file=sys.stderr)
-        args.gpus = world
-    # QRGPU_BENCH_REHEARSAL=1: every rank on cuda:0, the gather through gloo on host copies -- a functional rehearsal of the N > 1 code
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    # QRGPU_BENCH_REHEARSAL=1: every rank on device 0, the gather through gloo on host copies -- a functional rehearsal of the N > 1 code
     # path on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
     rehearsal = os.environ.get("QRGPU_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    dist = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="gloo")      # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id.  (gloo announces its connections on the C-level
+        # stdout: keep that off the one JSON line this program prints)
+        sys.stdout.flush()
+        saved = os.dup(1); os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+        finally:
+            os.dup2(saved, 1); os.close(saved)
+    dry = os.environ.get("QRGPU_BENCH_DRY", "")
+    if dry:
+        # launcher self-test (tests/test_bench_launch.py, no GPU): rendezvous, one max-reduce, one JSON line; "fail<r>" makes rank r exit 3 first
+        if dry == "fail%d" % rank:
+            sys.exit(3)
+        v = float(rank + 1)
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); v = float(t.item())
+            dist.barrier(); dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test", "value": v, "n_gpus": world, "dry": True}))
+        return
 
     pkg = _load_pkg()
     if rank == 0 or (local_rank == 0 and not rehearsal):
         pkg._build.build()          # one build per node; the other ranks wait (the build is also file-locked)
     if world > 1:
         dist.barrier()
+    if args.mode == "single":
+        print(json.dumps(single_mode(args, pkg)))
+        return
     n, h = args.robots, args.horizon
     ctx = pkg.Context(device_id=local_rank, max_batch=n, horizon_max=16)   # raises without gfx950 / built library
     ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h)
     ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
 
     if args.mode in ("vmc", "frontend", "estimator"):
         if rank == 0:
-            print(json.dumps(side_mode(args, pkg, ctx, torch, dev, stream)))
+            print(json.dumps(side_mode(args, pkg, ctx)))
         ctx.close()
         return
 
@@ -277,7 +481,8 @@ def main():
     D = max(1, min(args.draws, args.steps))
     SEQ = max(1, args.seq)
     S = pkg.to_soa
-    T = lambda a: torch.from_numpy(S(a)).to(dev)
+    dv = Dev(pkg, ctx)
+    T = dv.soa
     seed_rank = 0 if args.same_seed_ranks else rank
     extra = dict(frac_all_stance=0.0, frac_three_leg=0.0) if args.trot_only else {}
     d_type = None
@@ -286,7 +491,7 @@ def main():
             raise SystemExit("--mixed needs --mode tick and an even --robots")
         ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h)
         ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
-        d_type = torch.from_numpy(pkg.shard.interleave_types(n, 2)).to(dev)
+        d_type = dv.put(pkg.shard.interleave_types(n, 2))
 
     def population(d):
         seed = 0xA1 + 2 + 1000 * d + 100000 * seed_rank          # draw 0 of rank 0 is make_batch(seed = 0xA1 + 2): BASELINE configs[2]'s seed rule
@@ -313,12 +518,12 @@ def main():
     walk = list(range(SEQ)) + list(range(SEQ - 2, 0, -1))        # 0 1 .. S-1 S-2 .. 1 | 0 1 ..: every step's batch is a neighbour of the last one
     if args.walk == "forward":
         walk = list(range(SEQ))                                  # 0 1 .. S-1 | 0 1 ..: time only runs forwards, one discontinuity per SEQ steps
-    d_prev = torch.zeros((3, n), dtype=torch.float32, device=dev)
-    d_force = torch.zeros((12, n), dtype=torch.float32, device=dev)
-    d_qdes = torch.zeros((24, n), dtype=torch.float32, device=dev)
-    d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
-    d_tau2 = [torch.zeros((12, n), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-    d_tau_all = torch.zeros((world, 12, n), dtype=torch.float32, device=dev) if world > 1 else None   # rank-major
+    d_prev = dv.zeros((3, n))
+    d_force = dv.zeros((12, n))
+    d_qdes = dv.zeros((24, n))
+    d_status = dv.zeros((n,), np.int32)
+    d_tau2 = [dv.zeros((12, n)) for _ in range(2 if world > 1 else 1)]
+    d_tau_all = dv.zeros((world, 12, n)) if world > 1 else None   # rank-major
     nstep = [0]
     cur = dict(draw=0, k12=True, fixed=None)
 
@@ -333,15 +538,15 @@ def main():
         if args.mode == "tick":
             ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_force, tau, d_status, d_type, qdes=d_qdes if cur["k12"] else None)
         elif args.mode == "mpc":
-            ctx.mpc_solve_batch(n, ds, dt_, dg, dfb[13:25], d_force, tau, d_status)
+            ctx.mpc_solve_batch(n, ds, dt_, dg, dfb.row(13), d_force, tau, d_status)
         else:
             ctx.wbc_run_batch(n, dfb, dcmd, d_prev, tau, d_qdes, d_status)
         if world > 1:
             if rehearsal:
-                torch.cuda.synchronize()
+                ctx.sync()
                 parts = [torch.empty((12, n)) for _ in range(world)]
-                dist.all_gather(parts, tau.cpu())
-                d_tau_all.copy_(torch.stack(parts))
+                dist.all_gather(parts, torch.from_numpy(tau.download()))
+                d_tau_all.upload(torch.stack(parts).numpy())
             else:
                 ctx.allgather_tau(tau, n, d_tau_all, slot)     # RCCL over xGMI on the context's own stream: the only exchange of the path
 
@@ -349,16 +554,19 @@ def main():
         if world > 1:
             if not rehearsal:
                 ctx.comm_sync()
-            torch.cuda.synchronize()
+            ctx.sync()
             dist.barrier()
-        torch.cuda.synchronize()
+        ctx.sync()
+
+    def reset(draw, k12=True, fixed=None, lpt=True):
+        cur.update(draw=draw, k12=k12, fixed=fixed)
+        ctx.set_lpt_schedule(lpt)                               # forgets the dispatch history: another population
+        d_prev.zero()
+        nstep[0] = 0
 
     def timed(steps, warmup, draw, k12=True, fixed=None, lpt=True):
         """`warmup` untimed then `steps` timed steps on one population with a fresh scheduler history.  -> seconds (max over ranks)"""
-        cur.update(draw=draw, k12=k12, fixed=fixed)
-        ctx.set_lpt_schedule(lpt)                               # forgets the dispatch history: another population
-        d_prev.zero_()
-        nstep[0] = 0
+        reset(draw, k12, fixed, lpt)
         for _ in range(warmup):
             step()
         fence()
@@ -381,26 +589,27 @@ def main():
     # cost 17 us of a 0.29 ms step (3.50 against 3.73 M ticks/s with none: QRGPU_BENCH_KERNEL_TIMING=0 / 1 / N for the A/B; every 4th 3.65, every
     # 8th 3.69 M)
     # -- and only around timed steps (the warm-up steps of a draw start cold)
-    ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "8" if args.steps >= 160 else "4" if args.steps >= 40 else "2"))
+    ktime = int(os.environ.get("QRGPU_BENCH_KERNEL_TIMING", "8" if args.steps >= 160 else "4"))
     ctx.enable_timing(0)
     if ktime:
         ctx.enable_timing(ktime); ctx.enable_timing(-1)        # the event pool is made here, paused: nothing of it inside a draw's barrier-to-barrier region
-    draw_s, draw_flags, draw_itmax = [], [], []
+    draw_s, draw_flags, draw_itmax, draw_itmean = [], [], [], []
     cur["ktime"] = ktime
     for d in range(D):
         draw_s.append(timed(share[d], args.warmup, d))
-        st_d = d_status.cpu().numpy().astype(np.int64)          # (outside the timed region: the last step's status words of this draw)
-        draw_flags.append(int(((st_d & 0xff0000ff) != 0).sum())); draw_itmax.append(int(((st_d >> 8) & 0xffff).max()))
+        st_d = d_status.download()          # (outside the timed region: the last step's status words of this draw)
+        draw_flags.append(int((pkg.status_flags(st_d) != 0).sum())); draw_itmax.append(int(pkg.status_iterations(st_d).max()))
+        draw_itmean.append(float(pkg.status_iterations(st_d).mean()))
     if world > 1:
-        own = d_tau_all[rank]
-        if not torch.equal(own, d_tau2[(nstep[0] - 1) & 1]):
+        own = d_tau_all.download()[rank]
+        if not np.array_equal(own, d_tau2[(nstep[0] - 1) & 1].download()):
             raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
     mpc_ms, mpc_cnt = ctx.get_timing(0)
     wbc_ms, wbc_cnt = ctx.get_timing(1)
     if not mpc_cnt and not wbc_cnt: mpc_ms = wbc_ms = float("nan")            # (QRGPU_BENCH_KERNEL_TIMING=0)
     ctx.enable_timing(False)
     cur["ktime"] = 0
-    status = d_status.cpu().numpy()
+    status = d_status.download()
     rates = [world * n * share[d] / draw_s[d] for d in range(D)]
     value = float(np.median(rates))
 
@@ -424,57 +633,62 @@ def main():
         side["ticks_per_s_slot_order_dispatch"] = n * ks / timed(ks, 3, 0, lpt=False)          # no scheduling history at all
         side["ticks_per_s_without_k12"] = n * ks / timed(ks, args.warmup, 0, k12=False)
         side["ticks_per_s_same_batch_replayed"] = n * ks / timed(ks, args.warmup, 0, fixed=0)   # round 1's methodology (history = replay)
-        # PCIe-inclusive rate (never `value`): host buffers in, torques out, every step
-        host_in = [torch.from_numpy(S(host0[0][k])).pin_memory() for k in keys]
-        host_tau = torch.empty((12, n), dtype=torch.float32).pin_memory()
-        cur.update(draw=0, k12=True, fixed=0)
-        torch.cuda.synchronize()
+        # the eight draws as eight ranks: what 8 GPUs would lose to the spread between populations
+        side["predicted_weak_scaling_8"] = predicted_weak_scaling(ctx, step, fence, reset, D, min(args.warmup, 10))
+        # PCIe-inclusive rate (never `value`): pinned host buffers in, torques out, every step
+        host_in = []
+        for k in keys:
+            pa = ctx.alloc_pinned(S(host0[0][k]).shape); pa.array[...] = S(host0[0][k]); host_in.append(pa)
+        host_tau = ctx.alloc_pinned((12, n))
+        reset(0, True, 0)
+        ctx.sync()
         tp0 = time.perf_counter()
         for _ in range(20):
             for hsrc, ddst in zip(host_in, dev_seq[0][0]):
-                ddst.copy_(hsrc, non_blocking=True)
+                ddst.copy_from_pinned(hsrc)
             step()
-            host_tau.copy_(d_tau2[0], non_blocking=True)
-            torch.cuda.synchronize()
+            d_tau2[0].copy_to_pinned(host_tau)
+            ctx.sync()
         side["pcie_inclusive_ticks_per_s"] = n * 20 / (time.perf_counter() - tp0)
         # SURVEY 8f kernels in front of the tick, timed on their own (never part of `value`)
         fe, fst = pkg.workload.make_frontend_batch(n, seed=0xFE)
         d_fe, d_fst = T(fe), T(fst)
-        d_traj2, d_gait2, d_cmd2 = (torch.empty_like(x) for x in (dev_seq[0][0][1], dev_seq[0][0][2], dev_seq[0][0][4]))
-        d_upd = torch.zeros((n,), dtype=torch.int32, device=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d_traj2, d_gait2, d_cmd2 = dv.zeros((12 * h, n)), dv.zeros((4 * h, n)), dv.zeros((67, n))
+        d_upd = dv.zeros((n,), np.int32)
         for _ in range(5):
             ctx.mpc_frontend_batch(n, d_fe, d_fst, d_traj2, d_gait2, d_cmd2, d_upd)
-        e0.record(stream)
+        ctx.mark(0)
         for _ in range(50):
             ctx.mpc_frontend_batch(n, d_fe, d_fst, d_traj2, d_gait2, d_cmd2, d_upd)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        side["frontend_kernel_us"] = 1e3 * e0.elapsed_time(e1) / 50
+        ctx.mark(1)
+        side["frontend_kernel_us"] = 1e3 * ctx.mark_elapsed_ms(0, 1) / 50
         ctx.vmc_setup_packed(0, pkg.workload.vmc_cfg("a1"), pkg.model_desc("a1")[:3])
         vin, vq = pkg.workload.make_vmc_batch(n, seed=0xB2)
         d_vin, d_vq = T(vin), T(vq)
-        d_vf, d_vt = torch.empty((12, n), dtype=torch.float32, device=dev), torch.empty((12, n), dtype=torch.float32, device=dev)
-        d_vs = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_vf, d_vt = dv.zeros((12, n)), dv.zeros((12, n))
+        d_vs = dv.zeros((n,), np.int32)
         for _ in range(3):
             ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
-        e0.record(stream)
+        ctx.mark(0)
         for _ in range(20):
             ctx.vmc_force_batch(n, d_vin, d_vq, d_vf, d_vt, d_vs)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        side["vmc_qp_kernel_us"] = 1e3 * e0.elapsed_time(e1) / 20
+        ctx.mark(1)
+        side["vmc_qp_kernel_us"] = 1e3 * ctx.mark_elapsed_ms(0, 1) / 20
 
     if rank == 0:
-        iters = ((status >> 8) & 0xffff).astype(np.float64)
-        flags = status.astype(np.int64) & 0xff0000ff
+        iters = pkg.status_iterations(status).astype(np.float64)
+        flags = pkg.status_flags(status)
         ms_per_step = 1e3 * world * n / value
-        it_mean = float(iters.mean()) if args.mode != "wbc" else 0.0
-        flop_dense = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + 20.3 * FLOP_K6_PER_ITER      # SURVEY 8(d)'s dense count (cold start: 20.3 changes)
+        ms_pooled = 1e3 * sum(draw_s) / args.steps
+        it_mean = float(np.mean(draw_itmean)) if args.mode != "wbc" else 0.0
+        # SURVEY 8(d)'s dense count with the change count this run measured (mean over the draws' last steps; a cold start takes 20.3)
+        flop_dense = FLOP_K4_HESSIAN + FLOP_K4_GRADIENT + FLOP_K6_FACTOR + it_mean * FLOP_K6_PER_ITER
+        traffic, traffic_src = committed_traffic("qr_mpc_kernel" if args.mode != "wbc" else "qr_wbc_kernel", n, h)
         if args.mode == "wbc":
             dom_ms, dom_name = wbc_ms, "qr_wbc_kernel"
             roof = {"bound": "latency", "kernel": dom_name, "achieved": FLOP_WBC * n / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F64_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                    "frac": FLOP_WBC * n / (dom_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS, "traffic": None, "kernel_ms": dom_ms, "kernel_launches": wbc_cnt,
+                    "frac": FLOP_WBC * n / (dom_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel_ms": dom_ms, "kernel_launches": wbc_cnt,
                     "note": "SURVEY 8(d)'s estimate of 0.35 MFLOP per robot (fp64); one wavefront per robot, dependent small-matrix chains"}
         else:
             dom_ms, dom_name = mpc_ms, "qr_mpc_kernel"
@@ -493,12 +707,16 @@ def main():
                                 "what": "v_mfma_f32_16x16x4_f32 flops issued by K4 (2*16*16*4 each, zero padding of the tiles included) = MFMA utilisation over the whole kernel"},
                 "fp32_vector": {"achieved": v32, "peak": PEAK_F32_MATRIX_TFLOPS, "frac": v32 / PEAK_F32_MATRIX_TFLOPS},
                 "executed_flop_per_robot": {k: v / n for k, v in flop.items()},
-                "dense_yardstick": {"flop_per_robot": flop_dense, "achieved": flop_dense * n / sec / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                "dense_yardstick": {"flop_per_robot": flop_dense, "working_set_changes": it_mean, "achieved": flop_dense * n / sec / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
                                     "frac": flop_dense * n / sec / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                                    "what": "SURVEY.md 8(d)'s dense count (12h x 13h x 12h GEMM, n^3/3 factorisation, 4 n^2 per change) over the same kernel time: "
-                                            "a yardstick against that accounting, not work the kernel does (swing variables are eliminated, zero terms skipped)"},
-                "traffic": None, "kernel_ms": dom_ms, "kernel_launches": mpc_cnt, "other_kernel_ms": wbc_ms,
+                                    "what": "SURVEY.md 8(d)'s dense count (12h x 13h x 12h GEMM, n^3/3 factorisation, 4 n^2 per change at the change count this run "
+                                            "measured) over the same kernel time: a yardstick against that accounting, not work the kernel does (swing variables are "
+                                            "eliminated, zero terms skipped)"},
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": dom_ms, "kernel_launches": mpc_cnt, "other_kernel_ms": wbc_ms,
                 "kernel_ms_is": "mean over the launches bracketed by HIP events on the launching stream: every %d-th timed step" % ktime,
+                "outside_kernels_ms": ms_pooled - (mpc_ms + wbc_ms) if args.mode == "tick" else None,
+                "outside_kernels_is": "all timed steps pooled: ms per step minus the two kernels' mean times (launch boundaries, the trailing list launch, the gate, events)",
                 "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         what = "full MPC+WBC tick (K1-K14: kinematic projection on, motor tail on)"
         out = {
@@ -516,6 +734,8 @@ def main():
                        "ticks_per_s_all_steps": world * n * args.steps / sum(draw_s),
                        "rank_batches": "every rank draws the same populations (control)" if args.same_seed_ranks else "every rank draws its own populations",
                        "parallelism": "robots sharded over %d GPU(s); qrgpu_allgather_tau (RCCL, context-owned stream) overlapped with the next tick" % world,
+                       "host_plumbing": "no GPU array library: device / pinned buffers, stream, events and the collective behind the C ABI" +
+                                        ("; torch.distributed (gloo, CPU) for the launcher's barrier / max-reduce / id hand-over" if world > 1 else "; torch not imported"),
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "status_flags_nonzero_per_draw": draw_flags, "max_active_set_changes_per_draw": draw_itmax,
                        "dispatch": "longest-first from the previous step's per-robot solve time (a prediction: consecutive steps see different batches)",
@@ -546,14 +766,14 @@ def main():
             res = {}
             for mode in ("f32", args.hessian):
                 ctx.set_hessian_mode(mode); ctx.set_warm_start(False)
-                d_prev.zero_()
-                d_f1, d_t1, d_s1 = torch.zeros_like(d_force), torch.zeros_like(d_tau2[0]), torch.zeros_like(d_status)
+                d_prev.zero()
+                d_f1, d_t1, d_s1 = dv.zeros((12, n)), dv.zeros((12, n)), dv.zeros((n,), np.int32)
                 ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_f1, d_t1, d_s1, d_type, qdes=d_qdes)
-                torch.cuda.synchronize()
-                res[mode] = (d_f1.cpu().numpy().T, d_t1.cpu().numpy().T, d_s1.cpu().numpy())
+                ctx.sync()
+                res[mode] = (d_f1.download().T, d_t1.download().T, d_s1.download())
             ctx.set_warm_start(True)
             fg, tg, sg = res[args.hessian]
-            ok = ((sg.astype(np.int64) & 0xff0000ff) == 0) & (st_cpu == 0)
+            ok = (pkg.status_flags(sg) == 0) & (st_cpu == 0)
             cfgo = out["config"]
             cfgo["max_rel_torque_err_vs_cpu"] = float((np.abs(tg - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
             cfgo["max_rel_force_err_vs_cpu"] = float((np.abs(fg - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
@@ -564,22 +784,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, b0, h, mode=0 if args.mode == "mpc" else 1)
             # BASELINE's metric quotes the torque error beside the rate: one more (untimed) call on draw 0's first batch from fresh WBC
             # memory, against what the CPU pass returned for the same inputs; robots flagged on either side are counted, not compared
-            d_prev.zero_()
-            d_f1, d_t1, d_s1, d_q1 = torch.zeros_like(d_force), torch.zeros_like(d_tau2[0]), torch.zeros_like(d_status), torch.zeros_like(d_qdes)
+            d_prev.zero()
+            d_f1, d_t1, d_s1, d_q1 = dv.zeros((12, n)), dv.zeros((12, n)), dv.zeros((n,), np.int32), dv.zeros((24, n))
             ds, dt_, dg, dfb, dcmd = dev_seq[0][0]
             if args.mode == "tick":
                 ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_f1, d_t1, d_s1, d_type, qdes=d_q1)
             else:
-                ctx.mpc_solve_batch(n, ds, dt_, dg, dfb[13:25], d_f1, d_t1, d_s1)
-            torch.cuda.synchronize()
+                ctx.mpc_solve_batch(n, ds, dt_, dg, dfb.row(13), d_f1, d_t1, d_s1)
+            ctx.sync()
             f_cpu, tau_cpu, st_cpu, q_cpu = cpu_baseline.outputs
-            ok = ((d_s1.cpu().numpy().astype(np.int64) & 0xff0000ff) == 0) & (st_cpu == 0)
-            f_gpu, tau_gpu = d_f1.cpu().numpy().T, d_t1.cpu().numpy().T
+            ok = (pkg.status_flags(d_s1.download()) == 0) & (st_cpu == 0)
+            f_gpu, tau_gpu = d_f1.download().T, d_t1.download().T
             cfgo = out["config"]
             cfgo["max_rel_force_err_vs_cpu"] = float((np.abs(f_gpu - f_cpu).max(1) / np.maximum(1.0, np.abs(f_cpu).max(1)))[ok].max())
             cfgo["max_rel_torque_err_vs_cpu"] = float((np.abs(tau_gpu - tau_cpu) / np.maximum(1.0, np.abs(tau_cpu))).max(1)[ok].max())
             if args.mode == "tick":
-                cfgo["max_abs_qdes_err_vs_cpu"] = float(np.abs(d_q1.cpu().numpy().T - q_cpu)[ok].max())
+                cfgo["max_abs_qdes_err_vs_cpu"] = float(np.abs(d_q1.download().T - q_cpu)[ok].max())
             cfgo["robots_compared_with_cpu"] = int(ok.sum())
             if getattr(reference_solver, "as_called", None) is not None:
                 # against the reference's solver exactly as the reference calls it (asymmetric fp32 H, nWSR = 100): DESIGN.md 2
@@ -590,12 +810,29 @@ def main():
                     "robots": int(idx.size), "reference_converged": int(conv.sum()), "reference_hit_nwsr_100": int((nwsr >= 100).sum()),
                     "max_rel_force_err": float(rel[conv].max()) if conv.any() else None,
                     "note": "first-step forces of this batch's first robots vs qpOASES 3.2.0 fed the asymmetric fp32 H with nWSR = 100 "
-                            "(qr_mpc_interface.cpp:418-438); the reference's own H <-> H^T ambiguity bounds this figure (DESIGN.md 2, tests/test_gpu_golden.py)"}
+                            "(qr_mpc_interface.cpp:418-438): these 24 robots are rows 62-85 of tests/golden/mpc_golden.npz, where the full-tick torque is "
+                            "checked too; north_star's 1e-4 is not met against this comparator -- nor by the reference against itself (DESIGN.md 2, "
+                            "tests/golden/parity_as_called.json, tests/test_gpu_golden.py)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def committed_traffic(kernel, n, h):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
+    the gfx950 correction of MI355X_MICROARCH.md), which are separate profiler runs of this same command: profiles/r03_pmc_summary.json names
+    the commit they were taken at.  Only quoted for the configuration they were collected on (1024 robots, h = 10)."""
+    p = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    if not os.path.exists(p) or n != 1024 or h != 10:
+        return None, None
+    try:
+        d = json.load(open(p))
+        k = d["kernels"][kernel]
+        return float(k["hbm_bytes_per_launch"]), "profiles/r03_pmc_summary.json (commit %s; %s)" % (d.get("commit", "?"), d.get("recipe", "rocprofv3 --pmc passes of bench.py"))
+    except Exception:
+        return None, None
 
 
 if __name__ == "__main__":

@@ -453,6 +453,16 @@ void *qrgpu_malloc(qrgpu_ctx *ctx, unsigned long long bytes);   /* hipMalloc on 
 void qrgpu_free(qrgpu_ctx *ctx, void *p);
 int  qrgpu_memcpy_h2d(qrgpu_ctx *ctx, void *dst, const void *src, unsigned long long bytes);
 int  qrgpu_memcpy_d2h(qrgpu_ctx *ctx, void *dst, const void *src, unsigned long long bytes);
+/* Pinned host memory and asynchronous copies on the context stream (kind: 0 host->device, 1 device->host, 2 device->device; the host
+ * side should be qrgpu_host_alloc memory), an asynchronous byte fill, and caller-indexed timing marks: qrgpu_mark(i) records event i on
+ * the context stream (index < 65536; created on first use), qrgpu_mark_elapsed_ms waits for mark `to` and returns the device time between
+ * the two.  Launcher plumbing for callers that use no GPU array library (bench.py). */
+void *qrgpu_host_alloc(qrgpu_ctx *ctx, unsigned long long bytes);
+void qrgpu_host_free(qrgpu_ctx *ctx, void *p);
+int  qrgpu_memcpy_async(qrgpu_ctx *ctx, void *dst, const void *src, unsigned long long bytes, int kind);
+int  qrgpu_memset_async(qrgpu_ctx *ctx, void *dst, int byte_value, unsigned long long bytes);
+int  qrgpu_mark(qrgpu_ctx *ctx, int index);
+int  qrgpu_mark_elapsed_ms(qrgpu_ctx *ctx, int from, int to, double *ms);
 
 #ifdef __cplusplus
 }

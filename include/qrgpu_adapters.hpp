@@ -73,7 +73,7 @@ inline void SolveMPCKernel(V3 &p, V3 &v, Q4 &q, V3 &w, M34 &r, V3 &rpy, float *s
     const float pp[3] = {p[0], p[1], p[2]}, vv[3] = {v[0], v[1], v[2]}, ww[3] = {w[0], w[1], w[2]};
     const float qq[4] = {q[0], q[1], q[2], q[3]}, rr[3] = {rpy[0], rpy[1], rpy[2]};
     int rc = qrgpu_mpc_solve1(g.ctx, 0, pp, vv, qq, ww, r.data(), rr, state_trajectory, gait, nullptr, g.q_soln, nullptr, &g.status);
-    if (rc != QRGPU_OK || (g.status & 0xff)) std::printf("failed to solve!\n");        // the reference's only error channel (:440-442)
+    if (rc != QRGPU_OK || ((unsigned)g.status & QRGPU_ST_FLAG_MASK)) std::printf("failed to solve!\n");        // the reference's only error channel (:440-442)
     g.has_solved = true;
 }
 

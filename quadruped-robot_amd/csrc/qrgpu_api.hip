@@ -252,8 +252,27 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
     const size_t in1 = 28 + 12 * QRGPU_MAX_HORIZON + 4 * QRGPU_MAX_HORIZON + 12 + 37 + 67 + 3;
-    if (hipMalloc(&c->d_in1, in1 * sizeof(float)) != hipSuccess || hipMalloc(&c->d_out1, 64 * sizeof(float)) != hipSuccess ||
-        hipMalloc(&c->d_st1, 4 * sizeof(int)) != hipSuccess || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
+    static_assert(28 + 12 * QRGPU_MAX_HORIZON + 4 * QRGPU_MAX_HORIZON + 12 + 37 + 67 + 3 <= 512, "staging layout");
+    {
+        const char *e = getenv("QRGPU_SINGLE_COPIES");
+        c->zero_copy = !(e && atoi(e) != 0);
+    }
+    bool stage_ok;
+    if (c->zero_copy) {
+        // [0, 512) floats in, [512, 576) floats out, [576, 580) status / type words
+        void *dp = nullptr;
+        stage_ok = hipHostMalloc(&c->h_stage, 640 * sizeof(float), hipHostMallocMapped) == hipSuccess &&
+                   hipHostGetDevicePointer(&dp, c->h_stage, 0) == hipSuccess;
+        if (stage_ok) {
+            memset(c->h_stage, 0, 640 * sizeof(float));
+            c->h_in1 = (float *)c->h_stage; c->h_out1 = c->h_in1 + 512; c->h_st1 = (int *)(c->h_in1 + 576);
+            c->d_in1 = (float *)dp; c->d_out1 = c->d_in1 + 512; c->d_st1 = (int *)(c->d_in1 + 576);
+        }
+    } else {
+        stage_ok = hipMalloc(&c->d_in1, in1 * sizeof(float)) == hipSuccess && hipMalloc(&c->d_out1, 64 * sizeof(float)) == hipSuccess &&
+                   hipMalloc(&c->d_st1, 4 * sizeof(int)) == hipSuccess;
+    }
+    if (!stage_ok || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
         hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
@@ -279,9 +298,13 @@ void qrgpu_destroy(qrgpu_ctx *c)
     hipSetDevice(c->device);
     qrgpu_comm_destroy(c);
     for (int k = 0; k < 2; ++k) for (auto &e : c->ev[k]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    if (c->d_in1) hipFree(c->d_in1);
-    if (c->d_out1) hipFree(c->d_out1);
-    if (c->d_st1) hipFree(c->d_st1);
+    for (auto &e : c->marks) hipEventDestroy(e);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    else {
+        if (c->d_in1) hipFree(c->d_in1);
+        if (c->d_out1) hipFree(c->d_out1);
+        if (c->d_st1) hipFree(c->d_st1);
+    }
     if (c->d_wbc) hipFree(c->d_wbc);
     if (c->d_cmd_tick) hipFree(c->d_cmd_tick);
     if (c->d_order) hipFree(c->d_order);
@@ -898,6 +921,38 @@ int qrgpu_set_torque_epilogue(qrgpu_ctx *c, int flags)
     return QRGPU_OK;
 }
 
+// The single-robot calls stage through the context (qrgpu_ctx.h): with zero copy the host fills the pinned block in place, the one
+// launch reads and writes it over PCIe, and the only stream command besides the launch is the wait.
+static int stage_in(qrgpu_ctx *c, const float *src, size_t nfloat, int type_id, int **d_type)
+{
+    *d_type = nullptr;
+    if (c->zero_copy) {
+        memcpy(c->h_in1, src, nfloat * sizeof(float));
+        if (type_id != 0) { c->h_st1[1] = type_id; *d_type = c->d_st1 + 1; }
+        return QRGPU_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in1, src, nfloat * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (type_id != 0) {
+        *d_type = c->d_st1 + 1;
+        c->type_stage = type_id;         // (a context member: the copy is asynchronous)
+        HIPCHK(c, hipMemcpyAsync(*d_type, &c->type_stage, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
+    return QRGPU_OK;
+}
+static int stage_out(qrgpu_ctx *c, float *out, size_t nfloat, int *st)
+{
+    if (c->zero_copy) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(out, c->h_out1, nfloat * sizeof(float));
+        *st = c->h_st1[0];
+        return QRGPU_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, nfloat * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QRGPU_OK;
+}
+
 int qrgpu_mpc_solve1(qrgpu_ctx *c, int type_id, const float p[3], const float v[3], const float quat[4], const float w[3],
                      const float r[12], const float rpy[3], const float *traj, const float *gait, const float q[12],
                      double f_out[12], float tau_out[12], int *status)
@@ -905,24 +960,23 @@ int qrgpu_mpc_solve1(qrgpu_ctx *c, int type_id, const float p[3], const float v[
     if (!c || !p || !v || !quat || !w || !r || !rpy || !traj || !gait || !f_out) return QRGPU_ERR_BAD_ARG;
     if (type_id < 0 || type_id >= QR_MAX_TYPES || !c->mpc_ready[type_id]) return QRGPU_ERR_NOT_SETUP;
     const int h = c->mpc.horizon;
-    std::vector<float> in(28 + 16 * h + 12, 0.f);
+    float in[28 + 16 * QRGPU_MAX_HORIZON + 12];
+    const size_t nin = 28 + 16 * (size_t)h + 12;
     memcpy(&in[0], p, 12); memcpy(&in[3], v, 12); memcpy(&in[6], quat, 16); memcpy(&in[10], w, 12);
     memcpy(&in[13], r, 48); memcpy(&in[25], rpy, 12);
     memcpy(&in[28], traj, sizeof(float) * 12 * h);
     memcpy(&in[28 + 12 * h], gait, sizeof(float) * 4 * h);
-    if (q) memcpy(&in[28 + 16 * h], q, 48);
+    if (q) memcpy(&in[28 + 16 * h], q, 48); else memset(&in[28 + 16 * h], 0, 48);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_in1, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     int *d_type = nullptr;
-    int tid_host = type_id;
-    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
-    int rc = launch_mpc(c, 1, d_type, c->d_in1, c->d_in1 + 28, c->d_in1 + 28 + 12 * h, c->d_in1 + 28 + 16 * h, c->d_out1,
-                        (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1, nullptr, nullptr, nullptr);
+    int rc = stage_in(c, in, nin, type_id, &d_type);
+    if (rc) return rc;
+    rc = launch_mpc(c, 1, d_type, c->d_in1, c->d_in1 + 28, c->d_in1 + 28 + 12 * h, c->d_in1 + 28 + 16 * h, c->d_out1,
+                    (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1, nullptr, nullptr, nullptr);
     if (rc) return rc;
     float out[24]; int st = 0;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = stage_out(c, out, 24, &st);
+    if (rc) return rc;
     for (int i = 0; i < 12; ++i) f_out[i] = out[i];
     if (q && tau_out) for (int i = 0; i < 12; ++i) tau_out[i] = out[12 + i];
     if (status) *status = st;
@@ -937,19 +991,18 @@ int qrgpu_wbc_run1(qrgpu_ctx *c, int type_id, const float fb_state[37], const fl
     float in[37 + 67 + 3];
     memcpy(in, fb_state, 37 * 4); memcpy(in + 37, wbc_cmd, 67 * 4); memcpy(in + 104, prev_ori_vel, 12);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_in1, in, sizeof(in), hipMemcpyHostToDevice, c->stream));
     int *d_type = nullptr;
-    int tid_host = type_id;
-    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
+    int rc = stage_in(c, in, 107, type_id, &d_type);
+    if (rc) return rc;
     const bool want_q = qdes_out || qddes_out;
-    int rc = launch_wbc(c, 1, d_type, c->d_in1, c->d_in1 + 37, c->d_in1 + 104, c->d_out1, want_q ? c->d_out1 + 12 : nullptr,
-                        c->d_st1, nullptr, 0, 0);
+    rc = launch_wbc(c, 1, d_type, c->d_in1, c->d_in1 + 37, c->d_in1 + 104, c->d_out1, want_q ? c->d_out1 + 12 : nullptr,
+                    c->d_st1, nullptr, 0, 0);
     if (rc) return rc;
     float out[36]; int st = 0;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(prev_ori_vel, c->d_in1 + 104, 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->zero_copy) HIPCHK(c, hipMemcpyAsync(prev_ori_vel, c->d_in1 + 104, 12, hipMemcpyDeviceToHost, c->stream));
+    rc = stage_out(c, out, 36, &st);
+    if (rc) return rc;
+    if (c->zero_copy) memcpy(prev_ori_vel, c->h_in1 + 104, 12);
     memcpy(tau_out, out, 48);
     if (qdes_out) memcpy(qdes_out, out + 12, 48);
     if (qddes_out) memcpy(qddes_out, out + 24, 48);
@@ -969,19 +1022,15 @@ static int vmc_force1(qrgpu_ctx *c, int type_id, const float vmc_in[37], const f
     if (q) memcpy(in + 37, q, 48);
     if (ratio) memcpy(in + 49, ratio, 32);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_in1, in, sizeof(in), hipMemcpyHostToDevice, c->stream));
     int *d_type = nullptr;
-    int tid_host = type_id;
-    if (type_id != 0) { d_type = c->d_st1 + 1; HIPCHK(c, hipMemcpyAsync(d_type, &tid_host, sizeof(int), hipMemcpyHostToDevice, c->stream)); }
+    { const int rc_ = stage_in(c, in, sizeof(in) / sizeof(float), type_id, &d_type); if (rc_) return rc_; }
     VmcLaunch P = c->vmc;
     P.n = 1; P.ratio = ratio ? c->d_in1 + 49 : nullptr;
     hipLaunchKernelGGL(qr_vmc_kernel, dim3(8), dim3(64), 0, c->stream, P, d_type, c->d_in1, q ? c->d_in1 + 37 : nullptr, c->d_out1,
                        (q && tau_out) ? c->d_out1 + 12 : nullptr, c->d_st1);
     HIPCHK(c, hipGetLastError());
     float out[24]; int st = 0;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out1, sizeof(out), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_st1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = stage_out(c, out, 24, &st); if (rc_) return rc_; }
     memcpy(force_out, out, 48);
     if (q && tau_out) memcpy(tau_out, out + 12, 48);
     if (status) *status = st;
@@ -1120,6 +1169,50 @@ int qrgpu_memcpy_d2h(qrgpu_ctx *c, void *dst, const void *src, unsigned long lon
     if (!c) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QRGPU_OK;
+}
+
+void *qrgpu_host_alloc(qrgpu_ctx *c, unsigned long long bytes)
+{
+    if (!c) return nullptr;
+    void *p = nullptr;
+    hipSetDevice(c->device);
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void qrgpu_host_free(qrgpu_ctx *c, void *p) { if (c && p) { hipSetDevice(c->device); hipHostFree(p); } }
+int qrgpu_memcpy_async(qrgpu_ctx *c, void *dst, const void *src, unsigned long long bytes, int kind)
+{
+    if (!c || kind < 0 || kind > 2) return QRGPU_ERR_BAD_ARG;
+    static const hipMemcpyKind k[3] = {hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice};
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, k[kind], c->stream));
+    return QRGPU_OK;
+}
+int qrgpu_memset_async(qrgpu_ctx *c, void *dst, int byte_value, unsigned long long bytes)
+{
+    if (!c || !dst) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipMemsetAsync(dst, byte_value, bytes, c->stream));
+    return QRGPU_OK;
+}
+int qrgpu_mark(qrgpu_ctx *c, int index)
+{
+    if (!c || index < 0 || index >= 65536) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    while ((int)c->marks.size() <= index) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->marks.push_back(e);
+    }
+    HIPCHK(c, hipEventRecord(c->marks[index], c->stream));
+    return QRGPU_OK;
+}
+int qrgpu_mark_elapsed_ms(qrgpu_ctx *c, int from, int to, double *ms)
+{
+    if (!c || !ms || from < 0 || to < 0 || from >= (int)c->marks.size() || to >= (int)c->marks.size()) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipEventSynchronize(c->marks[to]));
+    float f = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&f, c->marks[from], c->marks[to]));
+    *ms = f;
     return QRGPU_OK;
 }
 

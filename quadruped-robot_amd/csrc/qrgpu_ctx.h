@@ -24,9 +24,17 @@ struct qrgpu_ctx {
     WbcConst *d_wbc = nullptr;
     bool wbc_dirty = true;
     // scratch for the single-robot calls and the fused tick
+    // Staging of the single-robot calls.  Default: ONE block of pinned, mapped host memory that the kernels read and write in place (zero
+    // copy: d_* are the device-side addresses of h_*), so a call is "fill h_in1, one launch, wait, read h_out1" with no copy command on the
+    // stream.  QRGPU_SINGLE_COPIES=1: device buffers and three hipMemcpyAsync per call (round 2's form, kept for the A/B of INTEGRATION.md).
     float *d_in1 = nullptr;       // staging: single-robot inputs
     float *d_out1 = nullptr;      // staging: single-robot outputs
     int *d_st1 = nullptr;
+    float *h_in1 = nullptr, *h_out1 = nullptr;     // host-side addresses of the same memory (zero copy) or null
+    int *h_st1 = nullptr;
+    void *h_stage = nullptr;      // the pinned block
+    bool zero_copy = false;
+    int type_stage = 0;           // (copy path) the type word in flight
     int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
     int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
     double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
@@ -76,6 +84,7 @@ struct qrgpu_ctx {
     unsigned ev_calls[2] = {0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
     size_t ev_used[2] = {0, 0};
+    std::vector<hipEvent_t> marks;   // qrgpu_mark: caller-indexed events on the context stream
 };
 
 #define HIPCHK(ctx, call)                                                                    \

@@ -111,7 +111,8 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
-           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch"]
+           "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch", "qrgpu_host_alloc", "qrgpu_host_free",
+           "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms"]
 
 
 def load_library():
@@ -182,6 +183,13 @@ def load_library():
     lib.qrgpu_free.argtypes = [vp, vp]; lib.qrgpu_free.restype = None
     lib.qrgpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_ulonglong]
     lib.qrgpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_ulonglong]
+    lib.qrgpu_host_alloc.restype = vp
+    lib.qrgpu_host_alloc.argtypes = [vp, C.c_ulonglong]
+    lib.qrgpu_host_free.argtypes = [vp, vp]
+    lib.qrgpu_memcpy_async.argtypes = [vp, vp, vp, C.c_ulonglong, ip]
+    lib.qrgpu_memset_async.argtypes = [vp, vp, ip, C.c_ulonglong]
+    lib.qrgpu_mark.argtypes = [vp, ip]
+    lib.qrgpu_mark_elapsed_ms.argtypes = [vp, ip, ip, C.POINTER(C.c_double)]
     _LIB = lib
     return lib
 
@@ -223,9 +231,47 @@ class DeviceArray:
         self.ctx._chk(self.ctx._lib.qrgpu_memcpy_d2h(self.ctx._h, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def zero(self):
+        """Asynchronous byte fill with 0 on the context stream."""
+        self.ctx._chk(self.ctx._lib.qrgpu_memset_async(self.ctx._h, self.ptr, 0, self.nbytes))
+        return self
+
+    def copy_from_pinned(self, pinned):
+        """Asynchronous host -> device copy from a PinnedArray of the same size."""
+        assert pinned.nbytes == self.nbytes
+        self.ctx._chk(self.ctx._lib.qrgpu_memcpy_async(self.ctx._h, self.ptr, pinned.ptr, self.nbytes, 0))
+        return self
+
+    def copy_to_pinned(self, pinned):
+        assert pinned.nbytes == self.nbytes
+        self.ctx._chk(self.ctx._lib.qrgpu_memcpy_async(self.ctx._h, pinned.ptr, self.ptr, self.nbytes, 1))
+        return pinned
+
+    def row(self, r0, r1=None):
+        """Device pointer (int) of rows [r0, r1) of a 2-d array, e.g. the joint angles inside fb_state."""
+        return self.ptr + r0 * int(np.prod(self.shape[1:])) * self.dtype.itemsize
+
     def free(self):
         if self.ptr:
             self.ctx._lib.qrgpu_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+
+class PinnedArray:
+    """hipHostMalloc-backed numpy view (qrgpu_host_alloc) for asynchronous copies."""
+
+    def __init__(self, ctx, shape, dtype=np.float32):
+        self.ctx, self.shape, self.dtype = ctx, tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = ctx._lib.qrgpu_host_alloc(ctx._h, max(self.nbytes, 8))
+        if not self.ptr:
+            raise QrgpuError("hipHostMalloc of %d bytes failed" % self.nbytes)
+        self.array = np.ctypeslib.as_array((C.c_char * self.nbytes).from_address(self.ptr)).view(self.dtype).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.ctx._lib.qrgpu_host_free(self.ctx._h, self.ptr)
             self.ptr = None
 
 
@@ -293,6 +339,18 @@ class Context:
 
     def alloc(self, shape, dtype=np.float32):
         return DeviceArray(self, shape, dtype)
+
+    def alloc_pinned(self, shape, dtype=np.float32):
+        return PinnedArray(self, shape, dtype)
+
+    def mark(self, index):
+        """Record timing mark `index` on the context stream."""
+        self._chk(self._lib.qrgpu_mark(self._h, int(index)))
+
+    def mark_elapsed_ms(self, a, b):
+        ms = C.c_double(0)
+        self._chk(self._lib.qrgpu_mark_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return ms.value
 
     # -- batched device-pointer API ---------------------------------------------------------------
     def mpc_solve_batch(self, n, mpc_state, traj, gait, q, force, tau=None, status=None, type_id=None):

@@ -1,12 +1,27 @@
 // Drives the header-only adapters exactly the way MPCStanceLegController::SolveDenseMPC and
 // qrWbcLocomotionController::Run do, on inputs read from stdin; prints forces and torques.
 // TEST INFRASTRUCTURE (tests/test_adapters.py).
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 #include "ref_stubs.hpp"
 #include "qrgpu_adapters.hpp"
 
-int main()
+// `adapter_demo --latency N`: after the one checked call of each adapter, N more timed calls of SolveMPCKernel (+ the twelve GetMPCSolution
+// reads SolveDenseMPC makes) and of WbcRun on the same inputs; prints "latency_mpc_us p50 p99 mean min" and "latency_wbc_us ..." (bench.py --mode single).
+static void print_latency(const char *name, std::vector<double> &us)
 {
+    std::sort(us.begin(), us.end());
+    double mean = 0; for (double x : us) mean += x; mean /= (double)us.size();
+    printf("%s %.2f %.2f %.2f %.2f\n", name, us[us.size() / 2], us[(us.size() * 99) / 100], mean, us.front());
+}
+
+int main(int argc, char **argv)
+{
+    const int lat_n = (argc >= 3 && !strcmp(argv[1], "--latency")) ? atoi(argv[2]) : 0;
     int h;
     float cfg[20], s[28], traj[12 * 16], gait[4 * 16], fb[37], cmd[67];
     if (scanf("%d", &h) != 1) return 2;
@@ -27,6 +42,19 @@ int main()
     printf("force");
     for (int leg = 0; leg < 4; ++leg) for (int ax = 0; ax < 3; ++ax) printf(" %.9g", Quadruped::GetMPCSolution(leg * 3 + ax));   // :404
     printf("\n");
+    if (lat_n > 0) {
+        std::vector<double> us;
+        double sink = 0;
+        for (int it = 0; it < lat_n + 20; ++it) {
+            const auto t0 = std::chrono::steady_clock::now();
+            Quadruped::SolveMPCKernel(p, v, q, w, r, rpy, traj, gait);
+            for (int k = 0; k < 12; ++k) sink += Quadruped::GetMPCSolution(k);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (it >= 20) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        }
+        print_latency("latency_mpc_us", us);
+        if (sink == 12345.678) printf("\n");
+    }
 
     if (qrgpu_adapters::WbcSetup(0.08505f, 0.2f, 0.2f) != 0) return 3;
     qrRobotStub robot;
@@ -47,6 +75,16 @@ int main()
     printf("status %d\ntau", st);
     for (int i = 0; i < 12; ++i) printf(" %.9g", tau[i]);
     printf("\n");
+    if (lat_n > 0) {
+        std::vector<double> us;
+        for (int it = 0; it < lat_n + 20; ++it) {
+            const auto t0 = std::chrono::steady_clock::now();
+            qrgpu_adapters::WbcRun(&robot, &d, tau, qd, qdd);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (it >= 20) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        }
+        print_latency("latency_wbc_us", us);
+    }
 
     // force-balance controller: TorqueStanceLegController::GetAction -> ComputeContactForce (qr_torque_stance_leg_controller.cpp:500)
     float vin[37];

@@ -1,0 +1,50 @@
+"""CPU: bench.py's own launcher.  `python bench.py --gpus N` without WORLD_SIZE must start N rank processes (the parent never touches a GPU),
+print rank 0's single JSON line, and fail -- never fall back to one GPU -- when a rank fails.  QRGPU_BENCH_DRY makes the ranks stop after the
+rendezvous (gloo) and one max-reduce, so this runs without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, dry, extra_env=None):
+    env = dict(os.environ, QRGPU_BENCH_DRY=dry)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+def test_self_launch_two_ranks_gloo():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1"], "1")
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1                                  # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] == 2.0       # the max-reduce over both ranks went through
+
+
+def test_self_launch_fails_when_a_rank_fails():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1"], "fail1")
+    assert r.returncode != 0
+    assert not any('"n_gpus": 1' in l for l in r.stdout.decode().splitlines())     # never continues as one GPU
+    assert "rank process failed" in r.stderr.decode()
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4"], "1", dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode == 2 and b"WORLD_SIZE" in r.stderr
+
+
+def test_single_process_dry_run_does_not_import_torch():
+    r = _run(["--gpus", "1"], "1", dict(PYTHONVERBOSE=""))
+    assert r.returncode == 0 and json.loads(r.stdout.decode().strip())["n_gpus"] == 1
+    code = "import sys, runpy; sys.argv = ['bench.py', '--gpus', '1']; runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules" % BENCH
+    env = dict(os.environ, QRGPU_BENCH_DRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
