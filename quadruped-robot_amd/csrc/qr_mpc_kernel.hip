@@ -31,6 +31,7 @@
 //   phase 6  f -> J'(-R'f) torques, store.
 // ============================================================================
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "qr_device_types.h"
 #include "qr_wave_helpers.h"
 
@@ -67,9 +68,6 @@ namespace qrgpu {
 #define QR_DBGT ((long long *)nullptr)
 #define QR_DBGH ((float *)nullptr)
 #define QR_DBGG ((float *)nullptr)
-#endif
-#ifndef QR_HESS_VALU
-#define QR_HESS_VALU 0           // 1: K4 as hand-written fmaf chains on the VALU (round 1), kept for A/B runs; 0: v_mfma_f32_16x16x4_f32
 #endif
 
 __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
@@ -115,101 +113,6 @@ __device__ __forceinline__ void load_block(const double *Mb, int k, int kc, Blk 
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) B.m[3 * i + j] = p[i * si + j * sj];
-}
-
-// One 3x3 block pair of the Hessian: hab = H[3a.., 3b..], hba = H[3b.., 3a..] as the fp32 k-ordered fmaf
-// chains of  qH = temp * Bqp  (:411), then out = (hab + hba')/2 in fp64.  la/lb: original leg-step ids
-// (4*step + leg).  The caller fences the scheduler between blocks so that only one block's temporaries are live.
-__device__ __forceinline__ Blk hess_block(const float *sT, const float *sU, int la, int lb, int h, float dt, float dt2, float minv,
-                                        const float *weights, float alpha, float *Hd, int NV)
-{
-#pragma clang fp contract(off)      // the fp32 chain must be exactly the written sequence (bit-identical to the oracle)
-    Blk out;
-    const int ia = la >> 2, pa = la & 3, ib = lb >> 2, pb = lb & 3;   // horizon step, leg
-    float w2[12];
-#pragma unroll
-    for (int s = 0; s < 12; ++s) w2[s] = 2.f * weights[s];
-    const float dtm = dt * minv;
-    const float two_alpha = 2.f * alpha;
-    float Ta[3][3], Tb[3][3], Ua[3][3], Ub[3][3], Uaw[3][3], Ubw[3][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Ta[s][j] = sT[9 * pa + 3 * s + j]; Tb[s][j] = sT[9 * pb + 3 * s + j];
-            Ua[s][j] = dt * sU[9 * pa + 3 * s + j]; Ub[s][j] = dt * sU[9 * pb + 3 * s + j];      // G rows 6-8
-            Uaw[s][j] = Ua[s][j] * w2[6 + s]; Ubw[s][j] = Ub[s][j] * w2[6 + s];                  // temp = G*2w
-        }
-    float hab[3][3], hba[3][3];      // hab[i][j] = H[3a+i][3b+j],  hba[j][i] = H[3b+j][3a+i]
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { hab[i][j] = 0.f; hba[j][i] = 0.f; }
-    const int r0 = ia > ib ? ia : ib;
-    for (int r = r0; r < h; ++r) {
-        const float caa = ((float)(r - ia) + 0.5f) * dt2, cab = ((float)(r - ib) + 0.5f) * dt2;
-        // s = 0..2 : rows c_a * T
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            float ga[3], gb[3], gaw[3], gbw[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                ga[j] = caa * Ta[s][j]; gb[j] = cab * Tb[s][j];
-                gaw[j] = ga[j] * w2[s]; gbw[j] = gb[j] * w2[s];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    hab[i][j] = __builtin_fmaf(gaw[i], gb[j], hab[i][j]);
-                    hba[j][i] = __builtin_fmaf(gbw[j], ga[i], hba[j][i]);
-                }
-        }
-        // s = 3..5 : rows (c_a/m) e_i  -> only the (i,i) entry of the block
-        {
-            const float cama = caa * minv, camb = cab * minv;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                hab[i][i] = __builtin_fmaf(cama * w2[3 + i], camb, hab[i][i]);
-                hba[i][i] = __builtin_fmaf(camb * w2[3 + i], cama, hba[i][i]);
-            }
-        }
-        // s = 6..8 : rows dt * U
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    hab[i][j] = __builtin_fmaf(Uaw[s][i], Ub[s][j], hab[i][j]);
-                    hba[j][i] = __builtin_fmaf(Ubw[s][j], Ua[s][i], hba[j][i]);
-                }
-        // s = 9..11 : rows (dt/m) e_i
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            hab[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hab[i][i]);
-            hba[i][i] = __builtin_fmaf(dtm * w2[9 + i], dtm, hba[i][i]);
-        }
-    }
-    if (la == lb) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { hab[i][i] = hab[i][i] + two_alpha; hba[i][i] = hba[i][i] + two_alpha; }   // + 2 alpha I (:411)
-    }
-    // the stated QP depends on H only through (H + H')/2: average the two fp32 entries exactly in fp64
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) out.m[3 * i + j] = 0.5 * ((double)hab[i][j] + (double)hba[j][i]);
-    if (Hd) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Hd[(size_t)(3 * la + i) * NV + 3 * lb + j] = hab[i][j];
-                Hd[(size_t)(3 * lb + j) * NV + 3 * la + i] = hba[j][i];
-            }
-    }
-    return out;
 }
 
 // Phase 6: first-step forces (staged in LDS, 12 doubles) -> force[12][n], and tau = J^T (-R^T f) per leg
@@ -371,10 +274,14 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #if defined(QR_TRACE) || defined(QR_DIAG_REFAC)
 #define QR_TS(i) do { } while (0)
 #else
+#ifdef QR_K4_STAMPS      // (slots 4-6 carry the unit loop's accumulated times in this diagnostic build)
+#define QR_TS(i) do { if (QR_DBGT && tid == 0 && (i) < 4) QR_DBGT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
+#else
 #define QR_TS(i) do { if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
 #endif
+#endif
     QR_TS(0);
-#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
+#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
     if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
 #endif
     // ---------------- phase 0: inputs ----------------
@@ -383,8 +290,23 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     for (int i = tid; i < NL; i += NTHR) sGait[i] = io.g_gait[(size_t)i * n + rid];
     __syncthreads();
 
-    // ---------------- phase 1: SRBD terms (every thread keeps R in registers) ----------------
+    // ---------------- phase 1: SRBD terms ----------------
+    // R = quat.toRotationMatrix() from the quaternion: phases 1-2 keep it in registers; the output phase, a whole active set later, forms it
+    // again from the copy of the quaternion in sMisc[4..7] (nine VGPRs less to carry -- and spill -- through the 128-register main pass)
+    auto quat_to_R = [](float w, float x, float y, float z, float (&R)[3][3]) {
+#pragma clang fp contract(off)
+        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+        const float twx = tx * w, twy = ty * w, twz = tz * w;
+        const float txx = tx * x, txy = ty * x, txz = tz * x;
+        const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        R[0][0] = 1.f - (tyy + tzz); R[0][1] = txy - twz;         R[0][2] = txz + twy;
+        R[1][0] = txy + twz;         R[1][1] = 1.f - (txx + tzz); R[1][2] = tyz - twx;
+        R[2][0] = txz - twy;         R[2][1] = tyz + twx;         R[2][2] = 1.f - (txx + tyy);
+    };
     float R[3][3];
+    quat_to_R(sSt[6], sSt[7], sSt[8], sSt[9], R);
+    if (tid < 4) ((float *)sMisc)[4 + tid] = sSt[6 + tid];
+#if 0
     {
 #pragma clang fp contract(off)
         const float w = sSt[6], x = sSt[7], y = sSt[8], z = sSt[9];
@@ -396,6 +318,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         R[1][0] = txy + twz;         R[1][1] = 1.f - (txx + tzz); R[1][2] = tyz - twx;
         R[2][0] = txz - twy;         R[2][1] = tyz + twx;         R[2][2] = 1.f - (txx + tyy);
     }
+#endif
     const float dt = C.dt, dt2 = C.dt * C.dt, minv = 1.0f / C.mass;
     if (tid < 4) {
 #pragma clang fp contract(off)
@@ -450,6 +373,23 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             fmk[pos] = (double)(sGait[tid] * C.fmax);
         }
         if (tid == 0) { sMisc[0] = __popcll(mask); sMisc[1] = 0; sMisc[2] = (int)(unsigned)mask; sMisc[3] = (int)(unsigned)(mask >> 32); }
+        // The operand table of phase 2 (K4), one row per free variable e = 3 pos + i: T_p[0..2][i], dt U_p[0..2][i], (i_a | i << 8).  Lanes 0-3 of
+        // this same wave have just written T and U, so a wave-level sync is all it takes -- the table is complete at the barrier below and the
+        // tiles' lane constants are one LDS round trip (not a chain leg-step id -> leg -> T / U entry) and no barrier of their own away.
+        wave_sync();
+        if (fr) {
+#pragma clang fp contract(off)
+            const int pos = __popcll(mask & ((1ull << tid) - 1ull));
+            const int p = tid & 3;
+            float *sOp_ = (float *)xz;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float *o = sOp_ + 8 * (3 * pos + i);
+                o[0] = sT[9 * p + i]; o[1] = sT[9 * p + 3 + i]; o[2] = sT[9 * p + 6 + i];
+                o[3] = C.dt * sU[9 * p + i]; o[4] = C.dt * sU[9 * p + 3 + i]; o[5] = C.dt * sU[9 * p + 6 + i];
+                ((int *)o)[6] = (tid >> 2) | (i << 8);
+            }
+        }
     }
     // v = Aqp x0 - X_d, one horizon step per thread (wave 1 so it overlaps the above)
     if (tid >= 64 && tid < 64 + h) {
@@ -531,10 +471,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         return;
     }
 
-    float w2[13];
-#pragma unroll
-    for (int s = 0; s < 12; ++s) w2[s] = 2.f * C.weights[s];
-    w2[12] = 0.f;
     const float dtm = dt * minv;
     const float two_alpha = 2.f * C.alpha;
 
@@ -543,9 +479,47 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // v_mfma_f32_16x16x4_f32), [2] fp64 flops of the sweep and x0, [3] fp64 flops of the active set (rebuilds included).  mul and add count 1
     // each, fma 2.  Wave 0 keeps the sums (uniform) and stores them at the end.
     double fl_v32 = 0.0, fl_m32 = 0.0, fl_sw = 0.0, fl_as = 0.0;
-    // ---------------- phase 2: Hessian blocks (registers) + gradient (LDS) ----------------
-    // (the torque map's Jacobian columns first, on twelve lanes of the last wave: it owns the fewest blocks, so this hides behind wave 0's)
-    if (MAXB <= 4 && io.g_tau && tid >= 192 && tid < 204) { const int e = tid - 192; mpc_jacobian_column(e / 3, e - 3 * (e / 3), rid, n, C, io.g_q, sJ + 3 * e); }
+#ifdef QR_K4_STAMPS
+#define K4_TS(i) do { } while (0)
+#define K4_WAVE_END() do { if (QR_DBGT && lane == 0 && (tid >> 6) < 8) QR_DBGT[(size_t)rid * 16 + 8 + (tid >> 6)] = clock64(); } while (0)
+#else
+#define K4_WAVE_END() do { } while (0)
+#define K4_TS(i) do { } while (0)
+#endif
+    K4_TS(8);
+    // ---------------- phase 2: Hessian (matrix cores -> fp32 tiles in LDS -> blocks in registers) + gradient (LDS) ----------------
+    // (the torque map's Jacobian columns first, on twelve lanes of the last wave)
+    // The torque map's Jacobian columns (AnalyticalLegJacobian, QS/robots/qr_robot.cpp:148-172) on twelve lanes of the second-to-last wave (the
+    // snake below deals it the cheapest units): lane 3 leg + m takes the sine and cosine of ONE angle -- abad, hip + knee / 2, knee -- and
+    // the three lanes of a leg trade them by shuffles, instead of every lane evaluating its column's six to eight sinf / cosf itself.
+    if (MAXB <= 4 && io.g_tau && (tid & ~63) == NTHR - 128) {
+        const int l12 = lane < 12 ? lane : 0;
+        const int leg = (l12 * 21846) >> 16, m = l12 - 3 * leg;
+        const float t0 = io.g_q[(size_t)(3 * leg) * n + rid], t1 = io.g_q[(size_t)(3 * leg + 1) * n + rid], t2 = io.g_q[(size_t)(3 * leg + 2) * n + rid];
+        const float tEff = t1 + t2 / 2;
+        const float ang = (m == 0) ? t0 : ((m == 1) ? tEff : t2);
+        const float sn = sinf(ang), cs = cosf(ang);
+        const float s0 = __shfl(sn, 3 * leg, 64), c0 = __shfl(cs, 3 * leg, 64), sE = __shfl(sn, 3 * leg + 1, 64), cE = __shfl(cs, 3 * leg + 1, 64);
+        const float s2 = __shfl(sn, 3 * leg + 2, 64), c2 = __shfl(cs, 3 * leg + 2, 64);
+        const float lu = C.upper_l, ll = C.lower_l;
+        const float sh = C.hip_l * ((leg & 1) ? 1.f : -1.f);
+        const float lEff = sqrtf(lu * lu + ll * ll + 2 * lu * ll * c2);
+        float J0, J1, J2;
+        if (m == 0) {
+            J0 = 0;
+            J1 = -sh * s0 + lEff * c0 * cE;
+            J2 = sh * c0 + lEff * s0 * cE;
+        } else if (m == 1) {
+            J0 = -lEff * cE;
+            J1 = -lEff * s0 * sE;
+            J2 = lEff * sE * c0;
+        } else {
+            J0 = ll * lu * s2 * sE / lEff - lEff * cE / 2;
+            J1 = -ll * lu * s0 * s2 * cE / lEff - lEff * s0 * sE / 2;
+            J2 = ll * lu * s2 * c0 * cE / lEff + lEff * sE * c0 / 2;
+        }
+        if (lane < 12) { sJ[3 * lane] = J0; sJ[3 * lane + 1] = J1; sJ[3 * lane + 2] = J2; }
+    }
     int ba[MAXB], bb[MAXB];
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
@@ -555,69 +529,104 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             int a = (int)((__builtin_sqrtf(8.f * (float)pid + 1.f) - 1.f) * 0.5f);
             while (tri(a + 1) <= pid) ++a;
             while (tri(a) > pid) --a;
-            const int b = pid - tri(a);                 // a >= b
-            ba[sl] = a; bb[sl] = b;
-#if QR_HESS_VALU
-            const Blk Hb = hess_block(sT, sU, sLs[a], sLs[b], h, dt, dt2, minv, C.weights, C.alpha,
-                                      QR_DBGH ? QR_DBGH + (size_t)rid * NV * NV : nullptr, NV);
-            // parked in its final M slot: keeps the 18 VGPRs per block out of the build's register budget
-            double *dst = Mb + pid * 9;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) dst[i] = Hb.m[i];
-#endif
+            ba[sl] = a; bb[sl] = pid - tri(a);          // a >= b
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the blocks' temporaries from overlapping (register pressure)
     }
-#if !QR_HESS_VALU
     // K4 on the matrix cores:  qH = temp * Bqp (:411) restricted to the stance columns, as 16 x 16 tiles of v_mfma_f32_16x16x4_f32.
     // That instruction IS the k-ordered fp32 fmaf chain (MI355X_MICROARCH.md: "exact f32, == fmaf chain, bitwise"), so the result is bit
     // for bit the oracle's dense GEMM (tests/test_gpu_mpc.py::test_assembly_bit_exact); the terms it adds beyond the hand-written chain
     // are exact zeros.  k runs over (horizon step r, state row s): per step three instructions cover s = 0..11 (s = 12 has weight 0),
     // lane group g = lane >> 4 supplying s = 4 q + g of instruction q.  Operands are generated in registers from the closed form of
     // Adt^a Bdt (no Bqp in memory): G[(r, s)][(a, i)] = c * T_p[s][i] | c / m | dt U_p[s - 6][i] | dt / m, c = (r - i_a + 1/2) dt^2, zero for r < i_a.
-    // Only tiles on or below the diagonal are visited, each with TWO accumulators: H[e_r][e_c] = sum temp[e_r][k] G[k][e_c] and
-    // H[e_c][e_r] = sum G[k][e_r] temp[e_c][k] (the same products, a * b = b * a) land in the same lane and register, so the fp64 average
-    // (H + H') / 2 needs no transpose and goes straight to the block-packed slot the sweep loads from.
+    //
+    // Round 3 form.  The stated QP needs H[x][y] AND H[y][x] (fp32 rounds them differently; (H + H') / 2 is taken exactly in fp64).  A UNIT of
+    // work is one accumulator chain of one tile on or below the tile diagonal:
+    //   off-diagonal tile (R, C), C < R:  unit 0:  D[row][col] = sum temp[e_r][k] G[k][e_c] = H[e_r][e_c]
+    //                                     unit 1:  D[row][col] = sum G[k][e_r] temp[e_c][k] = H[e_c][e_r]   (same lane and register as unit 0's)
+    //   diagonal tile (R, R):             ONE unit: the tile holds both H[e_r][e_c] and, at the transposed position, H[e_c][e_r] -- the second
+    //                                     chain round 2 ran there repeated the same products in the same order (a * b = b * a): a quarter of
+    //                                     all matrix instructions, and the most expensive tiles (tile (0, 0) runs over every horizon step)
+    // A wave takes a whole tile (both chains of an off-diagonal one share every product but the weights: 29 vector instructions per step for
+    // the two, against 2 x 22 apart -- the phase is bound by instruction issue, four waves to a SIMD, not by the matrix pipe); tiles are
+    // enumerated row by row (cost h - first step of the row: descending) and dealt to the waves in snake order; each chain
+    // leaves its 16 x 16 fp32 accumulator in LDS (the M region, idle until the sweep) and the block owners form (H + H') / 2 from there as they
+    // load their blocks -- no fp64 conversion, division by three or scattered 8-byte store behind the matrix instructions any more.
+    // The lane constants of a tile side come from a per-variable table (sOp, in the xz exchange area, idle until phase 4) built once per
+    // robot, instead of a chain of dependent LDS reads (leg-step id -> leg -> T / U entries) per tile and side.
+#ifdef QR_K4_PRIO
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) __builtin_amdgcn_s_setprio(QR_K4_PRIO);
+#endif
+    const int NT = (ns + 15) >> 4;
+    const int NOD = (NT * (NT - 1)) >> 1;                  // off-diagonal tiles below the diagonal
+    float *Hs = (float *)Mb;                               // [2 NOD + NT][16][16]: buffers 2 t, 2 t + 1 of off-diagonal tile t = tri(R - 1) + C, then one per diagonal tile
+    float *sOp = (float *)xz;                              // [ns][8]: T_p[0..2][i], dt U_p[0..2][i], (i_a | i << 8), -
+    if ((long long)NT * NT * 1024 > (long long)P.lds_bytes - (long long)((Mb - smem) * 8)) {
+        // (h = 11 all stance in the main pass's half-CU allotment: to the list pass, like a robot whose S^-1 does not fit)
+        if (tid == 0) {
+            if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
+            if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+        }
+        return;
+    }
+    K4_TS(10);
     {
 #pragma clang fp contract(off)
         typedef float f4 __attribute__((ext_vector_type(4)));
         const int wvb = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int NT = (ns + 15) >> 4, NTL = tri(NT);
+        constexpr int NW = NTHR / 64;
         const int g = lane >> 4, lc = lane & 15;
         const float w2q0 = 2.f * C.weights[g], w2q1 = 2.f * C.weights[4 + g], w2q2 = 2.f * C.weights[8 + g];
         float *Hd = QR_DBGH ? QR_DBGH + (size_t)rid * NV * NV : nullptr;
-        // lane constants of one side (row tile or column tile): the leg-step behind index e = 16 * tile + lc and its operand recipe
+        // lane constants of one side (row tile or column tile): the variable behind index e = 16 * tile + lc and its operand recipe
         auto side = [&](int tile, int &ia, float &al0, float &al1, float &k1, float &k2) {
             const int e = 16 * tile + lc;
             const bool valid = e < ns;
-            const int a = (e * 21846) >> 16;                       // e / 3
-            const int ls = valid ? sLs[a] : 0;
-            const int p = ls & 3, i = e - 3 * a;
-            ia = valid ? (ls >> 2) : h;                            // (rows / columns past the matrix never switch on)
-            al0 = (g < 3) ? sT[9 * p + 3 * g + i] : ((i == 0) ? minv : 0.f);
+            const float *o = sOp + 8 * (valid ? e : 0);
+            const int meta = ((const int *)o)[6];
+            const float o0 = o[g < 3 ? g : 2], o1 = o[3 + (g >= 2 ? g - 2 : 0)], o2 = o[5];
+            const int i = meta >> 8;
+            ia = valid ? (meta & 255) : h;                         // (rows / columns past the matrix never switch on)
+            al0 = (g < 3) ? o0 : ((i == 0) ? minv : 0.f);
             al1 = (i == g + 1) ? minv : 0.f;                       // used by lane groups 0, 1 only (s = 4, 5)
-            k1 = dt * sU[9 * p + 3 * ((g >= 2) ? g - 2 : 0) + i];  // s = 6, 7 for lane groups 2, 3
-            k2 = (g == 0) ? dt * sU[9 * p + 6 + i] : ((i == g - 1) ? dtm : 0.f);      // s = 8 | 9, 10, 11
+            k1 = o1;                                               // s = 6, 7 for lane groups 2, 3
+            k2 = (g == 0) ? o2 : ((i == g - 1) ? dtm : 0.f);       // s = 8 | 9, 10, 11
         };
-#if defined(QR_DIAG_REFAC)
-        const long long th0 = clock64();
-        long long th_loop = 0;
+        const int NU = (NT * (NT + 1)) >> 1;            // one unit per tile on or below the tile diagonal
+#ifdef QR_K4_STAMPS
+        long long k4_loop = 0, k4_setup = 0, k4_dump = 0;
 #endif
-        for (int t = wvb; t < NTL; t += NTHR / 64) {
-            int R = (int)((__builtin_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-            while (tri(R + 1) <= t) ++R;
-            while (tri(R) > t) --R;
-            const int Cc = t - tri(R);                                  // R >= Cc
+        // Deal.  Units come tile row by tile row, i.e. in order of descending cost (a row's chains run over h - first step of the row).  The
+        // last two waves carry the gradient (below) and the Jacobian columns, so the first NW - 2 units go to waves 0 .. NW - 3, and the rest
+        // go back and forth over waves NW - 1 .. 1 (snake) -- wave 0 keeps tile (0, 0) alone, the one chain that runs over every horizon step.
+        constexpr int NF = NW > 2 ? NW - 2 : NW, per = 2 * (NW - 1);
+        for (int it = 0; it == 0 || (wvb != 0 && NF + (it - 1) * per < NU); ++it) {
+          for (int half = 0; half < 2; ++half) {
+            int u;
+            if (it == 0) { if (half || wvb >= NF) continue; u = wvb; }
+            else u = NF + (it - 1) * per + (half == 0 ? NW - 1 - wvb : NW - 2 + wvb);
+            if (u >= NU) continue;
+#ifdef QR_K4_STAMPS
+            const long long k4_t0 = clock64();
+#endif
+            int R = (int)((__builtin_sqrtf(8.f * (float)u + 1.f) - 1.f) * 0.5f);
+            while (tri(R + 1) <= u) ++R;
+            while (tri(R) > u) --R;
+            const int Cc = u - tri(R);
+            const bool diag = Cc == R;
             int iaR, iaC;
             float a0R, a1R, k1R, k2R, a0C, a1C, k1C, k2C;
             side(R, iaR, a0R, a1R, k1R, k2R);
             side(Cc, iaC, a0C, a1C, k1C, k2C);
+            // the weighted (temp = G * 2w, rounding order (dt U) * 2w as the reference's) forms of the constants
             const float t1R = k1R * w2q1, t2R = k2R * w2q2, t1C = k1C * w2q1, t2C = k2C * w2q2;
-            const int r0 = sLs[(16 * R * 21846) >> 16] >> 2;            // first step at which any entry of the tile switches on
+            const int r0 = __builtin_amdgcn_readfirstlane(((const int *)(sOp + 8 * 16 * R))[6]) & 255;      // first step at which any entry of the tile switches on
             f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#if defined(QR_DIAG_REFAC)
-            const long long tl0 = clock64();
+#ifdef QR_K4_STAMPS
+            asm volatile("" :: "v"(t1R), "v"(t2R), "v"(t1C), "v"(t2C), "v"(a0R), "v"(a0C), "s"(r0));
+            const long long k4_t1 = clock64();
 #endif
+            const float bR = 0.5f - (float)iaR, bC = 0.5f - (float)iaC;      // (r - i_a) + 1/2 is exact in fp32 either way
             if (P.hess_mode == 1) {
                 // BASELINE.json configs[4]'s arithmetic: the same contraction on the bf16 matrix cores.  Every fp32 operand is cut into three
                 // bf16 limbs (8 + 8 + 8 significant bits: x = hi + mid + lo exactly up to the last limb's rounding) and the product a * b is taken as
@@ -644,98 +653,133 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const bf8 zero8 = packA(0.f);
                 for (int r = r0; r < h; ++r) {
                     const bool onR = r >= iaR, onC = r >= iaC;
-                    const float cR = ((float)(r - iaR) + 0.5f) * dt2, cC = ((float)(r - iaC) + 0.5f) * dt2;
+                    const float rf = (float)r;
+                    const float cR = (rf + bR) * dt2, cC = (rf + bC) * dt2;
                     float gR = cR * a0R, gC = cC * a0C;
                     float tR = gR * w2q0, tC = gC * w2q0;
                     gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(packA(tR), packB(gC), acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(packA(gR), packB(tC), acc2, 0, 0, 0);
+                    if (!diag) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(packA(gR), packB(tC), acc2, 0, 0, 0);
                     const float hR = cR * a1R, hC = cC * a1C;
                     const bf8 a1t = (g < 2) ? packA(onR ? hR * w2q1 : 0.f) : (onR ? Ak1t : zero8);
-                    const bf8 a1g = (g < 2) ? packA(onR ? hR : 0.f) : (onR ? Ak1g : zero8);
                     const bf8 b1g = (g < 2) ? packB(onC ? hC : 0.f) : (onC ? Bk1g : zero8);
-                    const bf8 b1t = (g < 2) ? packB(onC ? hC * w2q1 : 0.f) : (onC ? Bk1t : zero8);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1t, b1g, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1g, b1t, acc2, 0, 0, 0);
+                    if (!diag) {
+                        const bf8 a1g = (g < 2) ? packA(onR ? hR : 0.f) : (onR ? Ak1g : zero8);
+                        const bf8 b1t = (g < 2) ? packB(onC ? hC * w2q1 : 0.f) : (onC ? Bk1t : zero8);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1g, b1t, acc2, 0, 0, 0);
+                    }
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onR ? Ak2t : zero8, onC ? Bk2g : zero8, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onR ? Ak2g : zero8, onC ? Bk2t : zero8, acc2, 0, 0, 0);
+                    if (!diag) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(onR ? Ak2g : zero8, onC ? Bk2t : zero8, acc2, 0, 0, 0);
                 }
-            } else
-            for (int r = r0; r < h; ++r) {
-                const bool onR = r >= iaR, onC = r >= iaC;
-                const float cR = ((float)(r - iaR) + 0.5f) * dt2, cC = ((float)(r - iaC) + 0.5f) * dt2;
-                // s = 0..3
-                float gR = cR * a0R, gC = cC * a0C;
-                float tR = gR * w2q0, tC = gC * w2q0;
-                gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
-                // s = 4..7
-                const float hR = cR * a1R, hC = cC * a1C;
-                gR = (g < 2) ? hR : k1R; tR = (g < 2) ? hR * w2q1 : t1R;
-                gC = (g < 2) ? hC : k1C; tC = (g < 2) ? hC * w2q1 : t1C;
-                gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
-                // s = 8..11
-                gR = onR ? k2R : 0.f; tR = onR ? t2R : 0.f; gC = onC ? k2C : 0.f; tC = onC ? t2C : 0.f;
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+            } else if (diag) {
+                // diagonal tile: one chain, D[row][col] = sum temp[e_r][k] G[k][e_c] = H[e_r][e_c] for BOTH triangles of the tile
+                for (int r = r0; r < h; ++r) {
+                    const bool onR = r >= iaR;
+                    const float cR = ((float)r + bR) * dt2;
+                    float gR = cR * a0R;
+                    float tR = gR * w2q0;
+                    gR = onR ? gR : 0.f; tR = onR ? tR : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gR, acc1, 0, 0, 0);
+                    const float hR = cR * a1R;
+                    gR = (g < 2) ? hR : k1R; tR = (g < 2) ? hR * w2q1 : t1R;
+                    gR = onR ? gR : 0.f; tR = onR ? tR : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gR, acc1, 0, 0, 0);
+                    gR = onR ? k2R : 0.f; tR = onR ? t2R : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gR, acc1, 0, 0, 0);
+                }
+            } else {
+                // off-diagonal tile: both chains, sharing every product but the weights:  acc1 = H[e_r][e_c],  acc2[row][col] = H[e_c][e_r]
+                for (int r = r0; r < h; ++r) {
+                    const bool onR = r >= iaR, onC = r >= iaC;
+                    const float rf = (float)r;
+                    const float cR = (rf + bR) * dt2, cC = (rf + bC) * dt2;
+                    // s = 0..3
+                    float gR = cR * a0R, gC = cC * a0C;
+                    float tR = gR * w2q0, tC = gC * w2q0;
+                    gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+                    // s = 4..7
+                    const float hR = cR * a1R, hC = cC * a1C;
+                    gR = (g < 2) ? hR : k1R; tR = (g < 2) ? hR * w2q1 : t1R;
+                    gC = (g < 2) ? hC : k1C; tC = (g < 2) ? hC * w2q1 : t1C;
+                    gR = onR ? gR : 0.f; tR = onR ? tR : 0.f; gC = onC ? gC : 0.f; tC = onC ? tC : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+                    // s = 8..11
+                    gR = onR ? k2R : 0.f; tR = onR ? t2R : 0.f; gC = onC ? k2C : 0.f; tC = onC ? t2C : 0.f;
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tR, gC, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
+                }
             }
-#if defined(QR_DIAG_REFAC)
+#ifdef QR_K4_STAMPS
             asm volatile("" :: "v"(acc1), "v"(acc2));
-            th_loop += clock64() - tl0;
+            const long long k4_t2 = clock64();
 #endif
-            // D[row = 4 g + reg][col = lc] of both accumulators -> (H + H') / 2 in fp64, block-packed
-            const int ec = 16 * Cc + lc;
-            const int bq = (ec * 21846) >> 16, j = ec - 3 * bq;
+            // D[row = 4 g + reg][col = lc] -> the tile's buffer(s), row-major (4-byte stores: lanes lc are contiguous)
+            float *buf = Hs + 256 * (diag ? 2 * NOD + R : 2 * (((R * (R - 1)) >> 1) + Cc));
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int er = 16 * R + 4 * g + reg;
-                if (er < ns && ec <= er) {
-                    const int aq = (er * 21846) >> 16, i = er - 3 * aq;
-                    float v1 = acc1[reg], v2 = acc2[reg];                 // H[er][ec], H[ec][er]
-                    if (er == ec) { v1 = v1 + two_alpha; v2 = v2 + two_alpha; }      // + 2 alpha I (:411)
-                    const double o = 0.5 * ((double)v1 + (double)v2);
-                    Mb[(tri(aq) + bq) * 9 + 3 * i + j] = o;
-                    if (aq == bq && i != j) Mb[(tri(aq) + aq) * 9 + 3 * j + i] = o;
-                    if (Hd) {
-                        const int la = sLs[aq], lb = sLs[bq];
-                        Hd[(size_t)(3 * la + i) * NV + 3 * lb + j] = v1;
-                        Hd[(size_t)(3 * lb + j) * NV + 3 * la + i] = v2;
+            for (int reg = 0; reg < 4; ++reg) buf[(4 * g + reg) * 16 + lc] = acc1[reg];
+            if (!diag) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) buf[256 + (4 * g + reg) * 16 + lc] = acc2[reg];
+            }
+            if (Hd) {
+                const int ec = 16 * Cc + lc;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int er = 16 * R + 4 * g + reg;
+                    if (er < ns && ec < ns) {
+                        const int aq = (er * 21846) >> 16, bq = (ec * 21846) >> 16;
+                        const int xr_ = 3 * sLs[aq] + (er - 3 * aq), xc_ = 3 * sLs[bq] + (ec - 3 * bq);
+                        Hd[(size_t)xr_ * NV + xc_] = acc1[reg] + ((er == ec) ? two_alpha : 0.f);             // + 2 alpha I (:411)
+                        if (!diag) Hd[(size_t)xc_ * NV + xr_] = acc2[reg];
                     }
                 }
             }
+#ifdef QR_K4_STAMPS
+            { const long long k4_t3 = clock64(); k4_setup += k4_t1 - k4_t0; k4_loop += k4_t2 - k4_t1; k4_dump += k4_t3 - k4_t2; }
+#endif
+          }
         }
-#if defined(QR_DIAG_REFAC)
-        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 4] = clock64() - th0; QR_DBGT[(size_t)rid * 16 + 5] = th_loop; QR_DBGT[(size_t)rid * 16 + 6] = NTL; }
+#ifdef QR_K4_STAMPS
+        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 4] = k4_setup; QR_DBGT[(size_t)rid * 16 + 5] = k4_loop; QR_DBGT[(size_t)rid * 16 + 6] = k4_dump; }
 #endif
     }
-#endif
-    // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread
-    for (int e = tid; e < ns; e += NTHR) {
+    K4_TS(11);
+    // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread -- on the last two waves (variable e and, beyond 128 of them, e + 128 per thread), which the deal above leaves out of its first pass
+    for (int e = tid - (NTHR - 128); e >= 0 && e < ns; e += 128) {
 #pragma clang fp contract(off)
         const int ls = sLs[e / 3], j = e % 3, ia = ls >> 2, p = ls & 3;
         const float t0 = sT[9 * p + j], t1 = sT[9 * p + 3 + j], t2 = sT[9 * p + 6 + j];
-        const float u0 = (dt * sU[9 * p + j]) * w2[6], u1 = (dt * sU[9 * p + 3 + j]) * w2[7], u2 = (dt * sU[9 * p + 6 + j]) * w2[8];
-        const float dw = dtm * w2[9 + j];
+        const float wg0 = 2.f * C.weights[0], wg1 = 2.f * C.weights[1], wg2 = 2.f * C.weights[2], wg3 = 2.f * C.weights[3 + j], wg9 = 2.f * C.weights[9 + j];
+        const float u0 = (dt * sU[9 * p + j]) * (2.f * C.weights[6]), u1 = (dt * sU[9 * p + 3 + j]) * (2.f * C.weights[7]), u2 = (dt * sU[9 * p + 6 + j]) * (2.f * C.weights[8]);
+        const float dw = dtm * wg9;
         float acc = 0.f;
-        for (int r = ia; r < h; ++r) {
-            const float ca = ((float)(r - ia) + 0.5f) * dt2;
+        const float bA = 0.5f - (float)ia;
+        for (int r = 0; r < h; ++r) {               // (uniform trip count: the step's broadcast loads of v pipeline; steps before i_a add nothing)
+            const float ca = ((float)r + bA) * dt2;
             const float *vr = sV + 13 * r;
-            acc = __builtin_fmaf((ca * t0) * w2[0], vr[0], acc);
-            acc = __builtin_fmaf((ca * t1) * w2[1], vr[1], acc);
-            acc = __builtin_fmaf((ca * t2) * w2[2], vr[2], acc);
-            acc = __builtin_fmaf((ca * minv) * w2[3 + j], vr[3 + j], acc);
-            acc = __builtin_fmaf(u0, vr[6], acc);
-            acc = __builtin_fmaf(u1, vr[7], acc);
-            acc = __builtin_fmaf(u2, vr[8], acc);
-            acc = __builtin_fmaf(dw, vr[9 + j], acc);
+            float a2 = acc;
+            a2 = __builtin_fmaf((ca * t0) * wg0, vr[0], a2);
+            a2 = __builtin_fmaf((ca * t1) * wg1, vr[1], a2);
+            a2 = __builtin_fmaf((ca * t2) * wg2, vr[2], a2);
+            a2 = __builtin_fmaf((ca * minv) * wg3, vr[3 + j], a2);
+            a2 = __builtin_fmaf(u0, vr[6], a2);
+            a2 = __builtin_fmaf(u1, vr[7], a2);
+            a2 = __builtin_fmaf(u2, vr[8], a2);
+            a2 = __builtin_fmaf(dw, vr[9 + j], a2);
+            acc = (r >= ia) ? a2 : acc;
         }
         gl[e] = (double)acc;
         if (QR_DBGG) QR_DBGG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
     for (int c = tid; c < 6 * nls; c += NTHR) sPos[c] = -1;
+#ifdef QR_K4_PRIO
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) __builtin_amdgcn_s_setprio(0);
+#endif
+    K4_WAVE_END();
     QR_TS(2);
 
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
@@ -743,17 +787,44 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
     // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
     Blk A[MAXB];
-#if !QR_HESS_VALU
-    __syncthreads();               // the Hessian blocks were written by the waves that ran their tiles
-#endif
+    __syncthreads();               // every unit's tile is in LDS
+    K4_TS(12);
+    // block (a, b), a >= b, of (H + H') / 2: entry (i, j) from H[x][y] and H[y][x], x = 3 a + i >= y = 3 b + j (the block's lower half when
+    // a = b), both fp32, averaged exactly in fp64.  Off-diagonal tile (R, C): buffers at 512 (tri(R - 1) + C), H[x][y] at [x & 15][y & 15] of
+    // the first, H[y][x] at the same place of the second; diagonal tile: one buffer, H[y][x] at the transposed place.
 #pragma unroll
     for (int sl = 0; sl < MAXB; ++sl) {
         if (ba[sl] >= 0) {
-            const double *src = Mb + (tid + NTHR * sl) * 9;
+            const int a = ba[sl], b = bb[sl];
+            int rowp[3], rr[3], Rx[3], colp[3], cc[3];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) A[sl].m[i] = src[i];
+            for (int i = 0; i < 3; ++i) {
+                const int x = 3 * a + i, y = 3 * b + i;
+                Rx[i] = x >> 4; rr[i] = x & 15; rowp[i] = 256 * Rx[i] * (Rx[i] - 1) + 16 * rr[i];
+                cc[i] = y & 15; colp[i] = 512 * (y >> 4) + cc[i];
+            }
+            const int dbase = 512 * NOD;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (a == b && j > i) continue;                              // (mirrored below)
+                    const bool od = Rx[i] != ((3 * b + j) >> 4);
+                    const int dg = dbase + 256 * Rx[i];
+                    const int a1 = od ? rowp[i] + colp[j] : dg + 16 * rr[i] + cc[j];
+                    const int a2 = od ? a1 + 256 : dg + 16 * cc[j] + rr[i];
+                    float v1 = Hs[a1], v2 = Hs[a2];
+                    if (a == b && i == j) {
+#pragma clang fp contract(off)
+                        v1 = v1 + two_alpha; v2 = v1;                          // + 2 alpha I (:411), in fp32 as the reference adds it
+                    }
+                    const double o = 0.5 * ((double)v1 + (double)v2);
+                    A[sl].m[3 * i + j] = o;
+                    if (a == b) A[sl].m[3 * j + i] = o;
+                }
         }
     }
+    K4_TS(14);
     __syncthreads();               // every block is in registers: the M region can now carry the pivot panels
     // A wave beyond the active set's four that owns no block (a trotting robot's 300 blocks fill 4.7 of the 8 waves) is done: it would only
     // load panels and wait at barriers (a wave that has ended no longer counts there), competing for the LDS pipe with the ones that work.
@@ -884,11 +955,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
     if (QR_PFLOPS) {
-        const int NTf = (ns + 15) >> 4;
-        double steps = 0.0;                              // tile x horizon-step pairs of the lower tile triangle
-        for (int Rf = 0; Rf < NTf; ++Rf) steps += (double)(Rf + 1) * (double)(h - (sLs[(16 * Rf * 21846) >> 16] >> 2));
-        fl_m32 = steps * 6.0 * 2048.0;                   // 2 accumulators x 3 instructions, 2 * 16 * 16 * 4 flops each
-        fl_v32 = steps * 64.0 * 12.0;                    // operand generation: 12 mul / add per lane and step
+        double steps = 0.0;                              // chain x horizon-step pairs: two chains per off-diagonal tile, one per diagonal tile
+        for (int Rf = 0; Rf < NT; ++Rf) steps += (double)(2 * Rf + 1) * (double)(h - (sLs[(16 * Rf * 21846) >> 16] >> 2));
+        fl_m32 = steps * 3.0 * 2048.0;                   // 3 instructions per chain and step, 2 * 16 * 16 * 4 flops each
+        fl_v32 = steps * 64.0 * 8.0;                     // operand generation: ~8 mul / add per lane, chain and step
         double gsteps = 0.0;
         for (int kf = 0; kf < nls; ++kf) gsteps += (double)(h - (sLs[kf] >> 2));
         fl_v32 += gsteps * 3.0 * 24.0;                   // gradient: 8 fma + 8 mul per variable and step
@@ -1592,7 +1662,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         wave_sync();
         if (own) { const int ls = sLs[kme]; if (ls < 4) { xz[3 * ls] = x0; xz[3 * ls + 1] = x1; xz[3 * ls + 2] = x2; } }
         wave_sync();
-        mpc_outputs(lane, rid, n, xz, R, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
+        {
+            float Ro[3][3];
+            const float *qs = (const float *)sMisc + 4;
+            quat_to_R(qs[0], qs[1], qs[2], qs[3], Ro);
+            mpc_outputs(lane, rid, n, xz, Ro, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
+        }
         if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
         if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
         if (lane == 0 && QR_PFLOPS) { double *fo = QR_PFLOPS + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
@@ -1611,11 +1686,15 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8);
         }
         QR_TS(6);
-#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS)
+#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
         if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 13] = wall_clock64();
 #endif
 #ifndef QR_TRACE
+#ifdef QR_K4_STAMPS
+        if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; }
+#else
         if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; QR_DBGT[(size_t)rid * 16 + 14] = q; }
+#endif
 #ifdef QR_GI_STAMPS
         if (lane == 0 && QR_DBGT) for (int i = 0; i < 6; ++i) QR_DBGT[(size_t)rid * 16 + 8 + i] = cs_t[i];
 #endif

@@ -99,7 +99,8 @@ def comm_unique_id():
 
 
 def lib_path():
-    return os.path.join(_HERE, "libqrgpu.so")
+    """The in-tree library; QRGPU_LIB names another build of it for A/B runs on one box (scratch/ab_bench.sh)."""
+    return os.environ.get("QRGPU_LIB") or os.path.join(_HERE, "libqrgpu.so")
 
 
 EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_set_stream", "qrgpu_last_error",
