@@ -103,6 +103,7 @@ typedef enum {
 #define QRGPU_ST_MPC_NOTSPD    0x8    /* Hessian pivot <= 0                          */
 #define QRGPU_ST_BAD_TYPE      0x01000000  /* d_type_id names a type outside [0, QRGPU_MAX_TYPES) or one that was never set up: the robot was
                                          computed with the first type that was set up and its result must not be used */
+#define QRGPU_ST_PIPE_TIMEOUT  0x02000000  /* pipelined tick: the WBC never saw this robot's MPC forces arrive; the torques must not be used */
 #define QRGPU_ST_WBC_MAXITER   0x10
 #define QRGPU_ST_WBC_INFEAS    0x20
 #define QRGPU_ST_VMC_MAXITER   0x40
@@ -167,6 +168,13 @@ int  qrgpu_set_planned_list(qrgpu_ctx *ctx, int on, int big_nls);
  * empty launch, at most 64 robots per call (the rest keep QRGPU_ST_MPC_OVERFLOW), h <= 11 only (at h = 16 such robots keep S^-1 in a global scratch instead).
  * A robot nothing can hold keeps QRGPU_ST_MPC_OVERFLOW. */
 int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
+/* Pipelined tick (default on; batches of 64 robots and more): qrgpu_tick_batch queues its WBC launch on a stream of the context's own
+ * BESIDE the MPC launches instead of behind them.  Of a robot's WBC only the relaxation QP at its end reads the MPC's forces, so a WBC
+ * workgroup runs dynamics, task set and kinematic projection while its robot's solve is still going and takes the forces when that
+ * solve raises the robot's flag; the call's outputs are complete when the context stream's work is (stream order, as before).  Scheduling
+ * only: results are those of the serial form bit for bit.  A WBC workgroup that waits longer than 4 ms for its robot (never observed)
+ * gives the robot QRGPU_ST_PIPE_TIMEOUT. */
+int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
 const char *qrgpu_last_error(const qrgpu_ctx *ctx);
 /* Device facts for reports: returns CU count, writes name (<= len). */
 int  qrgpu_device_info(const qrgpu_ctx *ctx, char *name, int len, int *lds_per_cu_bytes);

@@ -85,7 +85,15 @@ struct MpcLaunch {
     int type_ready;             // bit t: type t was set up (robots naming any other type are flagged QRGPU_ST_BAD_TYPE)
     int epilogue;               // QRGPU_EPILOGUE_* bits applied to g_tau (MPC-only batches; 0 inside the fused tick)
     int hess_mode;              // K4 arithmetic: 0 = fp32 matrix instruction (exact fmaf chain), 1 = three-limb bf16 on the bf16 matrix instruction
+    // Pipelined tick (qrgpu_tick_batch): the WBC launch runs BESIDE the MPC launches on a stream of its own and takes a robot's
+    // forces as soon as that robot's solve has stored them.  done_flag[robot] = (tick epoch << 1) | on-the-rescue-list, written by the solve
+    // with an agent-scope store behind its write-through (sc1) output stores; main_started: bumped by every workgroup of the main pass as it
+    // starts (the WBC launch is gated on the whole main pass being resident, so that it can never take a CU from a solve it waits for).
+    unsigned *done_flag;
+    unsigned done_epoch;
+    int *main_started;
 };
+#define QRGPU_ST_PIPE_TIMEOUT_D 0x02000000   // pipelined tick: the WBC gave up waiting for this robot's MPC forces (never seen; never silent)
 
 // Force-balance QP parameters (qrgpu_vmc_desc): ComputeContactForce's arguments that do not change per tick.
 struct VmcType {
@@ -151,6 +159,15 @@ __host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h, bool multi)
     b += 4 * 16;                                                       // sMisc (+ the control block of the control/worker loop)
     return (b + 7) & ~(size_t)7;
 }
+
+// Pipelined tick, WBC side (qr_wbc_kernel): flag / epoch: the per-robot flags the MPC solves raise (MpcLaunch::done_flag); list / list_count: a
+// second pass over the robots of a list (the MPC's rescue list) instead of the whole batch.  All null / zero: the plain launch.
+struct WbcPipe {
+    const unsigned *flag;
+    unsigned epoch;
+    const int *list;
+    const int *list_count;
+};
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)
 // reduced to rigid-body parameters, plus the controller gains (include/qrgpu.h qrgpu_model_desc).

@@ -155,14 +155,20 @@ __device__ __forceinline__ float torque_epilogue(float tau, int motor, bool comp
     return (float)t;
 }
 
+// (st_out: a plain store, or -- pipelined tick, where another launch reads the value while this one still runs -- an agent-scope one:
+//  global_store ... sc1, written through to memory)
+__device__ __forceinline__ void st_out(float *p, float v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const double *yl, const float (&R)[3][3], const float *sJ, const MpcType &C,
                                             const float *__restrict__ g_q, float *__restrict__ g_force, float *__restrict__ g_force_wbc,
-                                            int force_stride, float *__restrict__ g_tau, int epilogue)
+                                            int force_stride, float *__restrict__ g_tau, int epilogue, bool through = false)
 {
     if (lane < 12) {
         const int leg = lane / 3;
         const float fx = (float)yl[3 * leg], fy = (float)yl[3 * leg + 1], fz = (float)yl[3 * leg + 2];
-        g_force[(size_t)lane * n + rid] = (float)yl[lane];
+        st_out(&g_force[(size_t)lane * n + rid], (float)yl[lane], through);
         if (g_force_wbc) g_force_wbc[(size_t)(force_stride + lane) * n + rid] = (float)yl[lane];
         if (g_tau) {
             // f_ff = -R^T f  (R^T = quaternionToRotationMatrix(quat)), tau = J^T f_ff
@@ -173,7 +179,7 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
             if (!sJ) mpc_jacobian_column(leg, lane - 3 * leg, rid, n, C, g_q, Jl);      // (h = 16 variants: no LDS to spare for the early copy)
             const float J0 = sJ ? sJ[3 * lane] : Jl[0], J1 = sJ ? sJ[3 * lane + 1] : Jl[1], J2 = sJ ? sJ[3 * lane + 2] : Jl[2];
             const float tq = J0 * fff[0] + J1 * fff[1] + J2 * fff[2];
-            g_tau[(size_t)lane * n + rid] = epilogue ? torque_epilogue(tq, lane, true, epilogue) : tq;
+            st_out(&g_tau[(size_t)lane * n + rid], epilogue ? torque_epilogue(tq, lane, true, epilogue) : tq, through);
         }
     }
 }
@@ -467,6 +473,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+            if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -566,6 +573,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
             if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+            if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -1666,10 +1674,20 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             float Ro[3][3];
             const float *qs = (const float *)sMisc + 4;
             quat_to_R(qs[0], qs[1], qs[2], qs[3], Ro);
-            mpc_outputs(lane, rid, n, xz, Ro, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue);
+            mpc_outputs(lane, rid, n, xz, Ro, sJ, C, io.g_q, io.g_force, io.g_force_wbc, io.force_stride, io.g_tau, P.epilogue, P.done_flag != nullptr);
         }
-        if (lane == 0 && io.g_status) io.g_status[rid] = st | ((iter & 0xffff) << 8);
+        if (lane == 0 && io.g_status) {
+            if (P.done_flag) __hip_atomic_store(io.g_status + rid, st | ((iter & 0xffff) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else io.g_status[rid] = st | ((iter & 0xffff) << 8);
+        }
         if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+        if (P.done_flag) {
+            // pipelined tick: the forces, torques and status word of this robot are on their way to memory (write-through stores of this very
+            // wave): wait for them, then raise the robot's flag for the WBC workgroup that is waiting for it (or, for a robot on its way to the
+            // list pass, tell that workgroup to leave it to the WBC pass behind the list launch)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | (to_rescue ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (lane == 0 && QR_PFLOPS) { double *fo = QR_PFLOPS + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
         if (lane == 0 && P.cost) {
             const long long c = (clock64() - t_begin) >> 12;
@@ -1713,6 +1731,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
     if (P.started && threadIdx.x == 0) atomicAdd(P.started, 1);        // (planned list launches: see qr_gate_kernel)
+    if (!LIST && P.main_started && P.rescue_mode == 0 && threadIdx.x == 0) atomicAdd(P.main_started, 1);     // (pipelined tick: the WBC launch's gate)
     if constexpr (LIST) {
         const bool planned = P.rescue_mode == 2;
         if (!planned && blockIdx.x < 8) {

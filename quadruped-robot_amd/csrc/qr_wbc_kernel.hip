@@ -341,7 +341,7 @@ __device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6]
 __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, const int n, const WbcConst &K, const int nc, const unsigned cpack, const bool bad_type,
                                                  const real *A, const real *JC, const real *qdd, const real *Cv, const real *Gv, const real *cm, real *W, int *sI,
                                                  float *__restrict__ g_tau, int *__restrict__ g_status, const int merge_tau, const int status_or, const int epilogue,
-                                                 long long *__restrict__ dbgT, float *__restrict__ g_qp)
+                                                 long long *__restrict__ dbgT, float *__restrict__ g_qp, const bool piped = false, float *__restrict__ g_prev = nullptr)
 {
 #define QW_TSF(i) do { if (dbgT && (threadIdx.x & 63) == 0 && threadIdx.x < 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     int qp_iters = 0;
@@ -589,13 +589,19 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
             // K14 tail (fused tick): UpdateLegCMD overwrites the stance legs (:205-219) AFTER qrFSMStateLocomotion::Run added the +-0.9 N m abad
             // compensation to every leg (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), so the compensation survives on swing legs only (their
             // command is what the MPC kernel left in g_tau); then the +-23 N m clip (QS/fsm/qr_safety_checker.cpp:48-66).  legCmd.tua is a double.
-            double t = stance ? (double)(float)acc : (double)g_tau[(size_t)lane * n + rid];
+            double t = stance ? (double)(float)acc
+                              : (double)(piped ? __hip_atomic_load(g_tau + (size_t)lane * n + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_tau[(size_t)lane * n + rid]);
             if (!stance && (epilogue & 1) && lane % 3 == 0) t += (double)((leg & 1) ? 0.9f : -0.9f);
             if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
             g_tau[(size_t)lane * n + rid] = (float)t;
         }
     }
-    if (lane == 0 && g_status) { if (status_or) g_status[rid] |= stw; else g_status[rid] = stw; }
+    if (g_prev && lane < 3) g_prev[(size_t)lane * n + rid] = (float)cm[12 + lane];          // desiredVel of the orientation task (quirk 4's memory)
+    if (lane == 0 && g_status) {
+        if (status_or & 2) stw |= QRGPU_ST_PIPE_TIMEOUT_D;
+        if (status_or & 1) g_status[rid] = stw | (piped ? __hip_atomic_load(g_status + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_status[rid]);
+        else g_status[rid] = stw;
+    }
     QW_TSF(9);
 #undef QW_TSF
 }
@@ -614,7 +620,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                    float *__restrict__ g_dbg, int merge_tau, int status_or, long long *__restrict__ dbgT,
                    const float *__restrict__ g_fr /* [12][n] Fr_des override (the MPC's forces in the fused tick) or null */,
                    int type_ready /* bit t: type t was set up */, int epilogue /* QRGPU_EPILOGUE_* bits (fused tick only) */,
-                   float *__restrict__ g_qp /* [n][30] inspection: the relaxation QP's z[18] and optimalFr[12], or null */)
+                   float *__restrict__ g_qp /* [n][30] inspection: the relaxation QP's z[18] and optimalFr[12], or null */,
+                   WbcPipe pipe /* pipelined tick: per-robot flags of the MPC launches running beside this one; or the list of a second pass */)
 {
 #ifndef QR_WBC_DBG_BUILD      // (the timed path's kernel carries neither the inspection outputs nor the cycle stamps: 2.5 % of its time; qr_wbc_kernel_dbg.hip
     dbgT = nullptr; g_dbg = nullptr; g_qp = nullptr;      //  compiles this file once more with them in, as qr_wbc_kernel_dbg, for the launches that ask for either)
@@ -623,9 +630,16 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 #define QW_TS1(i) do { if (dbgT && threadIdx.x == 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
     int qp_iters = 0;
-    const int rid = xcd_robot_index(blockIdx.x, n);
+    int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (pipe.list) {
+        // second pass of a pipelined tick: the robots the trailing MPC list launch has just re-solved (normally none)
+        int cnt = *pipe.list_count;
+        cnt = cnt < n ? cnt : n;
+        if ((int)blockIdx.x >= cnt) return;
+        rid = pipe.list[blockIdx.x];
+    }
     if (rid < 0) return;
     int tyid = type_id ? type_id[rid] : 0;
     const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
@@ -669,7 +683,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         for (int e = lane; e < 324; e += 64) A[e] = 0.0;
         for (int e = lane; e < 216; e += 64) JcA[e] = 0.0;
     } else if (g_tau) {
-        for (int i = lane; i < 67; i += 64) cm[i] = (real)((g_fr && i >= 51 && i < 63) ? g_fr[(size_t)(i - 51) * n + rid] : g_cmd[(size_t)i * n + rid]);
+        // (pipelined tick: the MPC's forces are taken right in front of the relaxation QP, the only place that reads them, once the robot's flag is up)
+        for (int i = lane; i < 67; i += 64) cm[i] = (real)((g_fr && i >= 51 && i < 63) ? (pipe.flag ? 0.f : g_fr[(size_t)(i - 51) * n + rid]) : g_cmd[(size_t)i * n + rid]);
     }
     __syncthreads();
     const real *quat = st, *pos = st + 4, *bv = st + 7, *qj = st + 13, *qdj = st + 25;
@@ -1012,8 +1027,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                 tkV[i] = cm[12 + i];
                 real x = K.kp_ori * so[i] + K.kd_ori * vev[i] + 0.0;
                 tkX[i] = fmin(fmax(x, -10.0), 10.0);
-                g_prev[(size_t)i * n + rid] = (float)cm[12 + i];
             }
+            // (this call's desiredVel becomes the next call's "previous" one, g_prev: stored by wave 0 at the very end -- in a pipelined tick a
+            //  robot that turns out to be on the MPC's list pass is computed again by the second WBC pass and must find g_prev as it was)
         }
         // --- position task (qr_task_body_position.cpp:43-67)
         {
@@ -1237,7 +1253,27 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (t < nt - 1) npre_update(T2); else wsync();
     }
 
-    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or, epilogue, dbgT, g_qp);
+    int pipe_st = 0;
+    if (pipe.flag) {
+        // Everything up to here needed the robot's state and commands only; the relaxation QP needs the MPC's first-step forces.  The robot's
+        // solve raises done_flag[robot] to this tick's epoch behind its write-through stores of force / tau / status (qr_mpc_kernel.hip): poll
+        // it with agent-scope (sc1) loads -- bounded: 4 ms of the 100 MHz clock, then the robot is flagged, never silently wrong -- and take the
+        // forces with loads of the same kind (they bypass this CU's L1, which may hold last tick's line).
+        unsigned v = 0;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            v = __hip_atomic_load(pipe.flag + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 1) == pipe.epoch) break;
+            if (wall_clock64() - t0 > 400000) { pipe_st = QRGPU_ST_PIPE_TIMEOUT_D; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (!pipe_st && (v & 1u)) return;              // on the MPC's list pass: the second WBC pass behind that launch takes this robot
+        if (lane < 12) cm[51 + lane] = (real)__hip_atomic_load(g_fr + (size_t)lane * n + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wsync();
+    }
+    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or | (pipe_st ? 2 : 0), epilogue, dbgT, g_qp,
+                     pipe.flag != nullptr, g_prev);
 }
 
 }  // namespace qrgpu

@@ -56,10 +56,10 @@ __global__ void qr_frontend_kernel(int n, int horizon, int numHorizonL, float dt
                                    float *g_gait, float *g_cmd, int *g_updated);
 __global__ void qr_wbc_kernel(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                               float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
-                              const float *g_fr, int type_ready, int epilogue, float *g_qp);
+                              const float *g_fr, int type_ready, int epilogue, float *g_qp, WbcPipe pipe);
 __global__ void qr_wbc_kernel_dbg(int n, const WbcConst *types, const int *type_id, const float *g_state, const float *g_cmd,
                                   float *g_prev, float *g_tau, float *g_qdes, int *g_status, float *g_dbg, int merge_tau, int status_or, long long *dbgT,
-                                  const float *g_fr, int type_ready, int epilogue, float *g_qp);
+                                  const float *g_fr, int type_ready, int epilogue, float *g_qp, WbcPipe pipe);
 }
 
 // MPC kernel variants: 0 = <5, BIG, ., 512> (h <= 16), 1 = <9, BIG, ., 256> (h <= 16, A/B), 2 = <4, ., ., 256> (h <= 11, A/B), 3 = <2, ., ., 512> (h <= 11
@@ -109,8 +109,8 @@ static int mpc_lds_bytes(const qrgpu_ctx *ctx, int h, bool inspection = false)
 }
 
 struct TimerScope {
-    qrgpu_ctx *c; int k; bool on;
-    TimerScope(qrgpu_ctx *ctx, int kernel) : c(ctx), k(kernel), on(ctx->timing)
+    qrgpu_ctx *c; int k; bool on; hipStream_t s;
+    TimerScope(qrgpu_ctx *ctx, int kernel, hipStream_t stream = nullptr, bool enabled = true) : c(ctx), k(kernel), on(ctx->timing && enabled), s(stream ? stream : ctx->stream)
     {
         if (on && ctx->timing_every > 1 && (ctx->ev_calls[kernel]++ % (unsigned)ctx->timing_every) != 0) on = false;
         if (!on) return;
@@ -119,12 +119,12 @@ struct TimerScope {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             c->ev[k].push_back({a, b});
         }
-        hipEventRecord(c->ev[k][c->ev_used[k]].first, c->stream);
+        hipEventRecord(c->ev[k][c->ev_used[k]].first, s);
     }
     ~TimerScope()
     {
         if (!on) return;
-        hipEventRecord(c->ev[k][c->ev_used[k]].second, c->stream);
+        hipEventRecord(c->ev[k][c->ev_used[k]].second, s);
         c->ev_used[k]++;
     }
 };
@@ -281,7 +281,10 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_pre_hint, c->h_pre_count, 0) != hipSuccess ||
         hipMalloc(&c->d_started, sizeof(int)) != hipSuccess || hipMemset(c->d_started, 0, sizeof(int)) != hipSuccess ||
-        create_side_stream(&c->side_stream) != hipSuccess ||
+        create_side_stream(&c->side_stream) != hipSuccess || hipStreamCreateWithFlags(&c->wbc_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_wbc_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_wbc_join, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
+        hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
@@ -318,6 +321,11 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
+    if (c->wbc_stream) hipStreamDestroy(c->wbc_stream);
+    if (c->ev_wbc_fork) hipEventDestroy(c->ev_wbc_fork);
+    if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
+    if (c->d_done_flag) hipFree(c->d_done_flag);
+    if (c->d_main_started) hipFree(c->d_main_started);
     if (c->d_started) hipFree(c->d_started);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
@@ -350,6 +358,12 @@ int qrgpu_set_planned_list(qrgpu_ctx *c, int on, int big_nls)
     c->planned = on != 0;
     c->big_nls = big_nls;
     c->plan_n = 0;
+    return QRGPU_OK;
+}
+int qrgpu_set_tick_pipeline(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->pipeline = on != 0;
     return QRGPU_OK;
 }
 int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
@@ -410,7 +424,8 @@ static int upload_wbc(qrgpu_ctx *c)
 static int ready_mask(const bool *r) { int m = 0; for (int t = 0; t < QR_MAX_TYPES; ++t) if (r[t]) m |= 1 << t; return m; }
 
 static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_traj, const float *d_gait,
-                      const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc, int epilogue = 0)
+                      const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc, int epilogue = 0,
+                      bool piped = false)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state || !d_traj || !d_gait || !d_force) return QRGPU_ERR_BAD_ARG;
     if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
@@ -421,6 +436,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.n = n;
     P.type_ready = ready_mask(c->mpc_ready);
     P.epilogue = epilogue;
+    // pipelined tick: the solves raise per-robot flags for the WBC launch that runs beside them (qrgpu_tick_batch)
+    P.done_flag = piped ? c->d_done_flag : nullptr;
+    P.done_epoch = c->tick_epoch;
+    P.main_started = piped ? c->d_main_started : nullptr;
     P.flops = (c->flops_on && !dH) ? c->d_flops : nullptr;
     if (P.flops) c->flops_n = n;
     // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
@@ -556,6 +575,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
+        R.done_flag = nullptr; R.main_started = nullptr;      // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass)
         R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
@@ -570,8 +590,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
         // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
         c->plan_n = planned ? n : 0;
+        c->last_rescue_parity = c->rescue_parity;
         c->rescue_parity ^= 1;
     }
+    c->last_rescue_active = rescue;
+    if (piped) c->main_started_total += (int)(8 * ((n + 7) / 8));
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {
         hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
@@ -594,7 +617,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr)
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr})
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -602,12 +625,13 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_wbc(c);
     if (rc) return rc;
+    const hipStream_t ws = stream_override ? stream_override : c->stream;
     {
-        TimerScope ts(c, 1);
+        TimerScope ts(c, 1, ws, pipe.list == nullptr);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
         // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
-        hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, c->stream, n, c->d_wbc, d_type, d_state,
+        hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, ws, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
-                           ready_mask(c->wbc_ready), epilogue, d_qp);
+                           ready_mask(c->wbc_ready), epilogue, d_qp, pipe);
     }
     HIPCHK(c, hipGetLastError());
     return QRGPU_OK;
@@ -907,11 +931,48 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     HIPCHK(c, hipSetDevice(c->device));
     // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written.
     // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
-    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, d_force ? d_force : c->d_cmd_tick, d_tau, d_status,
-                        nullptr, nullptr, nullptr, 0);
+    float *const force = d_force ? d_force : c->d_cmd_tick;
+    static const int pipe_env = [] { const char *e = getenv("QRGPU_TICK_PIPELINE"); return e ? atoi(e) : 1; }();
+    const bool piped = c->pipeline && pipe_env != 0 && n >= 64 && !c->d_dbg_cycles && !c->d_dbg_cycles_wbc;
+    if (!piped) {
+        int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0);
+        if (rc) return rc;
+        return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue);
+    }
+    // Pipelined tick.  Of a robot's WBC only the relaxation QP at its very end reads the MPC's forces, and the MPC launch spends its last third
+    // with most of its slots empty (two rounds of robots of very different length: DESIGN.md 5).  So the WBC launch goes on a stream of its own
+    // beside the MPC launches: a gate holds it until every workgroup of the main pass has started (it must never take a CU from a solve it is
+    // going to wait for), then its workgroups settle wherever a solve has left, run the rigid-body dynamics, the task set and the kinematic
+    // projection, and wait -- bounded -- at the QP for their robot's flag (qr_wbc_kernel.hip, qr_mpc_kernel.hip).  Robots the main pass hands
+    // to its trailing list launch are skipped there and taken by a second, list-driven WBC pass queued behind that launch.
+    if (++c->tick_epoch >= 0x7fffffffu) c->tick_epoch = 1;
+    // (No fork event from the context stream: the gate below opens only once this tick's main pass -- queued on the context stream behind
+    //  everything the caller put there -- is running, and the WBC launch of the previous tick is ahead of this one on the same stream.
+    //  QRGPU_PIPE_FORK=1 puts the event back: 10-15 us of cross-stream hand-over per tick.)
+    static const int pipe_fork = [] { const char *e = getenv("QRGPU_PIPE_FORK"); return e ? atoi(e) : 0; }();
+    if (pipe_fork) {
+        HIPCHK(c, hipEventRecord(c->ev_wbc_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->wbc_stream, c->ev_wbc_fork, 0));
+    }
+    // (QRGPU_PIPE_EARLY=K opens the gate K workgroups early: an experiment)
+    static const int pipe_early = [] { const char *e = getenv("QRGPU_PIPE_EARLY"); return e ? atoi(e) : 0; }();
+    const int expect = c->main_started_total + (int)(8 * ((n + 7) / 8)) - pipe_early;          // (launch_mpc adds the grid to main_started_total)
+    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, (long long)1000000);
+    HIPCHK(c, hipGetLastError());
+    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr};
+    int rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
+                        c->wbc_stream, wp);
     if (rc) return rc;
-    return launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0,
-                      d_force ? d_force : c->d_cmd_tick, c->epilogue);
+    HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
+    rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true);
+    if (rc) return rc;
+    if (c->last_rescue_active) {
+        WbcPipe lp{nullptr, 0u, c->d_rescue + 2, c->d_rescue + c->last_rescue_parity};
+        rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr, nullptr, lp);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
+    return QRGPU_OK;
 }
 
 int qrgpu_set_torque_epilogue(qrgpu_ctx *c, int flags)

@@ -53,6 +53,16 @@ struct qrgpu_ctx {
     int started_total = 0;                    // what that counter reaches once every planned launch issued so far has started (wraps like the counter)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // pipelined tick (qrgpu_set_tick_pipeline, default on): the WBC launch of a tick runs on wbc_stream beside that tick's MPC launches
+    bool pipeline = true;
+    hipStream_t wbc_stream = nullptr;
+    hipEvent_t ev_wbc_fork = nullptr, ev_wbc_join = nullptr;
+    unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by the MPC solves
+    int *d_main_started = nullptr;            // main-pass workgroups started, ever (the WBC launch's gate); never cleared
+    int main_started_total = 0;
+    unsigned tick_epoch = 0;
+    bool last_rescue_active = false;          // did the last launch_mpc carry a trailing list launch (so that flags may say "on the rescue list")?
+    int last_rescue_parity = 0;
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
     bool lpt = true;
     bool rescue = true;

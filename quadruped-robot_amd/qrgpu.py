@@ -113,7 +113,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch", "qrgpu_host_alloc", "qrgpu_host_free",
-           "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms"]
+           "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms", "qrgpu_set_tick_pipeline"]
 
 
 def load_library():
@@ -371,6 +371,10 @@ class Context:
         """qdes [24][n]: desiredJPos / desiredJVel of the kinematic projection (K12); None skips that projection."""
         self._chk(self._lib.qrgpu_tick_batch(self._h, n, _dp(type_id), _dp(mpc_state), _dp(traj), _dp(gait), _dp(fb_state),
                                              _dp(wbc_cmd), _dp(prev_ori), _dp(force), _dp(tau), _dp(qdes), _dp(status)))
+
+    def set_tick_pipeline(self, on=True):
+        """WBC launch of a tick beside its MPC launches (default) or behind them."""
+        self._chk(self._lib.qrgpu_set_tick_pipeline(self._h, 1 if on else 0))
 
     def set_torque_epilogue(self, hip_comp=False, clip=False):
         """K14 tail on the batched torques: +-0.9 N m abad compensation (qr_fsm_state_locomotion.cpp:141-151), +-23 N m clip (qr_safety_checker.cpp:48-66)."""

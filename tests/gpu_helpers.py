@@ -129,6 +129,7 @@ def run_tick(ctx, pkg, b, type_id=None, want_qdes=False):
              gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), fb=ctx.alloc((37, n)).upload(S(b["fb_state"])),
              cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
              force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32), qdes=ctx.alloc((24, n)))
+    d["tau"].upload(np.full((12, n), np.nan, np.float32)); d["status"].upload(np.full((n,), 0x7f0000ff, np.int32))      # (poisoned: see run_mpc)
     tid = ctx.alloc((n,), np.int32).upload(type_id) if type_id is not None else None
     ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"], tid,
                    qdes=d["qdes"] if want_qdes else None)

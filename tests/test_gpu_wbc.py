@@ -247,3 +247,78 @@ def test_unknown_type_is_flagged(gpu_ctx, pkg):
         ref = G.run_tick(gpu_ctx, pkg, b)
     assert np.array_equal(out["tau"][~bad], ref["tau"][~bad])
     assert np.all(np.isfinite(out["tau"]))
+
+
+def test_pipelined_tick_is_the_serial_tick_bit_for_bit(gpu_ctx, pkg, oracle):
+    """qrgpu_tick_batch queues its WBC launch beside the MPC launches (a stream of the context's own, per-robot flags raised by the solves
+    behind write-through stores of force / tau / status; qrgpu_set_tick_pipeline).  Scheduling only: forces, torques, status words, K12
+    outputs and the orientation task's memory are those of the serial form bit for bit -- over a temporally coherent sequence (warm starts,
+    planned list and dispatch history evolve alike on both sides), with K12 and the K14 tail on, and with robots that the main pass hands to
+    its trailing list launch (the second, list-driven WBC pass).  The last tick is also held against the oracle."""
+    h, n = 10, 512
+    outs = {}
+    for piped in (False, True):
+        ctx = pkg.Context(0, 1024, 16)            # contexts of their own: the same (empty) history on both sides
+        try:
+            G.setup_a1(ctx, pkg, h)
+            ctx.set_tick_pipeline(piped)
+            ctx.set_torque_epilogue(hip_comp=True, clip=True)
+            seq = pkg.make_batch_sequence(n, h, "a1", seed=0x91BE, steps=5, frac_all_stance=0.3, excite=1.5)     # plenty of robots beyond the main pass's rows
+            S = pkg.to_soa
+            d_prev = ctx.alloc((3, n)).upload(S(seq[0]["prev_ori_vel"]))
+            res = []
+            for b in seq:
+                d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])),
+                         gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), fb=ctx.alloc((37, n)).upload(S(b["fb_state"])),
+                         cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), force=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)),
+                         tau=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)), qdes=ctx.alloc((24, n)),
+                         status=ctx.alloc((n,), np.int32).upload(np.full((n,), 0x7f0000ff, np.int32)))
+                ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d_prev, d["force"], d["tau"], d["status"], qdes=d["qdes"])
+                ctx.sync()
+                res.append(dict(force=d["force"].download().T.copy(), tau=d["tau"].download().T.copy(), status=d["status"].download(),
+                                qdes=d["qdes"].download().T.copy(), prev=d_prev.download().T.copy()))
+                for v in d.values():
+                    v.free()
+            outs[piped] = res
+        finally:
+            ctx.close()
+    rescued = 0
+    for k, (a, b_) in enumerate(zip(outs[False], outs[True])):
+        for key in ("force", "tau", "status", "qdes", "prev"):
+            assert np.array_equal(a[key], b_[key]), (k, key)
+        assert np.all(G.flags(b_["status"]) & 0x02000000 == 0)              # nobody timed out waiting for its forces
+    last, b = outs[True][-1], seq[-1]
+    prev_in = outs[True][-2]["prev"]
+    f, tau, st, sec, prev, qdes = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"], b["gait"],
+                                                    b["fb_state"], b["wbc_cmd"], prev_in.copy(), nthreads=8, epilogue=3, want_qdes=True)
+    ok = (G.flags(last["status"]) == 0) & (st == 0)
+    assert ok.mean() > 0.97
+    assert np.all(np.abs(last["tau"][ok] - tau[ok]) <= G.tau_tol(tau[ok], 1e-4)), np.abs(last["tau"][ok] - tau[ok]).max()
+    assert np.array_equal(last["prev"], prev)
+
+
+def test_pipelined_tick_with_many_robots_on_the_list_pass(gpu_ctx, pkg, oracle):
+    """Every robot all-stance at twice the ranges: hundreds outgrow the main pass and go through the trailing list launch, whose robots the
+    WBC launch running beside the main pass must leave alone (flag bit 0) for the second, list-driven WBC pass.  No robot may come back
+    unsolved (poisoned outputs), and every unflagged one is the oracle's."""
+    h, n = 10, 512
+    G.setup_a1(gpu_ctx, pkg, h)
+    b = pkg.make_batch(n, h, "a1", seed=0xBEE6, excite=2.0, frac_all_stance=1.0, frac_three_leg=0.0)
+    gpu_ctx.set_rescue_pass(False)
+    try:
+        flagged = (G.flags(G.run_mpc(gpu_ctx, pkg, b)["status"]) & 0x4) != 0
+    finally:
+        gpu_ctx.set_rescue_pass(True)
+    assert flagged.sum() > 64
+    gpu_ctx.set_planned_list(False)           # (so that the list pass, not the planned launch, keeps getting them)
+    try:
+        out = G.run_tick(gpu_ctx, pkg, b)
+        out = G.run_tick(gpu_ctx, pkg, b)
+    finally:
+        gpu_ctx.set_planned_list(True)
+    assert np.all(np.isfinite(out["tau"])) and np.all(G.flags(out["status"]) & 0x02000000 == 0)
+    f, tau, st, sec, prev = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"], b["gait"],
+                                              b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=8)
+    ok = (G.flags(out["status"]) == 0) & (st == 0)
+    assert ok.mean() > 0.9 and (ok & flagged).sum() > 64
+    assert np.all(np.abs(out["tau"][ok] - tau[ok]) <= G.tau_tol(tau[ok], 1e-4)), np.abs(out["tau"][ok] - tau[ok]).max()
