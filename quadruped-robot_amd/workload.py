@@ -214,10 +214,11 @@ def make_batch_sequence(n, horizon=10, robot="a1", seed=0xA1, steps=8, dt=0.03, 
             rate = np.where(over | under, -rate, rate)
         return x, rate
 
+    dv = 0.018 if dt == 0.03 else 0.6 * dt          # <= 0.6 m/s^2 (rad/s^2) over one step
     for _ in range(1, steps):
         v = dict(v)
-        v["v_w"] = v["v_w"] + rng.uniform(-0.018, 0.018, (n, 3)) * np.array([1.0, 1.0, e * 0.2])
-        v["w_w"] = v["w_w"] + e * rng.uniform(-0.018, 0.018, (n, 3))
+        v["v_w"] = v["v_w"] + rng.uniform(-dv, dv, (n, 3)) * np.array([1.0, 1.0, e * 0.2])
+        v["w_w"] = v["w_w"] + e * rng.uniform(-dv, dv, (n, 3))
         for c, lim in ((0, 0.5), (1, 0.5), (2, e * 0.1 + 1e-9)):
             v["v_w"][:, c], _ = reflect(v["v_w"][:, c], None, -lim, lim)
         v["w_w"], _ = reflect(v["w_w"], None, -e * 0.5 - 1e-9, e * 0.5 + 1e-9)

@@ -148,3 +148,20 @@ def test_live_quadprogpp_on_the_wbc_qp(ref, pkg):
         q = O.wbc_qp(md, b["fb_state"][i], cmd, b["prev_ori_vel"][i], dtype=np.float32)
         z, fval = O.ref_quadprog(q["G"], q["g0"], q["CE"], q["ce0"], q["CI"], q["ci0"])
         assert np.isfinite(fval) and np.abs(z - q["z"]).max() <= 1e-10 * max(1.0, np.abs(z).max())
+
+
+def test_config0_fixture_is_what_the_oracle_gives(pkg):
+    """tests/golden/config0_a1_h10_2000.npz (the 2 000-tick single-robot sequence of BASELINE.json configs[0]): regenerated inputs match the
+    stored checksums and the oracle, driven with the reference's cadence, reproduces the stored forces and leg commands."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_config0", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_config0.py"))
+    M = importlib.util.module_from_spec(spec); spec.loader.exec_module(M)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config0_a1_h10_2000.npz"))
+    seq = M.stream(pkg)
+    assert len(seq) == 2000
+    forces, tua, n_active, iters = M.drive_oracle(pkg, seq)
+    assert np.array_equal(forces, fx["mpc_forces"]) and np.array_equal(tua.astype(np.float32), fx["leg_cmd_tua"])
+    assert forces.shape == (180, 12) and n_active.max() >= 20
+    # temporally coherent: consecutive MPC solves 15 ticks (0.03 s) apart differ by a small fraction of the force scale
+    late = forces[50:]
+    assert np.median(np.abs(np.diff(late, axis=0)).max(1)) < 0.25 * np.abs(late).max()
