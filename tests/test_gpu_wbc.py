@@ -322,3 +322,48 @@ def test_pipelined_tick_with_many_robots_on_the_list_pass(gpu_ctx, pkg, oracle):
     ok = (G.flags(out["status"]) == 0) & (st == 0)
     assert ok.mean() > 0.9 and (ok & flagged).sum() > 64
     assert np.all(np.abs(out["tau"][ok] - tau[ok]) <= G.tau_tol(tau[ok], 1e-4)), np.abs(out["tau"][ok] - tau[ok]).max()
+
+
+def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
+    """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
+    K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
+    the friction pyramid, zero on swing feet, torques within the clip, bit-identical on a second cold run; a sample of 96 robots (the 32 with
+    the most working-set changes among them) against the oracle, A1 and Lite3 each with its own parameters."""
+    h, n = 16, 1024
+    gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    gpu_ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h); gpu_ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
+    try:
+        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 2); bl = pkg.make_batch(n // 2, h, "lite3", seed=0xA1 + 2 + 0xD2)
+        b = dict(ba)
+        for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+            b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+        b["n"] = n
+        tid = pkg.shard.interleave_types(n, 2)
+        gpu_ctx.set_torque_epilogue(hip_comp=True, clip=True)
+        with G.cold_start(gpu_ctx):
+            out = G.run_tick(gpu_ctx, pkg, b, type_id=tid, want_qdes=True)
+            out2 = G.run_tick(gpu_ctx, pkg, b, type_id=tid, want_qdes=True)
+        assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
+        for k in ("force", "tau", "status", "qdes"):
+            assert np.array_equal(out[k], out2[k]), k
+        f = out["force"].reshape(n, 4, 3)
+        mu = np.float32(0.45)
+        fmaxv = np.where(tid == 0, np.float32(13.0 * 9.81), np.float32(8.742 * 9.81))[:, None]
+        assert np.all(f[:, :, 2] >= -1e-5) and np.all(f[:, :, 2] <= fmaxv * (1 + 1e-6))
+        assert np.all(np.abs(f[:, :, 0]) <= mu * f[:, :, 2] + 2e-5) and np.all(np.abs(f[:, :, 1]) <= mu * f[:, :, 2] + 2e-5)
+        assert np.all(f[b["gait"][:, :4] == 0] == 0)
+        assert np.abs(out["tau"]).max() <= 23.0 and np.all(np.isfinite(out["qdes"]))
+        it = G.iterations(out["status"])
+        sample = sorted(set(np.argsort(-it)[:32].tolist() + list(range(0, n, 16))))
+        for i in sample:
+            robot = "a1" if tid[i] == 0 else "lite3"
+            md = pkg.model_desc(robot)
+            ft, tt, st, _, _ = oracle.tick_batch(1, pkg.mpc_cfg(robot), h, md[:3], md, b["mpc_state"][i:i + 1], b["traj"][i:i + 1], b["gait"][i:i + 1], b["fb_state"][i:i + 1],
+                                                 b["wbc_cmd"][i:i + 1], b["prev_ori_vel"][i:i + 1].copy(), epilogue=3)
+            assert st[0] == 0, i
+            assert np.abs(out["force"][i] - ft[0]).max() <= 1e-5 * max(1.0, np.abs(ft[0]).max()), (i, it[i])
+            assert np.all(np.abs(out["tau"][i] - tt[0]) <= G.tau_tol(tt[0], 1e-4)), (i, it[i])
+        assert it.max() >= 60                       # (the shard holds the hard robots DESIGN.md 8 talks about)
+    finally:
+        gpu_ctx.set_torque_epilogue(False, False)
+        G.setup_a1(gpu_ctx, pkg, 10)
