@@ -478,7 +478,9 @@ def main():
     ctx.set_hessian_mode(args.hessian)
 
     # ---- populations: D draws x a coherent sequence each, all resident in HBM before anything is timed -----------------------
-    D = max(1, min(args.draws, args.steps))
+    # (at least five timed steps per draw: a draw's barrier-to-barrier region starts with an idle GPU, and two or three steps -- the driver's
+    #  --steps 20 over eight draws -- measure that start-up as much as the tick: four draws then)
+    D = max(1, min(args.draws, max(1, args.steps // 5)))
     SEQ = max(1, args.seq)
     S = pkg.to_soa
     dv = Dev(pkg, ctx)

@@ -725,13 +725,15 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             asm volatile("" :: "v"(acc1), "v"(acc2));
             const long long k4_t2 = clock64();
 #endif
-            // D[row = 4 g + reg][col = lc] -> the tile's buffer(s), row-major (4-byte stores: lanes lc are contiguous)
+            // D[row = 4 g + reg][col = lc] -> the tile's buffer(s), 4-byte stores, lanes lc contiguous.  Row r sits at physical row
+            // hs_row(r, Cc) = (4 (r & 3) + (r >> 2)) ^ (Cc & 1): the lane groups g = 0, 1 of a store land in different halves of the 32
+            // banks (rows 4 apart would share them), and the block owners' reads, which run across column tiles, alternate halves with the tile
             float *buf = Hs + 256 * (diag ? 2 * NOD + R : 2 * (((R * (R - 1)) >> 1) + Cc));
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) buf[(4 * g + reg) * 16 + lc] = acc1[reg];
+            for (int reg = 0; reg < 4; ++reg) buf[((4 * reg + g) ^ (Cc & 1)) * 16 + lc] = acc1[reg];
             if (!diag) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) buf[256 + (4 * g + reg) * 16 + lc] = acc2[reg];
+                for (int reg = 0; reg < 4; ++reg) buf[256 + ((4 * reg + g) ^ (Cc & 1)) * 16 + lc] = acc2[reg];
             }
             if (Hd) {
                 const int ec = 16 * Cc + lc;
@@ -804,12 +806,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     for (int sl = 0; sl < MAXB; ++sl) {
         if (ba[sl] >= 0) {
             const int a = ba[sl], b = bb[sl];
-            int rowp[3], rr[3], Rx[3], colp[3], cc[3];
+            int rowb[3], rr[3], rp[3], Rx[3], colb[3], cc[3], cp[3], Cy[3];          // (rp, cp: physical rows before the column tile's parity flip)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int x = 3 * a + i, y = 3 * b + i;
-                Rx[i] = x >> 4; rr[i] = x & 15; rowp[i] = 256 * Rx[i] * (Rx[i] - 1) + 16 * rr[i];
-                cc[i] = y & 15; colp[i] = 512 * (y >> 4) + cc[i];
+                Rx[i] = x >> 4; rr[i] = x & 15; rp[i] = 4 * (rr[i] & 3) + (rr[i] >> 2); rowb[i] = 256 * Rx[i] * (Rx[i] - 1);
+                Cy[i] = y >> 4; cc[i] = y & 15; cp[i] = 4 * (cc[i] & 3) + (cc[i] >> 2); colb[i] = 512 * Cy[i] + cc[i];
             }
             const int dbase = 512 * NOD;
 #pragma unroll
@@ -817,10 +819,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (a == b && j > i) continue;                              // (mirrored below)
-                    const bool od = Rx[i] != ((3 * b + j) >> 4);
-                    const int dg = dbase + 256 * Rx[i];
-                    const int a1 = od ? rowp[i] + colp[j] : dg + 16 * rr[i] + cc[j];
-                    const int a2 = od ? a1 + 256 : dg + 16 * cc[j] + rr[i];
+                    const bool od = Rx[i] != Cy[j];
+                    const int dg = dbase + 256 * Rx[i], par = Cy[j] & 1;
+                    const int a1 = od ? rowb[i] + colb[j] + 16 * (rp[i] ^ par) : dg + 16 * (rp[i] ^ par) + cc[j];
+                    const int a2 = od ? a1 + 256 : dg + 16 * (cp[j] ^ par) + rr[i];
                     float v1 = Hs[a1], v2 = Hs[a2];
                     if (a == b && i == j) {
 #pragma clang fp contract(off)
