@@ -615,6 +615,51 @@ def main():
     rates = [world * n * share[d] / draw_s[d] for d in range(D)]
     value = float(np.median(rates))
 
+    # diagnostic (QRGPU_BENCH_TIMELINE=1, stderr): where a pipelined tick's time goes, from the kernels' own stamps on the shared 100 MHz clock
+    if os.environ.get("QRGPU_BENCH_TIMELINE") and args.mode == "tick" and world == 1:
+        import ctypes as C_
+        lib_ = ctx._lib
+        lib_.qrgpu_debug_timeline.argtypes = [C_.c_void_p, C_.c_void_p]
+        reset(0)
+        for _ in range(12): step()
+        fence()
+        if lib_.qrgpu_debug_timeline(ctx._h, None) != 0:
+            raise SystemExit("QRGPU_BENCH_TIMELINE needs a library built with QRGPU_EXTRA_FLAGS=-DQR_TIMELINE")
+        for _ in range(48): step()
+        fence()
+        tl = np.zeros((65, 8), np.int64)
+        lib_.qrgpu_debug_timeline(ctx._h, tl.ctypes.data)
+        ep = int(tl[64, 0])
+        rows = []
+        for e in range(ep - 40, ep - 1):
+            a, b_ = tl[e & 63], tl[(e + 1) & 63]
+            t0 = a[0]
+            rows.append([(a[1] - t0) / 100, (a[2] - t0) / 100, (a[3] - t0) / 100, (a[4] - t0) / 100, (a[5] - t0) / 100, (a[6] - t0) / 100,
+                         (a[7] - t0) / 100 if a[7] else float("nan"), (b_[0] - t0) / 100])
+        rows = np.array(rows)
+        names = ["last main start", "last solve published", "first WBC workgroup", "last WBC workgroup done", "trailing launch starts", "trailing launch ends",
+                 "second WBC pass ends", "NEXT tick's first main workgroup"]
+        print("timeline of a pipelined tick (us after its first main-pass workgroup; median / mean over %d ticks):" % len(rows), file=sys.stderr)
+        for k, nm in enumerate(names):
+            print("   %-34s %7.1f %7.1f" % (nm, np.nanmedian(rows[:, k]), np.nanmean(rows[:, k])), file=sys.stderr)
+        tr = np.zeros((4, n), np.int32)
+        lib_.qrgpu_debug_timeline_robots.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_int]
+        if lib_.qrgpu_debug_timeline_robots(ctx._h, tr.ctypes.data, n) == 0:
+            t0_ = int(tl[(ep) & 63][0]) & 0xffffffff
+            rel = ((tr.astype(np.int64) - t0_ + (1 << 31)) % (1 << 32) - (1 << 31)) / 100.0        # us after the last tick's first main workgroup
+            ws, wf, we, ms = rel
+            late = ws > ms
+            print("   last tick, per robot: WBC workgroup started after its solve was published: %d of %d; of those, start - published: median %.1f max %.1f us" % (
+                int(late.sum()), n, np.median((ws - ms)[late]) if late.any() else 0, (ws - ms).max()), file=sys.stderr)
+            print("      flag seen - max(published, WBC start + 0): median %.1f  p99 %.1f us;  done - flag seen (QP + store): median %.1f p90 %.1f max %.1f us;  WBC start -> flag wait begins is not stamped" % (
+                np.median(wf - np.maximum(ms, ws)), np.percentile(wf - np.maximum(ms, ws), 99), np.median(we - wf), np.percentile(we - wf, 90), (we - wf).max()), file=sys.stderr)
+            print("      done - published: median %.1f p90 %.1f max %.1f us;  the last 5 robots done: (published, WBC start, flag seen, done) %s" % (
+                np.median(we - ms), np.percentile(we - ms, 90), (we - ms).max(), [(round(ms[k], 1), round(ws[k], 1), round(wf[k], 1), round(we[k], 1)) for k in np.argsort(-we)[:5]]), file=sys.stderr)
+            hist = np.histogram(ws, bins=np.arange(130, 240, 10))[0]
+            print("      WBC workgroup starts per 10 us from 130 us: %s;  solves published per 10 us from 130: %s" % (hist.tolist(), np.histogram(ms, bins=np.arange(130, 240, 10))[0].tolist()), file=sys.stderr)
+        print("   gap last WBC done -> next main start: median %.1f us;  last solve -> last WBC done: median %.1f us" % (
+            np.median(rows[:, 7] - np.maximum(rows[:, 3], rows[:, 5])), np.median(rows[:, 3] - rows[:, 1])), file=sys.stderr)
+
     # executed arithmetic of the MPC kernel (qrgpu_enable_flop_count): four more, untimed, steps on draw 0 with the counters on
     flop = None
     if args.mode != "wbc":

@@ -49,7 +49,8 @@ struct MpcLaunch {
     // Longest-first dispatch (DESIGN.md "tail"): slot j of an XCD's chunk solves robot order[j]; the kernel records what
     // the robot cost this time (clock64 ticks >> 12, saturated) for qr_lpt_order_kernel.  Either may be null.
     const int *order;
-    int *cost;
+    int *cost;                  // bits 0-7: cost in units of 4096 cycles, saturated; bit 8: `big`; bits 16-31: the same in units of 256 cycles
+    int cost_ema;               // the cost written is the mean of this solve's and the word's previous value (there is a history for this batch)
     // Rescue pass (DESIGN.md "working-set capacity"): a four-wave solve whose working set outgrows its 64 lanes / its LDS appends the
     // robot to rescue_list (rescue_count[parity] entries); the single-wave variant then re-solves exactly those robots with the
     // whole CU's LDS (rescue_mode = 1: workgroup b takes list entry b).  The main launch zeroes the other parity's counter.
@@ -89,6 +90,15 @@ struct MpcLaunch {
     // forces as soon as that robot's solve has stored them.  done_flag[robot] = (tick epoch << 1) | on-the-rescue-list, written by the solve
     // with an agent-scope store behind its write-through (sc1) output stores; main_started: bumped by every workgroup of the main pass as it
     // starts (the WBC launch is gated on the whole main pass being resident, so that it can never take a CU from a solve it waits for).
+    // Persistent main pass: the launch has one workgroup per resident slot and each takes robots off eight per-XCD queues (heads in qhead[8],
+    // this launch's; qhead_next[8] are zeroed for the next one) until all are empty, its own XCD's first.  Hardware dispatch hands workgroup b
+    // to XCD b % 8 in launch order and waits for a slot THERE: a free slot elsewhere stays empty meanwhile (6 us per second-round robot on
+    // average, 40 us at worst: scratch/diag_slots.py), and a new workgroup takes 3 us to come up.
+    int persist;
+    int *qhead, *qhead_next;
+    long long *tl;              // diagnostic (qrgpu_debug_timeline), or null
+    int *ftime;                 // pipelined tick: when each robot's solve raised its flag (low word of the 100 MHz clock) -> the WBC launch's order next tick
+    int *wbc_order_out;         // (trailing list launch / qr_lpt_order_kernel) that order, written for the next tick
     unsigned *done_flag;
     unsigned done_epoch;
     int *main_started;
@@ -167,6 +177,11 @@ struct WbcPipe {
     unsigned epoch;
     const int *list;
     const int *list_count;
+    int *finished;              // counted up once by either wave of a robot's workgroup when its outputs are in memory (written through): the tick's
+                                //   join is a one-thread launch on the context's stream that waits for 2 n more of these (cumulative, never cleared), or null
+    int *tlr;                   // diagnostic: [4][n] per robot, low word of the clock: WBC workgroup started, flag seen, done (last tick only), or null
+    long long *tl;              // diagnostic (qrgpu_debug_timeline): [64 epochs][8] first / last moments of a tick's launches on the 100 MHz clock, or null
+    const int *order;           // slot -> robot inside each XCD chunk: the robots in the order their solves ended in the last tick (MpcLaunch::ftime), or null
 };
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)

@@ -37,6 +37,17 @@
 
 namespace qrgpu {
 
+// Diagnostic hooks of the pipelined tick's timeline (qrgpu_debug_timeline, bench.py QRGPU_BENCH_TIMELINE=1; the finish-order experiment of the WBC
+// launch, QRGPU_WBC_ORDER=1, needs them too): compiled in only with -DQR_TIMELINE (QRGPU_EXTRA_FLAGS).  With the pointers merely null at run
+// time the main pass was 1.5-2 % slower (1.373 against 1.346 ms at 8192 robots, A/B on one box).
+#ifdef QR_TIMELINE
+#define QR_P_TL P.tl
+#define QR_P_FTIME P.ftime
+#else
+#define QR_P_TL ((long long *)nullptr)
+#define QR_P_FTIME ((int *)nullptr)
+#endif
+
 #define QR_AS_THREADS 256        // the four waves of phases 4-6 (control wave + three workers)
 // Pivot reciprocals of both sweeps: v_rcp_f64 + one Newton step (2.2e-15 relative, scratch/ubench/rcp.hip) -- 0.7 % of the main pass.  (Before
 // the periodic refresh of S^-1 existed, one robot of the stress set at twice the 8d ranges wandered into the iteration cap with it; with the
@@ -199,7 +210,7 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
         // broadcast), no atomics -- the counting sort below spends ~0.5 ms at 512 robots per chunk on atomics to a few hot bins -- and the
         // order is stable, i.e. the same for the same costs.
         const int m = hi - lo;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) hist[i] = cost[lo + i] & 255;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) hist[i] = (cost[lo + i] >> 16) & 0xffff;       // (the fine cost: units of 256 cycles)
         __syncthreads();
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const int ci = hist[i];
@@ -220,11 +231,32 @@ __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restr
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) order[lo + atomicAdd(&hist[255 - (cost[i] & 255)], 1)] = i;
 }
+// The WBC launch of a pipelined tick takes its robots, inside each XCD chunk, in the order their solves ended in the LAST tick (ftime: low
+// word of the shared 100 MHz clock at the moment the flag went up; compared as wrapping differences): a WBC workgroup that lands on a CU
+// while its robot is still being solved holds a slot for nothing, and there are far fewer slots than robots while the solves run.
+// Rank by comparison as above: a permutation of the chunk by construction.  Chunks beyond 2048 robots keep slot order.
+__device__ __forceinline__ void finish_order_chunk(int x, int n, const int *__restrict__ ftime, int *__restrict__ order, int *hist /* >= 2048 ints of LDS */)
+{
+    const int chunk = (n + 7) >> 3;
+    const int lo = x * chunk;
+    const int hi = (lo + chunk < n) ? lo + chunk : n;
+    const int m = hi - lo;
+    if (m > 2048) { for (int i = threadIdx.x; i < m; i += blockDim.x) order[lo + i] = lo + i; return; }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) hist[i] = ftime[lo + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const int ti = hist[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) { const int dlt = hist[j] - ti; rank += (dlt < 0 || (dlt == 0 && j < i)) ? 1 : 0; }
+        order[lo + rank] = lo + i;
+    }
+}
 #ifndef QR_FLOPS_BUILD
-__global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order)
+__global__ void __launch_bounds__(256) qr_lpt_order_kernel(int n, const int *__restrict__ cost, int *__restrict__ order, const int *__restrict__ ftime, int *__restrict__ wbc_order)
 {
     __shared__ int hist[2048];
     lpt_order_chunk(blockIdx.x, n, cost, order, hist);
+    if (ftime && wbc_order) { __syncthreads(); finish_order_chunk(blockIdx.x, n, ftime, wbc_order, hist); }
 }
 #endif
 
@@ -242,13 +274,27 @@ struct MpcIO {
 // One robot's MPC tick by one workgroup of NTHR threads.  MAXB: 3x3 blocks a thread keeps in registers during the sweep (MAXB * NTHR >= number of
 // stance leg-step pairs).  BIG: working-set positions 64 .. 95 live in a second set of per-lane registers.  Every wave returns from here
 // (the workers at their exit command, wave 0 after the outputs), so a workgroup may solve several robots in a row (list mode below).
-template <int MAXB, bool BIG, int NTHR>
+template <int MAXB, bool BIG, int NTHR, bool PERSIST = false>
 __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO &io, const int rid, double *smem)
 {
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    // (the persistent kernel calls this in a loop: without the opaque copy everything that depends on the thread index alone is hoisted out of
+    //  that loop and held in registers across the whole solve -- 98 spilled VGPRs in the 128-register main pass instead of 6)
+    if (PERSIST) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int n = P.n;
     const long long t_begin = P.cost ? clock64() : 0;
+    // Every workgroup barrier of the solve is counted (uniform, an SGPR): a workgroup of the persistent main pass keeps its waves beyond the
+    // active set's four alive -- they must come back for the next robot -- and a live wave counts at every s_barrier of its workgroup, so
+    // those waves cross barriers in step with the working ones until the count wave 0 leaves in sMisc[15] at the solve's last one (QR_IDLE).
+    int nbar = 0;
+#ifdef QR_NO_BARRIER_COUNT      // (A/B: what the count costs the kernels that never park a wave)
+#define QR_SYNC() do { __syncthreads(); } while (0)
+#else
+#define QR_SYNC() do { __syncthreads(); if (PERSIST) ++nbar; } while (0)
+#endif
+#define QR_IDLE() do { for (;;) { QR_SYNC(); if (((volatile int *)sMisc)[15] == nbar) break; } } while (0)
     // a type id outside the table, or one that was never set up, would read garbage (mass 0 => 1/mass = inf): the robot is solved with the
     // first valid type's constants and carries QRGPU_ST_BAD_TYPE
     int tyid = io.type_id ? io.type_id[rid] : 0;
@@ -291,10 +337,11 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
 #endif
     // ---------------- phase 0: inputs ----------------
+    if (tid == 0) sMisc[15] = -1;
     if (tid < 28) sSt[tid] = io.g_state[(size_t)tid * n + rid];
     for (int i = tid; i < NV; i += NTHR) sTraj[i] = io.g_traj[(size_t)i * n + rid];
     for (int i = tid; i < NL; i += NTHR) sGait[i] = io.g_gait[(size_t)i * n + rid];
-    __syncthreads();
+    QR_SYNC();
 
     // ---------------- phase 1: SRBD terms ----------------
     // R = quat.toRotationMatrix() from the quaternion: phases 1-2 keep it in registers; the output phase, a whole active set later, forms it
@@ -422,7 +469,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         for (int j = 0; j < 12; ++j) sV[13 * r + j] = ax[j] - sTraj[12 * r + j];
         sV[13 * r + 12] = ax[12] - 0.f;
     }
-    __syncthreads();
+    QR_SYNC();
     QR_TS(1);
     // LDS loads count as divergent for the compiler; make the sizes scalar so that loops and branches on them are SALU
     const int nls = __builtin_amdgcn_readfirstlane(sMisc[0]);
@@ -472,8 +519,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (tid == 0) {
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
         }
         return;
     }
@@ -572,8 +620,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (tid == 0) {
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0);
+            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
         }
         return;
     }
@@ -797,7 +846,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     //   A_ij <- A_ij - C_i P^-1 C_j',   A_ik <- C_i P^-1,   A_kk <- -P^-1.
     // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
     Blk A[MAXB];
-    __syncthreads();               // every unit's tile is in LDS
+    QR_SYNC();               // every unit's tile is in LDS
     K4_TS(12);
     // block (a, b), a >= b, of (H + H') / 2: entry (i, j) from H[x][y] and H[y][x], x = 3 a + i >= y = 3 b + j (the block's lower half when
     // a = b), both fp32, averaged exactly in fp64.  Off-diagonal tile (R, C): buffers at 512 (tri(R - 1) + C), H[x][y] at [x & 15][y & 15] of
@@ -835,10 +884,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
     }
     K4_TS(14);
-    __syncthreads();               // every block is in registers: the M region can now carry the pivot panels
+    QR_SYNC();               // every block is in registers: the M region can now carry the pivot panels
     // A wave beyond the active set's four that owns no block (a trotting robot's 300 blocks fill 4.7 of the 8 waves) is done: it would only
     // load panels and wait at barriers (a wave that has ended no longer counts there), competing for the LDS pipe with the ones that work.
-    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS && (tid & ~63) >= npairs) return;
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS && (tid & ~63) >= npairs) { if (PERSIST) QR_IDLE(); return; }
     {
         double *panel0 = Mb, *panel1 = Mb + NL * 9;
 #ifdef QR_SWEEP_STAMPS
@@ -878,7 +927,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             double *pan = (k & 1) ? panel1 : panel0, *pnext = (k & 1) ? panel0 : panel1;
             VS_STAMP(3);
             VS_STAMP(0);
-            __syncthreads();
+            QR_SYNC();
             VS_STAMP(1);
             // the first block's operands do not depend on P^-1: their LDS round trip hides behind its computation
             double Cx0[9], Cb0[9];
@@ -948,7 +997,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         VS_STAMP(3);
         if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 8] = vs_t[0]; QR_DBGT[(size_t)rid * 16 + 9] = vs_t[1]; QR_DBGT[(size_t)rid * 16 + 10] = vs_t[2]; QR_DBGT[(size_t)rid * 16 + 11] = vs_t[3]; QR_DBGT[(size_t)rid * 16 + 12] = 0; }
 #endif
-        __syncthreads();           // everybody is done with the panels before M overwrites them
+        QR_SYNC();           // everybody is done with the panels before M overwrites them
 #pragma unroll
         for (int sl = 0; sl < MAXB; ++sl) {
             if (ba[sl] >= 0) {
@@ -957,11 +1006,11 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 for (int i = 0; i < 9; ++i) dst[i] = -A[sl].m[i];         // M = +H^-1
             }
         }
-        __syncthreads();
+        QR_SYNC();
     }
     // phases 0-3 may run on more than four waves (NTHR / 64: one block of a trotting robot's Hessian per thread); the active set is a
     // four-wave protocol, so the others are done here (a wave that has ended no longer counts at the workgroup's barriers)
-    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) return;
+    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) { if (PERSIST) QR_IDLE(); return; }
     if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
     if (QR_PFLOPS) {
@@ -1017,7 +1066,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2;
             }
             if (wv == 0) for (int e = lane; e < 6 * nls; e += 64) sPos[e] = (short)-1;
-            __syncthreads();
+            QR_SYNC();
             if (own) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { x0 -= xz[v * NV + 3 * kme]; x1 -= xz[v * NV + 3 * kme + 1]; x2 -= xz[v * NV + 3 * kme + 2]; }
@@ -1025,7 +1074,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 // warm start solves the equality-constrained problem on a whole working set from it
                 if (wv == 0) { gl[3 * kme] = x0; gl[3 * kme + 1] = x1; gl[3 * kme + 2] = x2; }
             }
-            __syncthreads();
+            QR_SYNC();
         }
         QR_TS(4);
 #ifdef QR_CTRL_NOFASTZ
@@ -1100,7 +1149,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                 }
             }
-            __syncthreads();
+            QR_SYNC();
 #if defined(QR_DIAG_REFAC)
             const long long tb1 = clock64();
 #endif
@@ -1124,7 +1173,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                         if (c1 || i == p + 1) nxt[c1 ? i : j] = v;
                     }
                 }
-                __syncthreads();
+                QR_SYNC();
             }
 #if defined(QR_DIAG_REFAC)
             const long long tb2 = clock64();
@@ -1149,7 +1198,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                 }
             }
-            __syncthreads();
+            QR_SYNC();
             return ok;
         };
         enum { CMD_GO = 0, CMD_EXIT = 1, CMD_REBUILD = 2 };
@@ -1157,7 +1206,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // ================================ workers ================================
             const int g = wv - 1;                         // 0..2
             for (;;) {
-                __syncthreads();                          // X1
+                QR_SYNC();                          // X1
                 const int cmd = __builtin_amdgcn_readfirstlane(sCtl[0]);
                 if (cmd == CMD_EXIT) return;
                 const int q = __builtin_amdgcn_readfirstlane(sCtl[1]);
@@ -1170,7 +1219,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const double dq = (lane < q) ? dd[lane] : 0.0;
                 const double dq2 = (hi && lane + 64 < q) ? dd[lane + 64] : 0.0;
                 r_partial(q, dq, dq2);
-                __syncthreads();                          // B2
+                QR_SYNC();                          // B2
                 double rq, rq2 = 0.0;
                 { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                 if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
@@ -1211,7 +1260,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                 }
                 if (own) { xz[wv * NV + 3 * kme] = p0; xz[wv * NV + 3 * kme + 1] = p1; xz[wv * NV + 3 * kme + 2] = p2; }
-                __syncthreads();                          // B3
+                QR_SYNC();                          // B3
                 const int flags = __builtin_amdgcn_readfirstlane(sCtl[2]);
                 if (flags & F_FULL) {
                     // bordered update of S^-1, columns j = g (mod 3); published by the next X1
@@ -1253,18 +1302,18 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     if (lane < q) sl = Sinv[pidx(lane, l)];
                     if (hi && lane + 64 < q) sl2 = Sinv[pidx(lane + 64, l)];
                     const double isl = fast_rcp(rd2(sl, sl2, l));
-                    __syncthreads();                      // D1: everyone has column l before anyone changes S^-1
+                    QR_SYNC();                      // D1: everyone has column l before anyone changes S^-1
                     for (int j = g; j < q; j += 3) {
                         if (j == l) continue;
                         const double sj = rd2(sl, sl2, j) * isl;
                         if (lane < q && lane != l && j <= lane) Sinv[tril + j] -= sl * sj;
                         if (hi && lane + 64 < q && lane + 64 != l && j <= lane + 64) Sinv[tril2 + j] -= sl2 * sj;
                     }
-                    __syncthreads();                      // D2
+                    QR_SYNC();                      // D2
                     double m0 = 0.0, m1 = 0.0;
                     if (l != last && g == 0 && lane < last) m0 = (lane == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane)];
                     if (hi && l != last && g == 0 && lane + 64 < last) m1 = (lane + 64 == l) ? Sinv[tri(last) + last] : Sinv[pidx(last, lane + 64)];
-                    __syncthreads();                      // D3
+                    QR_SYNC();                      // D3
                     if (l != last && g == 0 && lane < last) Sinv[pidx(l, lane)] = m0;
                     if (hi && l != last && g == 0 && lane + 64 < last) Sinv[pidx(l, lane + 64)] = m1;
                 }
@@ -1354,7 +1403,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (lane < q) sAct[lane] = 6 * ck + ct;
                 if (BIG && lane + 64 < q) sAct[lane + 64] = 6 * ck2 + ct2;
                 if (lane == 0) { sCtl[0] = CMD_REBUILD; sCtl[1] = q; }
-                __syncthreads();                          // X1
+                QR_SYNC();                          // X1
 #if defined(QR_DIAG_REFAC)
                 const long long tr0 = clock64();
 #endif
@@ -1386,9 +1435,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     if (hi) { dq2 = (lane + 64 < q) ? slack_at_x0(ck2, ct2) : 0.0; if (lane + 64 < q) dd[lane + 64] = dq2; }
                     if (lane < q) dd[lane] = dq;
                     if (lane == 0) { sCtl[0] = CMD_GO; sCtl[1] = q; }
-                    __syncthreads();                      // X1
+                    QR_SYNC();                      // X1
                     r_partial(q, dq, dq2);
-                    __syncthreads();                      // B2
+                    QR_SYNC();                      // B2
                     double rq, rq2 = 0.0;
                     { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
                     if (hi) { const double rs = (xr2[lane] + xr2[64 + lane]) + (xr2[128 + lane] + xr2[192 + lane]); rq2 = (lane + 64 < q) ? rs : 0.0; }
@@ -1407,7 +1456,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     int lpos = -1;
                     if (drop && !block_drop) { lpos = first_lane(lane < q && rq == worst); if (hi && lpos < 0) lpos = 64 + first_lane(lane + 64 < q && rq2 == worst); }
                     if (lane == 0) { sCtl[2] = (drop && !block_drop) ? F_DROP : 0; sCtl[3] = lpos; }
-                    __syncthreads();                      // B3
+                    QR_SYNC();                      // B3
                     if (block_drop) {
                         // (the workers saw a round without a drop and wait at X1 for the next command)
                         const unsigned long long k1 = __ballot(lane < q && !neg1), k2 = hi ? __ballot(lane + 64 < q && !neg2) : 0ull;
@@ -1455,16 +1504,16 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                         else { clk = __builtin_amdgcn_readlane(ck, l); clt = __builtin_amdgcn_readlane(ct, l); }
                         if (BIG && last >= 64) { cmk = __builtin_amdgcn_readlane(ck2, last - 64); cmt = __builtin_amdgcn_readlane(ct2, last - 64); }
                         else { cmk = __builtin_amdgcn_readlane(ck, last); cmt = __builtin_amdgcn_readlane(ct, last); }
-                        __syncthreads();                  // D1
+                        QR_SYNC();                  // D1
                         if (fastz && l != last && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
-                        __syncthreads();                  // D2
+                        QR_SYNC();                  // D2
                         if (l != last) {
                             if (lane == l) { ck = cmk; ct = cmt; }
                             if (BIG && lane + 64 == l) { ck2 = cmk; ct2 = cmt; }
                         }
                         if (lane == clk) { amask &= ~(1u << clt); sPos[6 * clk + clt] = (short)-1; }
                         if (l != last && lane == cmk) { posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt)); sPos[6 * cmk + cmt] = (short)l; }
-                        __syncthreads();                  // D3
+                        QR_SYNC();                  // D3
                         --q;
                     }
                     if (q == 0) { x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2]; uq = 0.0; uq2 = 0.0; break; }
@@ -1550,10 +1599,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (lane < q) dd[lane] = dq;
                 if (lane == 0) { sCtl[0] = 0; sCtl[1] = q; }
                 CS_STAMP(1);
-                __syncthreads();                          // X1
+                QR_SYNC();                          // X1
                 CS_STAMP(2);
                 r_partial(q, dq, dq2);
-                __syncthreads();                          // B2
+                QR_SYNC();                          // B2
                 CS_STAMP(3);
                 double rq, rq2 = 0.0;
                 { const double rs = (xr[lane] + xr[64 + lane]) + (xr[128 + lane] + xr[192 + lane]); rq = (lane < q) ? rs : 0.0; }
@@ -1588,7 +1637,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #endif
                 if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
                 CS_STAMP(4);
-                __syncthreads();                          // B3
+                QR_SYNC();                          // B3
                 CS_STAMP(5);
                 if (degenerate) { if (lane == kp) xmask |= 1u << tp; break; }
                 if (over) { st |= QRGPU_ST_MPC_OVERFLOW_D; done = true; break; }      // (main pass: the robot goes on the rescue list below)
@@ -1624,23 +1673,23 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     else { clk = __builtin_amdgcn_readlane(ck, l); clt = __builtin_amdgcn_readlane(ct, l); }
                     if (BIG && last >= 64) { cmk = __builtin_amdgcn_readlane(ck2, last - 64); cmt = __builtin_amdgcn_readlane(ct2, last - 64); ulast = readlane_d(uq2, last - 64); }
                     else { cmk = __builtin_amdgcn_readlane(ck, last); cmt = __builtin_amdgcn_readlane(ct, last); ulast = readlane_d(uq, last); }
-                    __syncthreads();                      // D1
+                    QR_SYNC();                      // D1
                     if (fastz && l != last && own) { const double *wl_ = Wc + last * nsp + 3 * kme; double *wd_ = Wc + l * nsp + 3 * kme; wd_[0] = wl_[0]; wd_[1] = wl_[1]; wd_[2] = wl_[2]; }
-                    __syncthreads();                      // D2
+                    QR_SYNC();                      // D2
                     if (l != last) {
                         if (lane == l) { uq = ulast; ck = cmk; ct = cmt; }
                         if (BIG && lane + 64 == l) { uq2 = ulast; ck2 = cmk; ct2 = cmt; }
                     }
                     if (lane == clk) { amask &= ~(1u << clt); sPos[6 * clk + clt] = (short)-1; }
                     if (l != last && lane == cmk) { posk = (posk & ~(0xffull << (8 * cmt))) | ((unsigned long long)l << (8 * cmt)); sPos[6 * cmk + cmt] = (short)l; }
-                    __syncthreads();                      // D3
+                    QR_SYNC();                      // D3
                     xmask = 0;
                     --q;
                 }
             }
         }
-        if (lane == 0) sCtl[0] = CMD_EXIT;                // workers leave at their next X1
-        __syncthreads();
+        if (lane == 0) { sCtl[0] = CMD_EXIT; sMisc[15] = nbar + 1; }      // workers leave at their next X1 (and the parked waves of a persistent workgroup with them)
+        QR_SYNC();
         QR_TS(5);
         const bool to_rescue = (st & QRGPU_ST_MPC_OVERFLOW_D) && P.rescue_list && !P.rescue_mode;
         if (warm && !to_rescue) {                         // (a robot on its way to the list pass keeps last tick's guess for that pass)
@@ -1689,10 +1738,19 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // list pass, tell that workgroup to leave it to the WBC pass behind the list launch)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | (to_rescue ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
+            if (lane == 0 && QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 2, wall_clock64());
         }
         if (lane == 0 && QR_PFLOPS) { double *fo = QR_PFLOPS + (size_t)rid * 4; fo[0] = fl_v32; fo[1] = fl_m32; fo[2] = fl_sw; fo[3] = fl_as; }
         if (lane == 0 && P.cost) {
-            const long long c = (clock64() - t_begin) >> 12;
+            // what this robot cost, in units of 256 cycles -- smoothed over ticks when there is a history: half of a robot's tick-to-tick variation is
+            // the change count of its active set, which does not persist (correlation 0.47 between consecutive ticks), and a longest-first
+            // order from last tick's cost alone ends 10 us later than one from the running mean (scratch/analyze_predict.py)
+            long long c = (clock64() - t_begin) >> 8;
+            if (c > 0xffff) c = 0xffff;
+            if (P.cost_ema) c = (c + ((P.cost[rid] >> 16) & 0xffff) + 1) >> 1;
+            const int cfine = (int)c;
+            c >>= 4;
             int big = 0;
             if (P.pre_list) {
                 // does this robot belong in the planned list next time?  It overflowed, or ended within six rows of what the main pass's LDS
@@ -1703,7 +1761,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (qcm > 64) qcm = 64;
                 big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
             }
-            P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8);
+            P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16);
         }
         QR_TS(6);
 #if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
@@ -1718,9 +1776,14 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #ifdef QR_GI_STAMPS
         if (lane == 0 && QR_DBGT) for (int i = 0; i < 6; ++i) QR_DBGT[(size_t)rid * 16 + 8 + i] = cs_t[i];
 #endif
+#ifdef QR_SLOT_STAMPS      // which CU ran this robot (HW_ID, XCC_ID): per-CU timelines of a launch, scratch/diag_slots.py
+        if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
 #endif
     }
 }
+#undef QR_SYNC
+#undef QR_IDLE
 
 // Launch wrappers (one inlined copy of the solve each).
 //   LIST = false, main pass: workgroup b solves the robot of slot xcd_robot_index(b) (through the longest-first order when there is one);
@@ -1734,6 +1797,12 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
     extern __shared__ double smem[];
     if (P.started && threadIdx.x == 0) atomicAdd(P.started, 1);        // (planned list launches: see qr_gate_kernel)
     if (!LIST && P.main_started && P.rescue_mode == 0 && threadIdx.x == 0) atomicAdd(P.main_started, 1);     // (pipelined tick: the WBC launch's gate)
+    if (QR_P_TL && threadIdx.x == 0) {
+        long long *tl = QR_P_TL + (P.done_epoch & 63u) * 8;
+        const long long t = wall_clock64();
+        if (!LIST && P.rescue_mode == 0) { atomicMin(tl + 0, t); atomicMax(tl + 1, t); }
+        if (LIST && P.rescue_mode == 1) atomicMin(tl + 5, t);
+    }
     if constexpr (LIST) {
         const bool planned = P.rescue_mode == 2;
         if (!planned && blockIdx.x < 8) {
@@ -1741,6 +1810,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                 lpt_order_chunk(blockIdx.x, P.n, P.lpt_cost_in, P.lpt_order_out, (int *)smem);
                 __syncthreads();
             }
+            if (QR_P_FTIME && P.wbc_order_out) { finish_order_chunk(blockIdx.x, P.n, QR_P_FTIME, P.wbc_order_out, (int *)smem); __syncthreads(); }
             if (P.pre_list && P.skip && P.lpt_cost_in) {
                 // plan the next call: robots whose solve left the `big` bit go on the planned list and are skipped by the main pass
                 const int chunk = (P.n + 7) >> 3, lo = blockIdx.x * chunk, hi = (lo + chunk < P.n) ? lo + chunk : P.n;
@@ -1768,6 +1838,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             mpc_solve_robot<MAXB, BIG, NTHR>(P, io, list[e], smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
+        if (QR_P_TL && threadIdx.x == 0 && P.rescue_mode == 1) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 6, wall_clock64());
     } else {
         if (P.rescue_mode == 3) {
             // planned list, one robot per workgroup (so that the waves beyond the active set's four may leave after the sweep, which a workgroup
@@ -1782,17 +1853,65 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             mpc_solve_robot<MAXB, BIG, NTHR>(P, io, P.pre_list[blockIdx.x], smem);
             return;
         }
-        const int slot = xcd_robot_index(blockIdx.x, P.n);
-        if (slot < 0) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
             if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
             if (P.pre_count) { P.pre_count[P.rescue_parity ^ 1] = 0; P.pre_count[2] = 0; }
         }
+        const int slot = xcd_robot_index(blockIdx.x, P.n);
+        if (slot < 0) return;
         const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
         if (P.skip && P.skip[rid]) return;             // solved by the planned list launch, beside this one
         mpc_solve_robot<MAXB, BIG, NTHR>(P, io, rid, smem);
     }
 }
+
+#ifndef QR_FLOPS_BUILD
+// Persistent main pass (MpcLaunch::persist): one workgroup per resident slot; robots come off the queue of the workgroup's own XCD (slot
+// order of its chunk = the longest-first order), then off the others'; every robot taken counts for the WBC launch's gate.
+template <int MAXB, bool BIG, int NTHR>
+__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
+void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
+{
+    extern __shared__ double smem[];
+    volatile int *sNext = (volatile int *)smem;        // (the head of the dynamic LDS, dead between two solves: a static word would push the second workgroup off the CU)
+    if (QR_P_TL && threadIdx.x == 0) atomicMin(QR_P_TL + (P.done_epoch & 63u) * 8, wall_clock64());
+    if (blockIdx.x == 0 && threadIdx.x == 0) {         // the next call's counters
+        if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
+        if (P.pre_count) { P.pre_count[P.rescue_parity ^ 1] = 0; P.pre_count[2] = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) P.qhead_next[threadIdx.x] = 0;
+    const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);      // HW_REG_XCC_ID[3:0]
+    const int chunk = (P.n + 7) >> 3;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int got = -1;
+            for (int a = 0; a < 8 && got < 0; ++a) {
+                const int y = (xcc + a) & 7, lo = y * chunk;
+                const int len = (lo + chunk < P.n ? lo + chunk : P.n) - lo;
+                while (len > 0 && __hip_atomic_load(P.qhead + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len) {
+                    const int k = atomicAdd(P.qhead + y, 1);
+                    if (k >= len) break;
+                    if (P.main_started) atomicAdd(P.main_started, 1);
+                    const int r = P.order ? P.order[lo + k] : lo + k;
+                    if (P.skip && P.skip[r]) continue;         // solved by the planned list launch, beside this one
+                    got = r;
+                    if (QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 1, wall_clock64());
+                    break;
+                }
+            }
+            *sNext = got;
+        }
+        __syncthreads();
+        const int rid = *sNext;
+        __syncthreads();
+        if (rid < 0) return;
+        mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, rid, smem);
+        __syncthreads();                               // every wave is out of the solve before the LDS is carved again
+    }
+}
+template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
+template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
+#endif
 
 template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
 template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
@@ -1807,12 +1926,18 @@ template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);  
 // main pass's thousand workgroups fill every CU first and the listed robot starts 80-160 us late -- which is then the end of the launch.
 // The counter is cumulative and never cleared (`expected_total` is the host's running sum of the grids, compared as a wrapping difference):
 // a workgroup that starts after a gate has timed out is counted where it belongs instead of leaking into the next call's count.
-__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks)
+// `timed_out` (pinned host memory, or null): set to 1 when the wait ends on the clock instead of the counter -- the join of a pipelined tick
+// must not give up silently (qrgpu_tick_batch, qrgpu_sync).
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) < 0 && wall_clock64() - t0 < max_ticks)
+    for (;;) {
+        if ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) >= 0) return;
+        if (wall_clock64() - t0 >= max_ticks) break;
         __builtin_amdgcn_s_sleep(16);
+    }
+    if (timed_out) { *timed_out = 1; __threadfence_system(); }
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

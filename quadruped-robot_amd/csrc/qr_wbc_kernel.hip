@@ -30,6 +30,15 @@
 
 namespace qrgpu {
 
+// Diagnostic hooks of the pipelined tick's timeline: compiled in only with -DQR_TIMELINE (see qr_mpc_kernel.hip)
+#ifdef QR_TIMELINE
+#define QW_P_TL pipe.tl
+#define QW_P_TLR pipe.tlr
+#else
+#define QW_P_TL ((long long *)nullptr)
+#define QW_P_TLR ((int *)nullptr)
+#endif
+
 typedef double real;
 
 struct v3 { real x, y, z; };
@@ -335,39 +344,48 @@ __device__ __forceinline__ bool sym3_inverse(const real *W, real thr, real iv[6]
 #define CLEG(k) ((int)((cpack >> (4 * (k))) & 15u))
 #define TLEG(k) ((int)((tpack >> (4 * (k))) & 15u))
 
+// Output stores of a pipelined tick are written through (agent scope, sc1) so that the wave can tell the tick's join when they are in memory
+// (wbc_signal_done): a plain store otherwise.
+__device__ __forceinline__ void st_w(float *p, float v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ void st_w(int *p, int v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ void wbc_signal_done(int *finished, int lane)
+{
+    if (!finished) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have been acknowledged
+    if (lane == 0) __hip_atomic_fetch_add(finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The relaxation QP of K13 and the torque store (+ K14 tail), on one wavefront.  Inputs in LDS: A (mass matrix), JC (stacked contact
 // Jacobian), qdd (commanded accelerations of the recursion), Cv, Gv, cm (commands incl. Fr_des and the contact flags).  Wq: >= QW_SIZE doubles
 // of workspace laid out as the QW_* offsets say (Nq over NP + T1, Sq over JB + JTP + JTB, the vectors at VEC / QP).
-__device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, const int n, const WbcConst &K, const int nc, const unsigned cpack, const bool bad_type,
-                                                 const real *A, const real *JC, const real *qdd, const real *Cv, const real *Gv, const real *cm, real *W, int *sI,
-                                                 float *__restrict__ g_tau, int *__restrict__ g_status, const int merge_tau, const int status_or, const int epilogue,
-                                                 long long *__restrict__ dbgT, float *__restrict__ g_qp, const bool piped = false, float *__restrict__ g_prev = nullptr)
+//
+// In two parts.  wbc_qp_setup is everything that does not read Fr_des: the force-free part of gen, the constraint normals, and the 6 x 6 block
+// of the floating-base equalities with its inverse.  In a pipelined tick it runs BEFORE the workgroup waits for the MPC's forces, so that only
+// the right-hand sides, the changes of the working set and the store are left behind the robot's flag.  Returns true when the equalities
+// are dependent (QRGPU_ST_WBC_INFEAS).  The arithmetic of every value is what it was in one piece.
+__device__ __forceinline__ bool wbc_qp_setup(const int lane, const WbcConst &K, const int nc, const real *A, const real *JC, const real *qdd, const real *Cv, const real *Gv,
+                                             real *W, int *sI)
 {
-#define QW_TSF(i) do { if (dbgT && (threadIdx.x & 63) == 0 && threadIdx.x < 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
-    int qp_iters = 0;
     const int dimFr = 3 * nc;
     real *tv = W + QW_VEC + 18;
     real *Nq = W + QW_NP;          // 30 x 18 QP constraint normals
     real *Sq = W + QW_JB;          // 18 x 18 S^-1
     real *qd_ = W + QW_QP;         // 32 d
-    real *qr_ = qd_ + 32;          // 32 r
-    real *qu_ = qr_ + 32;          // 32 u
-    real *qc0 = qu_ + 32;          // 32 constraint offsets
-    real *qx = qc0 + 32;           // 18 z
-    QW_TSF(7);
-    // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
-    //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
-    //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
-    //   inequalities    :  Uf (Fr_des + z_f) - ineqVec >= 0
+    real *qx = qd_ + 128;          // 18 z
     const int nz = 6 + dimFr, np_ = 6, mi = 6 * nc;
-    // gen (tv) = A qdd + C + G - Jc^T Fr_des  (all 18 rows; rows 6.. are reused for the torque)
+    // gen (tv) = A qdd + C + G - Jc^T Fr_des  (all 18 rows; rows 6.. are reused for the torque): here without the last term
     if (lane < 18) {
         real acc = Cv[lane] + Gv[lane];
         for (int k = 0; k < 18; ++k) acc += A[lane * 18 + k] * qdd[k];
-        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * CLEG(k / 3) + k % 3];
         tv[lane] = acc;
     }
-    // constraint normals Nq[c][0:nz], offsets qc0[c]
+    // constraint normals Nq[c][0:nz]
     for (int e = lane; e < (np_ + mi) * nz; e += 64) {
         const int c = e / nz, j = e - c * nz;
         real v = 0.0;
@@ -384,7 +402,54 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
         }
         Nq[c * 18 + j] = v;
     }
+    if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
+    if (lane < 32) sI[32 + lane] = -1;    // constraint -> position or -1
     wsync();
+    // The six floating-base equalities enter together instead of one active-set iteration each: with S_e = N_e M N_e' (6 x 6),
+    // u_e = -S_e^-1 c_e, z = M N_e' u_e, S^-1 = S_e^-1, working set = {0..5}.  Same point the six equality iterations reach.
+    const real iw_fb = 1.0 / (real)K.w_fb, iw_fr = 1.0 / (real)K.w_fr;
+    if (lane < 36) {
+        const int a = lane / 6, b2 = lane - 6 * a;
+        real acc = 0.0;
+        for (int j = 0; j < nz; ++j) acc += Nq[a * 18 + j] * ((j < 6) ? iw_fb : iw_fr) * Nq[b2 * 18 + j];
+        Sq[a * 18 + b2] = acc;
+    }
+    wsync();
+    real tr = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) tr += Sq[a * 18 + a];
+    const real minpiv = spd_inverse<1>(lane, Sq, 18, 6, qd_);
+    return !(minpiv > 1e-14 * tr);        // dependent equalities
+}
+
+__device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, const int n, const WbcConst &K, const int nc, const unsigned cpack, const bool bad_type,
+                                                 const bool eq_dependent, const real *A, const real *JC, const real *cm, real *W, int *sI,
+                                                 float *__restrict__ g_tau, int *__restrict__ g_status, const int merge_tau, const int status_or, const int epilogue,
+                                                 long long *__restrict__ dbgT, float *__restrict__ g_qp, const bool piped = false, float *__restrict__ g_prev = nullptr)
+{
+#define QW_TSF(i) do { if (dbgT && (threadIdx.x & 63) == 0 && threadIdx.x < 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+    int qp_iters = 0;
+    const int dimFr = 3 * nc;
+    real *tv = W + QW_VEC + 18;
+    real *Nq = W + QW_NP;          // 30 x 18 QP constraint normals
+    real *Sq = W + QW_JB;          // 18 x 18 S^-1
+    real *qd_ = W + QW_QP;         // 32 d
+    real *qr_ = qd_ + 32;          // 32 r
+    real *qu_ = qr_ + 32;          // 32 u
+    real *qc0 = qu_ + 32;          // 32 constraint offsets
+    real *qx = qc0 + 32;           // 18 z
+    // ---------------- relaxation QP (SetCost/SetEqualityConstraint/SetInequalityConstraint :129-167,232-247) ----------------
+    //   min 1/2 z' W z,  W = diag(w_fb x6, w_fr x dimFr)
+    //   equalities  i<6 :  A[i,0:6] z_fb - Jc[:,i]' z_f + gen_i = 0,   gen = (A qdd + C + G - Jc' Fr_des)[0:6]
+    //   inequalities    :  Uf (Fr_des + z_f) - ineqVec >= 0
+    const int nz = 6 + dimFr, np_ = 6, mi = 6 * nc;
+    if (lane < 18) {
+        real acc = tv[lane];
+        for (int k = 0; k < dimFr; ++k) acc -= JC[k * 18 + lane] * cm[51 + 3 * CLEG(k / 3) + k % 3];
+        tv[lane] = acc;
+    }
+    wsync();
+    // offsets qc0[c]
     if (lane < np_ + mi) {
         const int c = lane;
         real v;
@@ -397,7 +462,6 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
         }
         qc0[c] = v;
     }
-    if (lane < 18) qx[lane] = 0.0;        // g0 = 0  =>  unconstrained minimiser z = 0
     wsync();
     int stw = bad_type ? QRGPU_ST_BAD_TYPE_D : 0;
     {
@@ -411,25 +475,11 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
         int *iter_out = &qp_iters;
         bool fail = false;
         int *act = sI;             // active ids
-        int *posi = sI + 32;       // constraint -> position or -1
-        if (lane < 32) posi[lane] = -1;
-        wsync();
-        // The six floating-base equalities enter together instead of one active-set iteration each: with S_e = N_e M N_e' (6 x 6),
-        // u_e = -S_e^-1 c_e, z = M N_e' u_e, S^-1 = S_e^-1, working set = {0..5}.  Same point the six equality iterations reach.
+        int *posi = sI + 32;       // constraint -> position or -1 (cleared by wbc_qp_setup)
+        // the six floating-base equalities: S^-1 = S_e^-1 is in place (wbc_qp_setup); u_e = -S_e^-1 c_e, z = M N_e' u_e, working set = {0..5}
         int next_eq = 0;
         {
-            if (lane < 36) {
-                const int a = lane / 6, b2 = lane - 6 * a;
-                real acc = 0.0;
-                for (int j = 0; j < nz; ++j) acc += Nq[a * 18 + j] * Minv(j) * Nq[b2 * 18 + j];
-                Sq[a * 18 + b2] = acc;
-            }
-            wsync();
-            real tr = 0.0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) tr += Sq[a * 18 + a];
-            const real minpiv = spd_inverse<1>(lane, Sq, 18, 6, qd_);
-            if (!(minpiv > 1e-14 * tr)) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; }      // dependent equalities
+            if (eq_dependent) { stw |= QRGPU_ST_WBC_INFEAS_D; fail = true; }
             if (lane < 6) {
                 real acc = 0.0;
 #pragma unroll
@@ -584,7 +634,7 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
         const int leg = lane / 3;
         const bool stance = cm[63 + leg] != 0.0;
         if (!epilogue) {
-            if (!merge_tau || stance) g_tau[(size_t)lane * n + rid] = (float)acc;
+            if (!merge_tau || stance) st_w(&g_tau[(size_t)lane * n + rid], (float)acc, piped);
         } else {
             // K14 tail (fused tick): UpdateLegCMD overwrites the stance legs (:205-219) AFTER qrFSMStateLocomotion::Run added the +-0.9 N m abad
             // compensation to every leg (QS/fsm/qr_fsm_state_locomotion.cpp:141-151), so the compensation survives on swing legs only (their
@@ -593,14 +643,14 @@ __device__ __forceinline__ void wbc_qp_and_store(const int lane, const int rid, 
                               : (double)(piped ? __hip_atomic_load(g_tau + (size_t)lane * n + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_tau[(size_t)lane * n + rid]);
             if (!stance && (epilogue & 1) && lane % 3 == 0) t += (double)((leg & 1) ? 0.9f : -0.9f);
             if (epilogue & 2) t = t > 23.0 ? 23.0 : (t < -23.0 ? -23.0 : t);
-            g_tau[(size_t)lane * n + rid] = (float)t;
+            st_w(&g_tau[(size_t)lane * n + rid], (float)t, piped);
         }
     }
-    if (g_prev && lane < 3) g_prev[(size_t)lane * n + rid] = (float)cm[12 + lane];          // desiredVel of the orientation task (quirk 4's memory)
+    if (g_prev && lane < 3) st_w(&g_prev[(size_t)lane * n + rid], (float)cm[12 + lane], piped);          // desiredVel of the orientation task (quirk 4's memory)
     if (lane == 0 && g_status) {
         if (status_or & 2) stw |= QRGPU_ST_PIPE_TIMEOUT_D;
-        if (status_or & 1) g_status[rid] = stw | (piped ? __hip_atomic_load(g_status + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_status[rid]);
-        else g_status[rid] = stw;
+        if (status_or & 1) st_w(&g_status[rid], stw | (piped ? __hip_atomic_load(g_status + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_status[rid]), piped);
+        else st_w(&g_status[rid], stw, piped);
     }
     QW_TSF(9);
 #undef QW_TSF
@@ -641,6 +691,9 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         rid = pipe.list[blockIdx.x];
     }
     if (rid < 0) return;
+    if (QW_P_TL && threadIdx.x == 0 && !pipe.list) atomicMin(QW_P_TL + (pipe.epoch & 63u) * 8 + 3, wall_clock64());
+    if (pipe.order && !pipe.list) rid = pipe.order[rid];        // (a permutation inside the XCD chunk: qr_mpc_kernel.hip, finish_order_chunk)
+    if (QW_P_TLR && threadIdx.x == 0 && !pipe.list) QW_P_TLR[rid] = (int)wall_clock64();
     int tyid = type_id ? type_id[rid] : 0;
     const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
     if (bad_type) tyid = __builtin_ctz(type_ready | (1 << QR_MAX_TYPES));     // computed with the first valid type, flagged QRGPU_ST_BAD_TYPE
@@ -1201,11 +1254,12 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             if (t < nt - 1) npre_update(T1); else wsync();
         }
         if (lane < 12) {
-            g_qdes[(size_t)lane * n + rid] = (float)(qj[lane] + dq1[6 + lane]);
-            g_qdes[(size_t)(12 + lane) * n + rid] = (float)dq2[6 + lane];
+            st_w(&g_qdes[(size_t)lane * n + rid], (float)(qj[lane] + dq1[6 + lane]), pipe.flag != nullptr);
+            st_w(&g_qdes[(size_t)(12 + lane) * n + rid], (float)dq2[6 + lane], pipe.flag != nullptr);
         }
       }
       QW_TS1(13);
+      wbc_signal_done(pipe.finished, lane);
       return;
     }
 
@@ -1253,6 +1307,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (t < nt - 1) npre_update(T2); else wsync();
     }
 
+    QW_TS(7);
+    const bool eq_dependent = wbc_qp_setup(lane, K, nc, A, JC, qdd, Cv, Gv, W, sI);
     int pipe_st = 0;
     if (pipe.flag) {
         // Everything up to here needed the robot's state and commands only; the relaxation QP needs the MPC's first-step forces.  The robot's
@@ -1268,12 +1324,16 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             __builtin_amdgcn_s_sleep(32);
         }
         v = __builtin_amdgcn_readfirstlane(v);
-        if (!pipe_st && (v & 1u)) return;              // on the MPC's list pass: the second WBC pass behind that launch takes this robot
+        if (QW_P_TLR && lane == 0) QW_P_TLR[n + rid] = (int)wall_clock64();
+        if (!pipe_st && (v & 1u)) { wbc_signal_done(pipe.finished, lane); return; }              // on the MPC's list pass: the second WBC pass behind that launch takes this robot
         if (lane < 12) cm[51 + lane] = (real)__hip_atomic_load(g_fr + (size_t)lane * n + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wsync();
     }
-    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, A, JC, qdd, Cv, Gv, cm, W, sI, g_tau, g_status, merge_tau, status_or | (pipe_st ? 2 : 0), epilogue, dbgT, g_qp,
+    wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, eq_dependent, A, JC, cm, W, sI, g_tau, g_status, merge_tau, status_or | (pipe_st ? 2 : 0), epilogue, dbgT, g_qp,
                      pipe.flag != nullptr, g_prev);
+    wbc_signal_done(pipe.finished, lane);
+    if (QW_P_TL && lane == 0) atomicMax(QW_P_TL + (pipe.epoch & 63u) * 8 + (pipe.list ? 7 : 4), wall_clock64());
+    if (QW_P_TLR && lane == 0 && !pipe.list) QW_P_TLR[2 * n + rid] = (int)wall_clock64();
 }
 
 }  // namespace qrgpu

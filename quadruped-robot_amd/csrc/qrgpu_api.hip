@@ -31,6 +31,9 @@ extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, Mpc
 extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
+template <int MAXB, bool BIG, int NTHR> __global__ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io);
+extern template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
 // the same kernels with the executed-arithmetic counters compiled in (qr_mpc_kernel_fl.hip)
 template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512>(MpcLaunch, MpcIO);
@@ -40,10 +43,10 @@ extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch,
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
-__global__ void qr_lpt_order_kernel(int n, const int *cost, int *order);
+__global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *g_in, float *g_out);
-__global__ void qr_gate_kernel(int *counter, int expected, long long max_ticks);
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
                                     float *g_vmc_in);
@@ -72,6 +75,8 @@ static const void *mpc_fn(int var, bool fl)
     case 2: return fl ? (const void *)qr_mpc_kernel_fl<4, false, false, 256> : (const void *)qr_mpc_kernel<4, false, false, 256>;
     case 3: return fl ? (const void *)qr_mpc_kernel_fl<2, false, false, 512> : (const void *)qr_mpc_kernel<2, false, false, 512>;
     case 4: return fl ? (const void *)qr_mpc_kernel_fl<4, true, true, 256> : (const void *)qr_mpc_kernel<4, true, true, 256>;
+    case 6: return (const void *)qr_mpc_persist_kernel<2, false, 512>;        // persistent forms of 3 and 0 (no counting build of these)
+    case 7: return (const void *)qr_mpc_persist_kernel<5, true, 512>;
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
 }
@@ -80,7 +85,7 @@ static const void *mpc_fn(int var, bool fl)
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
     static std::mutex mu;
-    static int configured[16][2][6];          // [device][counting build][variant], zero-initialised
+    static int configured[16][2][8];          // [device][counting build][variant], zero-initialised
     std::lock_guard<std::mutex> lk(mu);
     int &have = configured[c->device & 15][fl ? 1 : 0][var];
     if (have >= bytes) return QRGPU_OK;
@@ -278,17 +283,21 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 4)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_pre_count, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_pre_count, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->d_pre_hint, c->h_pre_count, 0) != hipSuccess ||
         hipMalloc(&c->d_started, sizeof(int)) != hipSuccess || hipMemset(c->d_started, 0, sizeof(int)) != hipSuccess ||
         create_side_stream(&c->side_stream) != hipSuccess || hipStreamCreateWithFlags(&c->wbc_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_wbc_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_wbc_join, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_wbc_finished, sizeof(int)) != hipSuccess || hipMemset(c->d_wbc_finished, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_ftime, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * (size_t)max_batch) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
+    c->h_pre_count[0] = c->h_pre_count[1] = c->h_pre_count[2] = c->h_pre_count[3] = 0;       // ([2]: a pipelined tick's join gave up waiting)
     memset(&c->mpc, 0, sizeof(c->mpc));
     memset(c->wbc_host, 0, sizeof(c->wbc_host));
     *out = c;
@@ -299,6 +308,8 @@ void qrgpu_destroy(qrgpu_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->wbc_stream) (void)hipStreamSynchronize(c->wbc_stream);
     qrgpu_comm_destroy(c);
     for (int k = 0; k < 2; ++k) for (auto &e : c->ev[k]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : c->marks) hipEventDestroy(e);
@@ -326,6 +337,12 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
     if (c->d_done_flag) hipFree(c->d_done_flag);
     if (c->d_main_started) hipFree(c->d_main_started);
+    if (c->d_ftime) hipFree(c->d_ftime);
+    if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
+    if (c->d_qhead) hipFree(c->d_qhead);
+    if (c->d_timeline) hipFree(c->d_timeline);
+    if (c->d_tlr) hipFree(c->d_tlr);
+    if (c->d_wbc_order) hipFree(c->d_wbc_order);
     if (c->d_started) hipFree(c->d_started);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
@@ -440,6 +457,20 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.done_flag = piped ? c->d_done_flag : nullptr;
     P.done_epoch = c->tick_epoch;
     P.main_started = piped ? c->d_main_started : nullptr;
+    P.tl = piped ? c->d_timeline : nullptr;
+    // QRGPU_WBC_ORDER=1 (an experiment, off by default): the solves also leave the moment they ended, from which the launch behind the main pass
+    // sorts the NEXT tick's WBC order (robots in the order their solves ended) into the half of d_wbc_order that this tick's WBC launch is not
+    // reading.  Measured: nothing at 1024 robots (4.15 against 4.16-4.20 M ticks/s: nine WBC workgroups in ten start AFTER their robot's solve
+    // has ended, they are short of slots, not waiting for flags) and -6 % at 8192 (two rank sorts of 1024-robot chunks behind the main pass).
+    // (The moments come from the timeline hooks: a library built with -DQR_TIMELINE only.)
+#ifdef QR_TIMELINE
+    static const int wbc_order_on = [] { const char *e = getenv("QRGPU_WBC_ORDER"); return e ? atoi(e) : 0; }();
+#else
+    static const int wbc_order_on = 0;
+#endif
+    const bool wbc_ord = piped && wbc_order_on != 0 && n <= 16384;
+    P.ftime = (wbc_ord || (piped && c->d_tlr)) ? c->d_ftime : nullptr;
+    P.wbc_order_out = wbc_ord ? c->d_wbc_order + (size_t)(c->wbc_order_parity ^ 1) * (size_t)c->max_batch : nullptr;
     P.flops = (c->flops_on && !dH) ? c->d_flops : nullptr;
     if (P.flops) c->flops_n = n;
     // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
@@ -453,6 +484,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const bool lpt = c->lpt && n >= 64 && !dH;
     P.order = (lpt && c->lpt_n == n) ? c->d_order : nullptr;
     P.cost = lpt ? c->d_cost : nullptr;
+    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && c->lpt_n == n && ema) ? 1 : 0; }
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
     P.sinv_spill = nullptr;
@@ -506,6 +538,34 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const void *fn = mpc_fn(var, fl);
     { const int rc_ = mpc_ensure_lds(c, var, fl, P.lds_bytes); if (rc_) return rc_; }
     if (rescue) { const int rc_ = mpc_ensure_lds(c, 4, fl, c->lds_per_cu); if (rc_) return rc_; }
+    // Persistent main pass (qr_device_types.h): when the batch is more than the machine holds at once, launch one workgroup per resident slot
+    // and let them take robots off per-XCD queues.  Default (QRGPU_PERSIST=1): the h > 11 variant only -- 1.31 -> 1.37 M ticks/s on the mixed
+    // h = 16 shard.  At h <= 11 (QRGPU_PERSIST=2 to try) it loses what it gains and more: the four waves a solve no longer needs after its sweep
+    // cannot leave a workgroup that has another robot to solve, they have to cross every barrier of the active set with the working ones
+    // (a live wave counts at s_barrier), and a parked wave's wake-up, look at the exit word and return to the barrier is on the critical
+    // path of each of the two hundred barriers of a solve: main pass 0.208 -> 0.231 ms at 1024 robots, 1.39 -> 1.46 ms at 8192.
+    // QRGPU_PERSIST=0: one workgroup per robot everywhere, dispatched by the hardware in launch order.
+    static const int persist_on = [] { const char *e = getenv("QRGPU_PERSIST"); return e ? atoi(e) : 1; }();
+    int main_grid = 8 * ((n + 7) / 8);
+    P.persist = 0; P.qhead = nullptr; P.qhead_next = nullptr;
+    const void *main_fn = fn;
+    if (persist_on && !fl && !tiny && (var == 0 || (var == 3 && persist_on >= 2))) {
+        const int pvar = var == 3 ? 6 : 7;
+        { const int rc_ = mpc_ensure_lds(c, pvar, false, P.lds_bytes); if (rc_) return rc_; }
+        if (c->main_slots[pvar][0] == 0 || c->main_slots_lds[pvar][0] != P.lds_bytes) {
+            int nb = 0;
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_fn(pvar, false), 512, (size_t)P.lds_bytes));
+            c->main_slots[pvar][0] = nb > 0 ? nb : 1; c->main_slots_lds[pvar][0] = P.lds_bytes;
+        }
+        const int slots = 8 * ((c->main_slots[pvar][0] * c->num_cu + 7) / 8);
+        if (main_grid > slots) {
+            P.persist = 1;
+            P.qhead = c->d_qhead + 8 * c->qhead_parity; P.qhead_next = c->d_qhead + 8 * (c->qhead_parity ^ 1);
+            c->qhead_parity ^= 1;
+            main_grid = slots;
+            main_fn = mpc_fn(pvar, false);
+        }
+    }
     MpcIO io;
     io.type_id = d_type; io.g_state = d_state; io.g_traj = d_traj; io.g_gait = d_gait; io.g_q = d_q; io.g_force = d_force; io.g_tau = d_tau;
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
@@ -521,6 +581,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
         P.skip = c->d_skip;
         MpcLaunch L = P;
+        L.persist = 0; L.qhead = nullptr; L.qhead_next = nullptr;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = c->lds_per_cu;
         static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
@@ -558,15 +619,15 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
-        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000); HIPCHK(c, hipGetLastError()); }
+        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr); HIPCHK(c, hipGetLastError()); }
     }
     {
         TimerScope ts(c, 0);
-        const dim3 grid(8 * ((n + 7) / 8));
+        const dim3 grid(main_grid);
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
         const int threads = (var == 3 || var == 0 || var == 5) ? 512 : 256;
-        HIPCHK(c, hipExtLaunchKernel(fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
+        HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
     if (have_plan && planned_mode != 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -574,6 +635,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
+        R.persist = 0; R.qhead = nullptr; R.qhead_next = nullptr;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.done_flag = nullptr; R.main_started = nullptr;      // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass)
         R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
@@ -594,13 +656,17 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         c->rescue_parity ^= 1;
     }
     c->last_rescue_active = rescue;
-    if (piped) c->main_started_total += (int)(8 * ((n + 7) / 8));
+    if (piped) c->main_started_total += P.persist ? n : (int)(8 * ((n + 7) / 8));      // (persistent: one count per robot taken off a queue)
     if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {
-        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order);
+        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order, (const int *)P.ftime, P.wbc_order_out);
         HIPCHK(c, hipGetLastError());
         c->lpt_n = n;
     }
+    // (the WBC order is sorted by the launch behind the main pass -- the trailing list launch or qr_lpt_order_kernel; any other MPC launch on
+    //  this context in between leaves the halves as they are and the next pipelined tick starts from slot order)
+    if (wbc_ord && (lpt || rescue)) { c->wbc_order_parity ^= 1; c->wbc_order_n = n; }
+    else c->wbc_order_n = 0;
     // The list's length reaches the host through pinned memory, unsynchronised: a caller that queues ticks faster than the GPU runs them
     // decides on a count several ticks old -- and on nothing at all for the first ticks of a new batch, whose listed robots then go through
     // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
@@ -617,7 +683,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr})
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr})
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -933,7 +999,12 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
     float *const force = d_force ? d_force : c->d_cmd_tick;
     static const int pipe_env = [] { const char *e = getenv("QRGPU_TICK_PIPELINE"); return e ? atoi(e) : 1; }();
-    const bool piped = c->pipeline && pipe_env != 0 && n >= 64 && !c->d_dbg_cycles && !c->d_dbg_cycles_wbc;
+    bool piped = c->pipeline && pipe_env != 0 && n >= 64 && !c->d_dbg_cycles && !c->d_dbg_cycles_wbc;
+    if (piped) {         // (not while the stream is being captured into a graph: the WBC launch lives on a stream of the context's own)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+        if (cap != hipStreamCaptureStatusNone) piped = false;
+    }
     if (!piped) {
         int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0);
         if (rc) return rc;
@@ -956,22 +1027,31 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     }
     // (QRGPU_PIPE_EARLY=K opens the gate K workgroups early: an experiment)
     static const int pipe_early = [] { const char *e = getenv("QRGPU_PIPE_EARLY"); return e ? atoi(e) : 0; }();
-    const int expect = c->main_started_total + (int)(8 * ((n + 7) / 8)) - pipe_early;          // (launch_mpc adds the grid to main_started_total)
-    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, (long long)1000000);
+    // (the half of d_wbc_order this tick's WBC launch reads: taken before launch_mpc, whose trailing launch writes the other half and flips the parity)
+    const int *const wbc_order_in = c->wbc_order_n == n ? c->d_wbc_order + (size_t)c->wbc_order_parity * (size_t)c->max_batch : nullptr;
+    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true);
+    if (rc) return rc;
+    const int expect = c->main_started_total - pipe_early;          // (launch_mpc has added this tick's main-pass units to main_started_total)
+    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, (long long)1000000, (int *)nullptr);
     HIPCHK(c, hipGetLastError());
-    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr};
-    int rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
-                        c->wbc_stream, wp);
+    // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
+    // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
+    static const int pipe_join = [] { const char *e = getenv("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
+    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in};
+    rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
+                    c->wbc_stream, wp);
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
-    rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true);
-    if (rc) return rc;
+    if (!pipe_join) HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
     if (c->last_rescue_active) {
-        WbcPipe lp{nullptr, 0u, c->d_rescue + 2, c->d_rescue + c->last_rescue_parity};
+        WbcPipe lp{nullptr, c->tick_epoch, c->d_rescue + 2, c->d_rescue + c->last_rescue_parity, nullptr, nullptr, c->d_timeline, nullptr};
         rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr, nullptr, lp);
         if (rc) return rc;
     }
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
+    if (pipe_join) {
+        c->wbc_finished_total += 2 * n;
+        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2);
+        HIPCHK(c, hipGetLastError());
+    } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
     return QRGPU_OK;
 }
 
@@ -1127,6 +1207,37 @@ int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to di
     return QRGPU_OK;
 }
 
+int qrgpu_debug_timeline(qrgpu_ctx *c, long long *host_out /* [65][8] (row 64, entry 0: the last tick's epoch), or NULL to switch on and reset */)
+{   // undocumented diagnostic: per pipelined tick (ring of 64, indexed by the tick's epoch & 63) on the shared 100 MHz clock:
+    // 0 first / 1 last start of a main-pass workgroup, 2 last solve published, 3 first WBC workgroup, 4 last WBC workgroup done,
+    // 5 trailing list launch started, 6 ended, 7 second WBC pass ended (0 / LLONG_MAX where nothing was recorded)
+    if (!c) return QRGPU_ERR_BAD_ARG;
+#ifndef QR_TIMELINE
+    c->err = "qrgpu_debug_timeline: the stamps are compiled in only with -DQR_TIMELINE (QRGPU_EXTRA_FLAGS)";
+    return QRGPU_ERR_NOT_SETUP;
+#endif
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->wbc_stream));
+    if (!c->d_timeline) HIPCHK(c, hipMalloc(&c->d_timeline, sizeof(long long) * 512));
+    if (!c->d_tlr) HIPCHK(c, hipMalloc(&c->d_tlr, sizeof(int) * 4 * (size_t)c->max_batch));
+    if (host_out) HIPCHK(c, hipMemcpy(host_out, c->d_timeline, sizeof(long long) * 512, hipMemcpyDeviceToHost));
+    long long init[512];
+    for (int e = 0; e < 64; ++e) for (int k = 0; k < 8; ++k) init[e * 8 + k] = (k == 0 || k == 3 || k == 5) ? 0x7fffffffffffffffLL : 0;
+    HIPCHK(c, hipMemcpy(c->d_timeline, init, sizeof(init), hipMemcpyHostToDevice));
+    if (host_out) host_out[512] = (long long)c->tick_epoch;
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_timeline_robots(qrgpu_ctx *c, int *host_out /* [4][n]: WBC started, flag seen, WBC done, the solve's flag raised */, int n)
+{   // undocumented diagnostic: per-robot moments of the last pipelined tick (after qrgpu_debug_timeline switched the stamps on)
+    if (!c || !c->d_tlr || !host_out || n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->wbc_stream));
+    HIPCHK(c, hipMemcpy(host_out, c->d_tlr, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out + 3 * (size_t)n, c->d_ftime, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    return QRGPU_OK;
+}
+
 int qrgpu_selftest(qrgpu_ctx *c, double *host_out256)
 {   // cross-lane helper self-test (tests/test_gpu_mpc.py::test_wave_helpers)
     if (!c || !host_out256) return QRGPU_ERR_BAD_ARG;
@@ -1165,6 +1276,13 @@ int qrgpu_sync(qrgpu_ctx *c)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pre_count && c->h_pre_count[2]) {
+        // the join of a pipelined tick waited 20 ms for its WBC launch and went on without it: outputs of that tick are incomplete
+        c->h_pre_count[2] = 0;
+        (void)hipStreamSynchronize(c->wbc_stream);
+        c->err = "pipelined tick: the WBC launch did not finish within 20 ms of its join (outputs of that tick were incomplete when the stream went on)";
+        return QRGPU_ERR_LAUNCH;
+    }
     return QRGPU_OK;
 }
 

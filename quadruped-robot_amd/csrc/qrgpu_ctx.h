@@ -63,6 +63,18 @@ struct qrgpu_ctx {
     unsigned tick_epoch = 0;
     bool last_rescue_active = false;          // did the last launch_mpc carry a trailing list launch (so that flags may say "on the rescue list")?
     int last_rescue_parity = 0;
+    int *d_qhead = nullptr;                   // [2][8] queue heads of the persistent main pass, ping-pong (a launch zeroes the other half)
+    int qhead_parity = 0;
+    int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
+    int main_slots_lds[16][2] = {};
+    int *d_wbc_finished = nullptr;            // waves of pipelined WBC launches whose outputs are in memory, ever (the tick's join); never cleared
+    int wbc_finished_total = 0;
+    int *d_tlr = nullptr;                     // diagnostic: [4][max_batch] per-robot WBC moments of the last pipelined tick
+    long long *d_timeline = nullptr;          // diagnostic (qrgpu_debug_timeline): [64][8], or null
+    int *d_ftime = nullptr;                   // [max_batch] when each robot's solve ended in the last pipelined tick (100 MHz clock, low word)
+    int *d_wbc_order = nullptr;               // [2][max_batch] the WBC launch's slot -> robot map from those times, ping-pong: a tick's WBC launch reads one
+    int wbc_order_parity = 0;                 //   half while the launch behind its main pass writes the other
+    int wbc_order_n = 0;                      // batch size the half to be read next was written for (0: none)
     int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
     bool lpt = true;
     bool rescue = true;

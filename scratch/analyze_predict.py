@@ -1,0 +1,66 @@
+import numpy as np, heapq
+z = np.load('/root/repo/gpurun_out/slots/predict.npz')
+buf, it, gait = z['buf'], z['it'], z['gait']
+T, n = buf.shape[:2]
+d = (buf[:, :, 13] - buf[:, :, 12]).astype(np.float64) / 100       # us
+ns = buf[:, :, 7].astype(np.float64)
+ph = np.diff(buf[:, :, :7], axis=2).astype(np.float64)             # load, H, sweep, x0, AS, out  (cycles)
+def span(order, dur, slots=512, gap=0.0):
+    s = [0.0] * slots; heapq.heapify(s); end = 0
+    for k in order:
+        a = heapq.heappop(s); e = a + (gap if a > 0 else 0) + dur[k]; end = max(end, e); heapq.heappush(s, e)
+    return end
+def chunk_order(key):        # descending within each XCD chunk, interleaved the way blockIdx walks them
+    chunk = n // 8; per = [np.argsort(-key[x * chunk:(x + 1) * chunk], kind='stable') + x * chunk for x in range(8)]
+    return np.array([per[b & 7][b >> 3] for b in range(n)])
+print("tick: corr(d_t, d_t-1) | span: measured order model (prev cost, chunks), global prev, oracle LPT, sum/512, max | mean |d_t - d_t-1|")
+for t in range(2, T):
+    prev = d[t - 1]
+    # sweep model: cycles ~ f(ns): fit from this data
+    r = np.corrcoef(d[t], prev)[0, 1]
+    q8 = np.minimum(255, (prev * 2400 / 4096).astype(int)).astype(float)
+    s_chunk = span(chunk_order(q8), d[t])
+    s_glob = span(np.argsort(-prev), d[t])
+    s_or = span(np.argsort(-d[t]), d[t])
+    # predictor 2: previous cost corrected by the change of the sweep with ns
+    sw = ph[:, :, 2] / 2400.0
+    coef = np.polyfit(ns[t - 1], sw[t - 1], 3)
+    pred2 = prev - np.polyval(coef, ns[t - 1]) + np.polyval(coef, ns[t])
+    s_p2 = span(np.argsort(-pred2), d[t])
+    # predictor 3: ns only
+    s_p3 = span(np.argsort(-ns[t]), d[t])
+    print("t%2d corr %.3f | chunks(prev) %.1f  global(prev) %.1f  prev+sweep(ns) %.1f  ns only %.1f  oracle %.1f | sum/512 %.1f max %.1f | mean abs change %.1f us, ns changed on %d robots" % (
+        t, r, s_chunk, s_glob, s_p2, s_p3, s_or, d[t].sum() / 512, d[t].max(), np.abs(d[t] - prev).mean(), int((ns[t] != ns[t - 1]).sum())))
+t = 5
+err = d[t] - d[t - 1]
+big = np.argsort(-np.abs(err))[:12]
+print("largest changes t=5: (d_prev, d, ns_prev, ns, it_prev, it, AS_prev k, AS k)")
+for k in big: print("  ", round(d[t-1][k],1), round(d[t][k],1), int(ns[t-1][k]), int(ns[t][k]), int(it[t-1][k]), int(it[t][k]), int(ph[t-1][k][4]/1000), int(ph[t][k][4]/1000))
+print("EMA predictors (global order, no gap): span with prev | mean of last 2 | mean of last 3 | ema .5 | oracle")
+ema = d[0].copy()
+for t in range(1, T):
+    if t >= 3:
+        print("t%2d  %.1f | %.1f | %.1f | %.1f | %.1f   (it-based: prev iterations %.1f)" % (t, span(np.argsort(-d[t-1]), d[t]), span(np.argsort(-(d[t-1]+d[t-2])), d[t]), span(np.argsort(-(d[t-1]+d[t-2]+d[t-3])), d[t]),
+              span(np.argsort(-ema), d[t]), span(np.argsort(-d[t]), d[t]), span(np.argsort(-it[t-1].astype(float)), d[t])))
+    ema = 0.5 * ema + 0.5 * d[t]
+# how much of d is explained by iterations in the same tick
+t = 5
+A = np.stack([np.ones(n), it[t].astype(float), ns[t]], 1)
+c, *_ = np.linalg.lstsq(A, d[t], rcond=None)
+print("d ~ %.1f + %.2f * iterations + %.2f * ns ; residual std %.1f us; corr(it_t, it_t-1) %.3f" % (c[0], c[1], c[2], (d[t] - A @ c).std(), np.corrcoef(it[t], it[t-1])[0,1]))
+print("phases mean (k cycles) load %.1f H %.1f sweep %.1f x0 %.1f AS %.1f out %.1f" % tuple(ph[t].mean(0) / 1000))
+print("EMA weights of the newest tick: mean span over t=3..14")
+for a in (1.0, 0.75, 0.5, 0.35, 0.25, 0.15):
+    ema = d[0].copy(); tot = []
+    for t in range(1, T):
+        if t >= 3: tot.append(span(np.argsort(-ema), d[t]))
+        ema = (1 - a) * ema + a * d[t]
+    print("  a = %.2f: %.1f us (first half %.1f, second half %.1f)" % (a, np.mean(tot), np.mean(tot[:6]), np.mean(tot[6:])))
+tot = [span(np.argsort(-d[t]), d[t]) for t in range(3, T)]; print("  oracle: %.1f" % np.mean(tot))
+# quantised to the kernel's 8-bit units (4096 cycles at 2.4 GHz = 1.7 us) and sorted inside XCD chunks
+for a in (1.0, 0.5, 0.25):
+    ema = d[0].copy(); tot = []
+    for t in range(1, T):
+        if t >= 3: tot.append(span(chunk_order(np.minimum(255, np.floor(ema / 1.7067))), d[t]))
+        ema = (1 - a) * ema + a * d[t]
+    print("  chunks + 8 bit, a = %.2f: %.1f us" % (a, np.mean(tot)))
