@@ -1911,11 +1911,13 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
 }
 template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
 template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
+template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);     // h <= 16, two four-wave workgroups per CU (no parked waves: every wave is in the active set)
 #endif
 
 template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
 template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
+template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);       // h <= 16, list launches (whole CU's LDS, 96 rows)
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep

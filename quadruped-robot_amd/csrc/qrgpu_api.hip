@@ -31,9 +31,11 @@ extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, Mpc
 extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);
 template <int MAXB, bool BIG, int NTHR> __global__ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);
 // the same kernels with the executed-arithmetic counters compiled in (qr_mpc_kernel_fl.hip)
 template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512>(MpcLaunch, MpcIO);
@@ -42,6 +44,7 @@ extern template __global__ void qr_mpc_kernel_fl<4, true, true, 256>(MpcLaunch, 
 extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, MpcIO);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -77,6 +80,8 @@ static const void *mpc_fn(int var, bool fl)
     case 4: return fl ? (const void *)qr_mpc_kernel_fl<4, true, true, 256> : (const void *)qr_mpc_kernel<4, true, true, 256>;
     case 6: return (const void *)qr_mpc_persist_kernel<2, false, 512>;        // persistent forms of 3 and 0 (no counting build of these)
     case 7: return (const void *)qr_mpc_persist_kernel<5, true, 512>;
+    case 8: return fl ? (const void *)qr_mpc_kernel_fl<9, true, true, 256> : (const void *)qr_mpc_kernel<9, true, true, 256>;     // h > 11, list launches
+    case 9: return (const void *)qr_mpc_persist_kernel<9, true, 256>;       // persistent form of 1
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
 }
@@ -85,7 +90,7 @@ static const void *mpc_fn(int var, bool fl)
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
     static std::mutex mu;
-    static int configured[16][2][8];          // [device][counting build][variant], zero-initialised
+    static int configured[16][2][10];          // [device][counting build][variant], zero-initialised
     std::lock_guard<std::mutex> lk(mu);
     int &have = configured[c->device & 15][fl ? 1 : 0][var];
     if (have >= bytes) return QRGPU_OK;
@@ -501,7 +506,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const bool tiny = small && n < 64 && !dH && tiny_whole_cu != 0;
     if (tiny) P.lds_bytes = c->lds_per_cu;
     // rescue pass for the h <= 11 main pass (not for inspection launches or tiny batches)
-    const bool rescue = c->rescue && !dH && small && !tiny;          // the h > 11 variant holds 96 rows itself
+    // h > 11, QRGPU_H16_TWO=1 (an experiment, off by default): the main pass runs TWO four-wave workgroups per CU on half the LDS each -- a
+    // trotting robot's inverse Hessian (40 stance leg-steps at h = 16: 59 KB) and a working set of up to ~45 rows fit -- and everything bigger
+    // (all-stance and three-leg robots, larger working sets: 15 % of the mixed shard) goes the way of the h <= 11 main pass: planned list beside
+    // the main pass, trailing list launch behind it, on the whole-CU kernels.  A solve is half sweep, half active set; the active set is a
+    // latency-bound four-wave protocol whatever the workgroup's size, and one workgroup per CU leaves the CU to it alone for that half.
+    // Measured on the mixed shard (scratch/diag_h16_two.py): robots that fit cost 190 us two to a CU (sweep 239 k cycles on four waves,
+    // 154 k on eight) against 150 us one to a CU -- 1.6 x per CU -- but 150-170 robots per tick are on the planned list at 330-400 us each on
+    // the striding four-wave list kernel, and 5-14 a tick outgrow the main pass unannounced and are re-solved BEHIND it: span 1.05 ms
+    // against 0.72 ms, 0.48 against 1.37 M ticks/s.  What it would take is in DESIGN.md 8.
+    static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 0; }();
+    const bool two = !small && h16_two != 0 && !dH && n >= 64;
+    if (two) { P.lds_bytes = (c->lds_per_cu / 2) & ~15; P.sinv_spill = nullptr; }
+    const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;
     P.rescue_count = rescue ? c->d_rescue : nullptr;
     P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
@@ -532,12 +549,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (h16_threads == 256 ? 1 : 0));
+    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : ((h16_threads == 256 || two) ? 1 : 0));
+    const int list_var = small ? 4 : 8;             // striding list kernel (trailing launch, long planned lists)
+    const int one_var = small ? 5 : 0;              // one listed robot per whole-CU eight-wave workgroup
     // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
     const bool fl = P.flops != nullptr || dH != nullptr || dG != nullptr || c->d_dbg_cycles != nullptr;
     const void *fn = mpc_fn(var, fl);
     { const int rc_ = mpc_ensure_lds(c, var, fl, P.lds_bytes); if (rc_) return rc_; }
-    if (rescue) { const int rc_ = mpc_ensure_lds(c, 4, fl, c->lds_per_cu); if (rc_) return rc_; }
+    if (rescue) { const int rc_ = mpc_ensure_lds(c, list_var, fl, c->lds_per_cu); if (rc_) return rc_; }
     // Persistent main pass (qr_device_types.h): when the batch is more than the machine holds at once, launch one workgroup per resident slot
     // and let them take robots off per-XCD queues.  Default (QRGPU_PERSIST=1): the h > 11 variant only -- 1.31 -> 1.37 M ticks/s on the mixed
     // h = 16 shard.  At h <= 11 (QRGPU_PERSIST=2 to try) it loses what it gains and more: the four waves a solve no longer needs after its sweep
@@ -549,12 +568,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     int main_grid = 8 * ((n + 7) / 8);
     P.persist = 0; P.qhead = nullptr; P.qhead_next = nullptr;
     const void *main_fn = fn;
-    if (persist_on && !fl && !tiny && (var == 0 || (var == 3 && persist_on >= 2))) {
-        const int pvar = var == 3 ? 6 : 7;
+    if (persist_on && !fl && !tiny && (var == 0 || var == 1 || (var == 3 && persist_on >= 2))) {
+        const int pvar = var == 3 ? 6 : (var == 1 ? 9 : 7);
         { const int rc_ = mpc_ensure_lds(c, pvar, false, P.lds_bytes); if (rc_) return rc_; }
         if (c->main_slots[pvar][0] == 0 || c->main_slots_lds[pvar][0] != P.lds_bytes) {
             int nb = 0;
-            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_fn(pvar, false), 512, (size_t)P.lds_bytes));
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_fn(pvar, false), var == 1 ? 256 : 512, (size_t)P.lds_bytes));
             c->main_slots[pvar][0] = nb > 0 ? nb : 1; c->main_slots_lds[pvar][0] = P.lds_bytes;
         }
         const int slots = 8 * ((c->main_slots[pvar][0] * c->num_cu + 7) / 8);
@@ -584,6 +603,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         L.persist = 0; L.qhead = nullptr; L.qhead_next = nullptr;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = c->lds_per_cu;
+        L.sinv_spill = c->d_sinv_spill;               // (null at h <= 11; the whole-CU kernels of h > 11 put S^-1 there when an all-stance robot's M leaves no room)
         static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
         const bool gate = gate_on && planned_mode != 1;
         L.started = gate ? c->d_started : nullptr;
@@ -606,15 +626,15 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
             int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
             g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
-            { const int rc_ = mpc_ensure_lds(c, 5, fl, c->lds_per_cu); if (rc_) return rc_; }
+            { const int rc_ = mpc_ensure_lds(c, one_var, fl, c->lds_per_cu); if (rc_) return rc_; }
             void *largs[2] = {(void *)&L, (void *)&io};
-            HIPCHK(c, hipExtLaunchKernel(mpc_fn(5, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
+            HIPCHK(c, hipExtLaunchKernel(mpc_fn(one_var, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
             c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
             void *largs[2] = {(void *)&L, (void *)&io};
-            HIPCHK(c, hipExtLaunchKernel(mpc_fn(4, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
+            HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -641,13 +661,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
         R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
+        R.sinv_spill = c->d_sinv_spill;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
         // empty pass at 4096 robots)
         int rgrid = 64 < n ? 64 : n;
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         void *rargs[2] = {(void *)&R, (void *)&io};
-        HIPCHK(c, hipExtLaunchKernel(mpc_fn(4, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, c->stream, nullptr, nullptr, 0));
+        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, c->stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
         // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
         // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
@@ -1204,6 +1225,15 @@ int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to di
         return QRGPU_OK;
     }
     if (host_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(host_out, c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)n, hipMemcpyDeviceToHost)); }
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_lists(qrgpu_ctx *c, int *host_out /* [4]: rescue list lengths (both parities), planned list lengths (both parities) */)
+{   // undocumented diagnostic: how many robots the last MPC launches handed to the trailing list launch / planned for the next call
+    if (!c || !host_out) return QRGPU_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out, c->d_rescue, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out + 2, c->d_pre, 2 * sizeof(int), hipMemcpyDeviceToHost));
     return QRGPU_OK;
 }
 
