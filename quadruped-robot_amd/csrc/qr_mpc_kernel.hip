@@ -1848,7 +1848,13 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             int cnt = P.pre_count[P.rescue_parity];
             cnt = cnt < P.n ? cnt : P.n;
             if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list)
-                for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = P.pre_list[e2];
+                for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) {
+                    const int r2 = P.pre_list[e2];
+                    P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = r2;
+                    // (pipelined tick: the WBC workgroup of a robot handed on like this must not wait for a flag nobody raises -- the main pass
+                    //  skips the robot, the trailing launch raises none -- but leave it to the WBC pass behind the trailing launch)
+                    if (P.done_flag) __hip_atomic_store(P.done_flag + r2, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             if ((int)blockIdx.x >= cnt) return;
             mpc_solve_robot<MAXB, BIG, NTHR>(P, io, P.pre_list[blockIdx.x], smem);
             return;

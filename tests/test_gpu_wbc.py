@@ -324,6 +324,55 @@ def test_pipelined_tick_with_many_robots_on_the_list_pass(gpu_ctx, pkg, oracle):
     assert np.all(np.abs(out["tau"][ok] - tau[ok]) <= G.tau_tol(tau[ok], 1e-4)), np.abs(out["tau"][ok] - tau[ok]).max()
 
 
+def test_pipelined_tick_with_a_planned_list_longer_than_the_host_saw_it(pkg, oracle):
+    """The planned launch's grid is the host's UNSYNCHRONISED copy of the list's length (plus two): when ticks are queued faster than they run,
+    the list planned by the tick before may be much longer, and the launch's last workgroup hands the remainder to the trailing list launch.
+    In a pipelined tick those robots are solved by nobody who raises a flag -- the main pass skips them, the trailing launch raises none -- so
+    the hand-over itself must tell their WBC workgroups to leave them to the second WBC pass (it did not: they waited out the 4 ms bound and
+    came back flagged QRGPU_ST_PIPE_TIMEOUT: 52 of them in this test).  Eight hard all-stance robots in the batch the host has seen planned, 120
+    in the two queued behind it without a sync; outputs of the last tick against the oracle, nobody timed out, nobody unsolved."""
+    h, n = 10, 512
+    ctx = pkg.Context(0, 1024, 16)
+    try:
+        G.setup_a1(ctx, pkg, h)
+        ctx.set_tick_pipeline(True)
+        trot = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=0.0, frac_three_leg=0.0)
+        stance = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=1.0, frac_three_leg=0.0, excite=2.0)     # (robots that outgrow the main pass)
+        def mix(k):
+            b = {key: (v.copy() if isinstance(v, np.ndarray) else v) for key, v in trot.items()}
+            idx = np.arange(k) * (n // max(k, 1)) + 3
+            for key in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+                b[key][idx] = stance[key][idx]
+            return b
+        few, many = mix(8), mix(120)                 # (5 and 59 of them end up on the planned list: scratch/diag_stale_plan.py)
+        S = pkg.to_soa
+        def upload(b):
+            return dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])),
+                        gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])), fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])))
+        dF, dM = upload(few), upload(many)
+        d_prev = ctx.alloc((3, n)).upload(S(many["prev_ori_vel"]))
+        force, tau, status = ctx.alloc((12, n)), ctx.alloc((12, n)), ctx.alloc((n,), np.int32)
+        def tick(d):
+            ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d_prev, force, tau, status)
+        for _ in range(4):                           # the host has seen a plan of five
+            tick(dF); ctx.sync()
+        d_prev.upload(S(many["prev_ori_vel"]))
+        tau.upload(np.full((12, n), np.nan, np.float32)); status.upload(np.full((n,), 0x7f0000ff, np.int32))
+        tick(dM); tick(dM)                           # no sync in between: the second one's planned launch is sized from a stale length
+        ctx.sync()
+        st_gpu, tau_gpu = status.download(), tau.download().T.copy()
+    finally:
+        ctx.close()
+    assert np.all(G.flags(st_gpu) & 0x02000000 == 0), "a WBC workgroup waited for forces nobody flagged"
+    assert np.all(np.isfinite(tau_gpu))
+    # the second tick's inputs: the same batch, the orientation task's memory as the first tick left it (desiredVel of the command: wbc_cmd[12:15])
+    f, tau_o, st, sec, prev = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), many["mpc_state"], many["traj"], many["gait"],
+                                                many["fb_state"], many["wbc_cmd"], many["wbc_cmd"][:, 12:15].copy(), nthreads=8)
+    ok = (G.flags(st_gpu) == 0) & (st == 0)
+    assert ok.mean() > 0.9
+    assert np.all(np.abs(tau_gpu[ok] - tau_o[ok]) <= G.tau_tol(tau_o[ok], 1e-4)), np.abs(tau_gpu[ok] - tau_o[ok]).max()
+
+
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
     K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
