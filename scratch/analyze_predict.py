@@ -64,3 +64,11 @@ for a in (1.0, 0.5, 0.25):
         if t >= 3: tot.append(span(chunk_order(np.minimum(255, np.floor(ema / 1.7067))), d[t]))
         ema = (1 - a) * ema + a * d[t]
     print("  chunks + 8 bit, a = %.2f: %.1f us" % (a, np.mean(tot)))
+print("risk-averse order: key = ema + k * smoothed |deviation| (global order, no gap); mean span over t = 4..14")
+for k in (0.0, 0.5, 1.0, 1.5, 2.0, 3.0):
+    ema = d[0].copy(); dev = np.zeros(n); tot = []
+    for t in range(1, T):
+        if t >= 4: tot.append(span(np.argsort(-(ema + k * dev)), d[t]))
+        dev = 0.5 * dev + 0.5 * np.abs(d[t] - ema)
+        ema = 0.5 * ema + 0.5 * d[t]
+    print("  k = %.1f: %.1f us" % (k, np.mean(tot)))
