@@ -620,7 +620,7 @@ def main():
         import ctypes as C_
         lib_ = ctx._lib
         lib_.qrgpu_debug_timeline.argtypes = [C_.c_void_p, C_.c_void_p]
-        reset(0)
+        reset(int(os.environ.get("QRGPU_BENCH_TIMELINE_DRAW", "0")) % D)
         for _ in range(12): step()
         fence()
         if lib_.qrgpu_debug_timeline(ctx._h, None) != 0:
@@ -637,6 +637,7 @@ def main():
             rows.append([(a[1] - t0) / 100, (a[2] - t0) / 100, (a[3] - t0) / 100, (a[4] - t0) / 100, (a[5] - t0) / 100, (a[6] - t0) / 100,
                          (a[7] - t0) / 100 if a[7] else float("nan"), (b_[0] - t0) / 100])
         rows = np.array(rows)
+        rows = rows[np.isfinite(rows[:, 0])]
         names = ["last main start", "last solve published", "first WBC workgroup", "last WBC workgroup done", "trailing launch starts", "trailing launch ends",
                  "second WBC pass ends", "NEXT tick's first main workgroup"]
         print("timeline of a pipelined tick (us after its first main-pass workgroup; median / mean over %d ticks):" % len(rows), file=sys.stderr)

@@ -177,6 +177,11 @@ struct WbcPipe {
     unsigned epoch;
     const int *list;
     const int *list_count;
+    const int *gate_abort;      // holds this tick's epoch when the gate in front of the WBC launch gave up waiting for the main pass (a caller with a long
+                                //   queue of its own work in front of the tick): that launch must not run -- it would read its inputs before the caller's
+                                //   stream has produced them and write its outputs before the solves write theirs -- so its workgroups leave at once and the
+                                //   second pass, behind the MPC launches on the context's stream, computes the whole batch: the serial tick.  Or null
+    int second;                 // this launch is the second pass (list / list_count may be null: nothing to do unless the gate gave up)
     int *finished;              // counted up once by either wave of a robot's workgroup when its outputs are in memory (written through): the tick's
                                 //   join is a one-thread launch on the context's stream that waits for 2 n more of these (cumulative, never cleared), or null
     int *tlr;                   // diagnostic: [4][n] per robot, low word of the clock: WBC workgroup started, flag seen, done (last tick only), or null

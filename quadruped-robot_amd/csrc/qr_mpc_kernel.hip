@@ -1934,9 +1934,10 @@ template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);  
 // main pass's thousand workgroups fill every CU first and the listed robot starts 80-160 us late -- which is then the end of the launch.
 // The counter is cumulative and never cleared (`expected_total` is the host's running sum of the grids, compared as a wrapping difference):
 // a workgroup that starts after a gate has timed out is counted where it belongs instead of leaking into the next call's count.
-// `timed_out` (pinned host memory, or null): set to 1 when the wait ends on the clock instead of the counter -- the join of a pipelined tick
-// must not give up silently (qrgpu_tick_batch, qrgpu_sync).
-__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out)
+// `timed_out` (or null): set to `timed_out_value` when the wait ends on the clock instead of the counter -- neither the join of a pipelined tick
+// (a word of pinned host memory: qrgpu_sync reports it) nor the gate of its WBC launch (the tick's epoch in a device word: every robot of
+// that tick is flagged QRGPU_ST_PIPE_TIMEOUT) may give up silently.
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
@@ -1945,7 +1946,7 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
         if (wall_clock64() - t0 >= max_ticks) break;
         __builtin_amdgcn_s_sleep(16);
     }
-    if (timed_out) { *timed_out = 1; __threadfence_system(); }
+    if (timed_out) { *timed_out = timed_out_value; __threadfence_system(); }
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

@@ -683,17 +683,22 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     int rid = xcd_robot_index(blockIdx.x, n);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (pipe.list) {
-        // second pass of a pipelined tick: the robots the trailing MPC list launch has just re-solved (normally none)
-        int cnt = *pipe.list_count;
-        cnt = cnt < n ? cnt : n;
-        if ((int)blockIdx.x >= cnt) return;
-        rid = pipe.list[blockIdx.x];
+    const bool gate_gave_up = pipe.gate_abort && __builtin_amdgcn_readfirstlane(*pipe.gate_abort) == (int)pipe.epoch;
+    if (pipe.second) {
+        // second pass of a pipelined tick: the robots the trailing MPC list launch has just re-solved (normally none) -- or, when the gate of
+        // the first pass gave up, every robot (WbcPipe::gate_abort)
+        if (!gate_gave_up) {
+            int cnt = pipe.list_count ? *pipe.list_count : 0;
+            cnt = cnt < n ? cnt : n;
+            if ((int)blockIdx.x >= cnt) return;
+            rid = pipe.list[blockIdx.x];
+        }
     }
     if (rid < 0) return;
-    if (QW_P_TL && threadIdx.x == 0 && !pipe.list) atomicMin(QW_P_TL + (pipe.epoch & 63u) * 8 + 3, wall_clock64());
-    if (pipe.order && !pipe.list) rid = pipe.order[rid];        // (a permutation inside the XCD chunk: qr_mpc_kernel.hip, finish_order_chunk)
-    if (QW_P_TLR && threadIdx.x == 0 && !pipe.list) QW_P_TLR[rid] = (int)wall_clock64();
+    if (!pipe.second && gate_gave_up) { wbc_signal_done(pipe.finished, lane); return; }
+    if (QW_P_TL && threadIdx.x == 0 && !pipe.second) atomicMin(QW_P_TL + (pipe.epoch & 63u) * 8 + 3, wall_clock64());
+    if (pipe.order && !pipe.second) rid = pipe.order[rid];        // (a permutation inside the XCD chunk: qr_mpc_kernel.hip, finish_order_chunk)
+    if (QW_P_TLR && threadIdx.x == 0 && !pipe.second) QW_P_TLR[rid] = (int)wall_clock64();
     int tyid = type_id ? type_id[rid] : 0;
     const bool bad_type = tyid < 0 || tyid >= QR_MAX_TYPES || !((type_ready >> (tyid & (QR_MAX_TYPES - 1))) & 1);
     if (bad_type) tyid = __builtin_ctz(type_ready | (1 << QR_MAX_TYPES));     // computed with the first valid type, flagged QRGPU_ST_BAD_TYPE
@@ -1332,8 +1337,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, eq_dependent, A, JC, cm, W, sI, g_tau, g_status, merge_tau, status_or | (pipe_st ? 2 : 0), epilogue, dbgT, g_qp,
                      pipe.flag != nullptr, g_prev);
     wbc_signal_done(pipe.finished, lane);
-    if (QW_P_TL && lane == 0) atomicMax(QW_P_TL + (pipe.epoch & 63u) * 8 + (pipe.list ? 7 : 4), wall_clock64());
-    if (QW_P_TLR && lane == 0 && !pipe.list) QW_P_TLR[2 * n + rid] = (int)wall_clock64();
+    if (QW_P_TL && lane == 0) atomicMax(QW_P_TL + (pipe.epoch & 63u) * 8 + (pipe.second ? 7 : 4), wall_clock64());
+    if (QW_P_TLR && lane == 0 && !pipe.second) QW_P_TLR[2 * n + rid] = (int)wall_clock64();
 }
 
 }  // namespace qrgpu

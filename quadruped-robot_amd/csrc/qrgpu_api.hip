@@ -49,7 +49,7 @@ __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *g_in, float *g_out);
-__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out);
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
                                     float *g_vmc_in);
@@ -296,6 +296,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_gate_abort, sizeof(int)) != hipSuccess || hipMemset(c->d_gate_abort, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_wbc_finished, sizeof(int)) != hipSuccess || hipMemset(c->d_wbc_finished, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_ftime, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * (size_t)max_batch) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -344,6 +345,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_main_started) hipFree(c->d_main_started);
     if (c->d_ftime) hipFree(c->d_ftime);
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
+    if (c->d_gate_abort) hipFree(c->d_gate_abort);
     if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);
     if (c->d_tlr) hipFree(c->d_tlr);
@@ -639,7 +641,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
-        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr); HIPCHK(c, hipGetLastError()); }
+        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0); HIPCHK(c, hipGetLastError()); }
     }
     {
         TimerScope ts(c, 0);
@@ -704,7 +706,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr})
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr})
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -714,7 +716,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     if (rc) return rc;
     const hipStream_t ws = stream_override ? stream_override : c->stream;
     {
-        TimerScope ts(c, 1, ws, pipe.list == nullptr);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
+        TimerScope ts(c, 1, ws, !pipe.second);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
         // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
         hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, ws, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
@@ -1053,24 +1055,29 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true);
     if (rc) return rc;
     const int expect = c->main_started_total - pipe_early;          // (launch_mpc has added this tick's main-pass units to main_started_total)
-    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, (long long)1000000, (int *)nullptr);
+    // (bounded at 50 ms; QRGPU_PIPE_GATE_MS for the tests.  A gate that gives up -- the caller had that much work of its own queued in front of
+    //  this tick -- turns the tick into the serial one: WbcPipe::gate_abort)
+    static const long long gate_ticks = [] { const char *e = getenv("QRGPU_PIPE_GATE_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
+    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, gate_ticks, c->d_gate_abort, (int)c->tick_epoch);
     HIPCHK(c, hipGetLastError());
     // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
     // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
     static const int pipe_join = [] { const char *e = getenv("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
-    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in};
+    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr, c->d_gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in};
     rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
                     c->wbc_stream, wp);
     if (rc) return rc;
     if (!pipe_join) HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
-    if (c->last_rescue_active) {
-        WbcPipe lp{nullptr, c->tick_epoch, c->d_rescue + 2, c->d_rescue + c->last_rescue_parity, nullptr, nullptr, c->d_timeline, nullptr};
+    {   // the second pass: the robots of the trailing launch's list (there is one at h <= 11) -- or every robot, should the gate have given up
+        const bool have_list = c->last_rescue_active;
+        WbcPipe lp{nullptr, c->tick_epoch, have_list ? c->d_rescue + 2 : nullptr, have_list ? c->d_rescue + c->last_rescue_parity : nullptr, c->d_gate_abort, 1, nullptr,
+                   nullptr, c->d_timeline, nullptr};
         rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr, nullptr, lp);
         if (rc) return rc;
     }
     if (pipe_join) {
         c->wbc_finished_total += 2 * n;
-        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2);
+        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2, 1);
         HIPCHK(c, hipGetLastError());
     } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
     return QRGPU_OK;

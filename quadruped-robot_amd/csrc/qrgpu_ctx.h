@@ -67,6 +67,7 @@ struct qrgpu_ctx {
     int qhead_parity = 0;
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
+    int *d_gate_abort = nullptr;              // epoch of the pipelined tick whose WBC gate timed out (0: none)
     int *d_wbc_finished = nullptr;            // waves of pipelined WBC launches whose outputs are in memory, ever (the tick's join); never cleared
     int wbc_finished_total = 0;
     int *d_tlr = nullptr;                     // diagnostic: [4][max_batch] per-robot WBC moments of the last pipelined tick

@@ -373,6 +373,53 @@ def test_pipelined_tick_with_a_planned_list_longer_than_the_host_saw_it(pkg, ora
     assert np.all(np.abs(tau_gpu[ok] - tau_o[ok]) <= G.tau_tol(tau_o[ok], 1e-4)), np.abs(tau_gpu[ok] - tau_o[ok]).max()
 
 
+_GATE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+h, n = 10, 256
+ctx = pkg.Context(0, 1024, 16)
+G.setup_a1(ctx, pkg, h)
+b = pkg.make_batch(n, h, "a1", seed=0x6A7E)
+for _ in range(4): ref = G.run_tick(ctx, pkg, b)       # (the first calls of a new batch size end with a stream sync: past those)
+S = pkg.to_soa
+d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+         fb=ctx.alloc((37, n)), cmd=ctx.alloc((67, n)), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
+         force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)), status=ctx.alloc((n,), np.int32).upload(np.full((n,), 0x7f0000ff, np.int32)))
+big = ctx.alloc((1 << 28,))                       # 1 GiB: a zero fill of it is a quarter of a millisecond of the context's stream
+pin_fb = ctx.alloc_pinned((37, n)); pin_fb.array[...] = S(b["fb_state"])
+pin_cmd = ctx.alloc_pinned((67, n)); pin_cmd.array[...] = S(b["wbc_cmd"])
+d["fb"].zero(); d["cmd"].zero()                   # what a WBC launch that ran too early would read
+ctx.sync()
+for _ in range(200):
+    big.zero()
+d["fb"].copy_from_pinned(pin_fb); d["cmd"].copy_from_pinned(pin_cmd)      # the caller's producer, on the context's stream, behind ~50 ms of its other work
+ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"])
+ctx.sync()
+st = d["status"].download(); tau = d["tau"].download().T
+print("result", int((G.flags(st) != 0).sum()), int((G.flags(ref["status"]) != 0).sum()), int(np.isfinite(tau).all()), float(np.abs(tau - ref["tau"]).max()))
+"""
+
+
+def test_wbc_gate_that_gives_up_turns_the_tick_into_the_serial_one(pkg):
+    """The WBC launch of a pipelined tick waits behind a gate for the tick's main pass to be running -- on a stream of its own, without an event
+    from the context's stream -- and that is also what keeps it from reading its inputs before the caller's earlier work on the context's
+    stream has produced them.  The gate's wait is bounded (50 ms).  Should it give up, the launch must not run at all (it would compute from
+    inputs that are not there yet and write its torques before the solves write theirs: round 3 had this hole behind a 10 ms bound): its
+    workgroups leave and the second pass, behind the MPC launches on the context's stream, computes every robot.  A process of its own with the
+    bound at 1 ms (QRGPU_PIPE_GATE_MS), ~50 ms of fills queued in front of the tick, and the WBC's inputs produced by the last copies in that queue."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, QRGPU_PIPE_GATE_MS="1")
+    r = subprocess.run([sys.executable, "-c", _GATE_SCRIPT, here], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [l.split()[1:] for l in r.stdout.strip().splitlines() if l.startswith("result")][0]
+    assert int(res[0]) == 0 and int(res[1]) == 0 and int(res[2]) == 1, res
+    assert float(res[3]) < 2e-4, res              # (the second tick starts from the first one's working sets: the same optimum to the solver's tolerance)
+
+
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
     K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
