@@ -96,6 +96,11 @@ struct MpcLaunch {
     // average, 40 us at worst: scratch/diag_slots.py), and a new workgroup takes 3 us to come up.
     int persist;
     int *qhead, *qhead_next;
+    // The planned launch's own gate (no event from the context's stream: a one-thread launch on the side stream polls a "go" the context's
+    // stream gives when it reaches this call) is bounded; should it give up, it leaves plan_epoch in *plan_abort: the planned workgroups then
+    // leave at once and the main pass solves the robots it would have skipped.  Null: the launch was forked with an event.
+    const int *plan_abort;
+    int plan_epoch;
     long long *tl;              // diagnostic (qrgpu_debug_timeline), or null
     int *ftime;                 // pipelined tick: when each robot's solve raised its flag (low word of the 100 MHz clock) -> the WBC launch's order next tick
     int *wbc_order_out;         // (trailing list launch / qr_lpt_order_kernel) that order, written for the next tick

@@ -1845,6 +1845,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             // striding over a list cannot allow): entry blockIdx.x of the list the last call's planning left.  The grid is the host's
             // unsynchronised copy of the list's length; should the list be longer, the last workgroup hands the remainder to the trailing list
             // launch, and workgroups past the end of a shorter list leave at once.
+            if (P.plan_abort && *P.plan_abort == P.plan_epoch) return;       // its gate gave up: the main pass solves everybody (below)
             int cnt = P.pre_count[P.rescue_parity];
             cnt = cnt < P.n ? cnt : P.n;
             if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list)
@@ -1866,7 +1867,8 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         const int slot = xcd_robot_index(blockIdx.x, P.n);
         if (slot < 0) return;
         const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
-        if (P.skip && P.skip[rid]) return;             // solved by the planned list launch, beside this one
+        // solved by the planned list launch, beside this one -- unless that launch's gate gave up waiting for this one's stream (plan_abort)
+        if (P.skip && P.skip[rid] && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) return;
         mpc_solve_robot<MAXB, BIG, NTHR>(P, io, rid, smem);
     }
 }
@@ -1899,7 +1901,7 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
                     if (k >= len) break;
                     if (P.main_started) atomicAdd(P.main_started, 1);
                     const int r = P.order ? P.order[lo + k] : lo + k;
-                    if (P.skip && P.skip[r]) continue;         // solved by the planned list launch, beside this one
+                    if (P.skip && P.skip[r] && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) continue;         // solved by the planned list launch, beside this one
                     got = r;
                     if (QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 1, wall_clock64());
                     break;
@@ -1937,9 +1939,10 @@ template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);  
 // `timed_out` (or null): set to `timed_out_value` when the wait ends on the clock instead of the counter -- neither the join of a pipelined tick
 // (a word of pinned host memory: qrgpu_sync reports it) nor the gate of its WBC launch (the tick's epoch in a device word: every robot of
 // that tick is flagged QRGPU_ST_PIPE_TIMEOUT) may give up silently.
-__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value)
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value, int *bump)
 {
     if (threadIdx.x != 0) return;
+    if (bump) __hip_atomic_fetch_add(bump, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the "go" of the planned launch's own gate: see qrgpu_api.hip)
     const long long t0 = wall_clock64();
     for (;;) {
         if ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) >= 0) return;

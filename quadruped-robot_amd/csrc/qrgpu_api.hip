@@ -49,7 +49,7 @@ __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
 __global__ void qr_swing_velocity_kernel(int n, EstimatorDesc D, SwingVelDesc V, const float *g_in, float *g_out);
-__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value);
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value, int *bump);
 __global__ void qr_ground_kernel(int n, int fresh, const float *g_in, double *g_st, float *g_out, float *g_est_in);
 __global__ void qr_walk_gait_kernel(int n, WalkDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_ratio,
                                     float *g_vmc_in);
@@ -296,6 +296,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_go, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_go, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_gate_abort, sizeof(int)) != hipSuccess || hipMemset(c->d_gate_abort, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_wbc_finished, sizeof(int)) != hipSuccess || hipMemset(c->d_wbc_finished, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_ftime, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * (size_t)max_batch) != hipSuccess ||
@@ -346,6 +347,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_ftime) hipFree(c->d_ftime);
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
     if (c->d_gate_abort) hipFree(c->d_gate_abort);
+    if (c->d_go) hipFree(c->d_go);
     if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);
     if (c->d_tlr) hipFree(c->d_tlr);
@@ -613,15 +615,32 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
         hipStream_t ls = planned_mode == 1 ? c->stream : c->side_stream;
-        if (planned_mode != 1) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        }
         // QRGPU_PLANNED_WAVES=4: the four-wave list kernel, a workgroup striding over the list (this round's first form)
         static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
-        if (planned_waves == 8 && n <= 2048 && c->h_pre_count[c->rescue_parity] <= c->num_cu / 4) {
+        const bool one_per_wg = planned_waves == 8 && n <= 2048 && c->h_pre_count[c->rescue_parity] <= c->num_cu / 4;
+        // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
+        // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and
+        // the first workgroup of the next main pass on ticks that have a plan, against 2 on ticks that have none (the kernels' stamps).  Instead: a
+        // one-thread launch on the side stream polls a "go" count that the gate in front of the main pass -- a launch on the context's stream --
+        // bumps before it waits for the listed workgroups.  Bounded (50 ms, QRGPU_PLAN_GO_MS); a gate that gives up calls the plan off for
+        // this call (MpcLaunch::plan_abort): nobody runs on inputs the caller's stream has not produced yet.
+        static const int planned_fork = [] { const char *e = getenv("QRGPU_PLANNED_FORK"); return e ? atoi(e) : 0; }();
+        const bool poll_fork = !planned_fork && planned_mode != 1 && gate && one_per_wg;
+        P.plan_abort = nullptr; P.plan_epoch = 0; L.plan_abort = nullptr; L.plan_epoch = 0;
+        if (poll_fork) {
+            static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
+            ++c->go_total;
+            if (++c->plan_epoch >= 0x7fffffff) c->plan_epoch = 1;
+            P.plan_abort = c->d_go + 1; P.plan_epoch = c->plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->side_stream, c->d_go, c->go_total, go_ticks, c->d_go + 1, c->plan_epoch, (int *)nullptr);
+            HIPCHK(c, hipGetLastError());
+        } else if (planned_mode != 1) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        }
+        if (one_per_wg) {
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
             // hands a longer list's tail to the trailing launch)
             L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
@@ -641,7 +660,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
-        if (gate && gate_expect > 0) { hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0); HIPCHK(c, hipGetLastError()); }
+        if (gate && gate_expect > 0) {
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, poll_fork ? c->d_go : (int *)nullptr);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     {
         TimerScope ts(c, 0);
@@ -1058,7 +1080,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (bounded at 50 ms; QRGPU_PIPE_GATE_MS for the tests.  A gate that gives up -- the caller had that much work of its own queued in front of
     //  this tick -- turns the tick into the serial one: WbcPipe::gate_abort)
     static const long long gate_ticks = [] { const char *e = getenv("QRGPU_PIPE_GATE_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, gate_ticks, c->d_gate_abort, (int)c->tick_epoch);
+    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, gate_ticks, c->d_gate_abort, (int)c->tick_epoch, (int *)nullptr);
     HIPCHK(c, hipGetLastError());
     // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
     // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
@@ -1077,7 +1099,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     }
     if (pipe_join) {
         c->wbc_finished_total += 2 * n;
-        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2, 1);
+        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2, 1, (int *)nullptr);
         HIPCHK(c, hipGetLastError());
     } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
     return QRGPU_OK;
@@ -1235,12 +1257,16 @@ int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to di
     return QRGPU_OK;
 }
 
-int qrgpu_debug_lists(qrgpu_ctx *c, int *host_out /* [4]: rescue list lengths (both parities), planned list lengths (both parities) */)
-{   // undocumented diagnostic: how many robots the last MPC launches handed to the trailing list launch / planned for the next call
+int qrgpu_debug_lists(qrgpu_ctx *c, int *host_out /* [8]: rescue list lengths (both parities), planned list lengths (both parities), "go" count and the
+                                                      plan epoch of a planned launch whose gate gave up, the tick epoch of a WBC gate that gave up, the context's plan epoch */)
+{   // undocumented diagnostic: how many robots the last MPC launches handed to the trailing list launch / planned for the next call; which gates gave up
     if (!c || !host_out) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(host_out, c->d_rescue, 2 * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(host_out + 2, c->d_pre, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out + 4, c->d_go, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out + 6, c->d_gate_abort, sizeof(int), hipMemcpyDeviceToHost));
+    host_out[7] = c->plan_epoch;
     return QRGPU_OK;
 }
 

@@ -67,6 +67,8 @@ struct qrgpu_ctx {
     int qhead_parity = 0;
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
+    int *d_go = nullptr;                      // [2]: [0] "go" count of the planned launches' gates (cumulative), [1] plan epoch of a gate that gave up
+    int go_total = 0, plan_epoch = 0;
     int *d_gate_abort = nullptr;              // epoch of the pipelined tick whose WBC gate timed out (0: none)
     int *d_wbc_finished = nullptr;            // waves of pipelined WBC launches whose outputs are in memory, ever (the tick's join); never cleared
     int wbc_finished_total = 0;

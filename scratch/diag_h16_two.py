@@ -26,7 +26,7 @@ tid = pkg.shard.interleave_types(n, 2)
 for t, k in enumerate(list(range(8)) + [6, 5, 4]):
     out = G.run_mpc(ctx, pkg, seq[k], type_id=tid)
     buf = np.zeros((n, 16), np.int64); lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, n)
-    cnt = np.zeros(4, np.int32); lib.qrgpu_debug_lists(ctx._h, cnt.ctypes.data)
+    cnt = np.zeros(8, np.int32); lib.qrgpu_debug_lists(ctx._h, cnt.ctypes.data)
     t0, t1 = buf[:, 12] / 100.0, buf[:, 13] / 100.0
     base = t0.min(); t0 -= base; t1 -= base
     d = t1 - t0; q = buf[:, 14]; nls = buf[:, 7] // 3

@@ -30,7 +30,7 @@ has = hasattr(lib, "qrgpu_debug_lists")
 def lists():
     if not has: return None
     lib.qrgpu_debug_lists.argtypes = [C.c_void_p, C.c_void_p]
-    c = np.zeros(4, np.int32); lib.qrgpu_debug_lists(ctx._h, c.ctypes.data); return c.tolist()
+    c = np.zeros(8, np.int32); lib.qrgpu_debug_lists(ctx._h, c.ctypes.data); return c.tolist()
 for i in range(4):
     tick(dF); ctx.sync(); print("few tick", i, "lists", lists())
 t0 = time.perf_counter()

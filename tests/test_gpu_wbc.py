@@ -420,6 +420,63 @@ def test_wbc_gate_that_gives_up_turns_the_tick_into_the_serial_one(pkg):
     assert float(res[3]) < 2e-4, res              # (the second tick starts from the first one's working sets: the same optimum to the solver's tolerance)
 
 
+_PLAN_GO_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+h, n = 10, 512
+ctx = pkg.Context(0, 1024, 16)
+G.setup_a1(ctx, pkg, h)
+trot = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=0.0, frac_three_leg=0.0)
+stance = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=1.0, frac_three_leg=0.0, excite=2.0)
+b = {key: (v.copy() if isinstance(v, np.ndarray) else v) for key, v in trot.items()}
+idx = np.arange(24) * (n // 24) + 3
+for key in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+    b[key][idx] = stance[key][idx]
+S = pkg.to_soa
+d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+         fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
+         force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
+def tick():
+    ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"])
+for _ in range(5):                                # a plan exists and the host has seen its length
+    tick(); ctx.sync()
+ref_tau, ref_st = d["tau"].download().T.copy(), d["status"].download()
+big = ctx.alloc((1 << 28,))
+pin = ctx.alloc_pinned((28, n)); pin.array[...] = S(b["mpc_state"])
+d["state"].zero()                                 # what a planned launch that ran too early would read
+d["tau"].upload(np.full((12, n), np.nan, np.float32)); d["status"].upload(np.full((n,), 0x7f0000ff, np.int32))
+ctx.sync()
+for _ in range(200):
+    big.zero()
+d["state"].copy_from_pinned(pin)                  # the caller's producer, behind ~30 ms of its other work on the context's stream
+tick(); ctx.sync()
+st, tau = d["status"].download(), d["tau"].download().T
+import ctypes as C
+lists = np.zeros(8, np.int32); ctx._lib.qrgpu_debug_lists.argtypes = [C.c_void_p, C.c_void_p]; ctx._lib.qrgpu_debug_lists(ctx._h, lists.ctypes.data)
+print("result", int((G.flags(st) != G.flags(ref_st)).sum()), int(np.isfinite(tau).all()), float(np.abs(tau - ref_tau).max()), int(lists[5] == lists[7] and lists[7] > 0), int(lists[6] != 0))
+"""
+
+
+def test_planned_launch_whose_go_never_comes_is_called_off(pkg):
+    """The planned launch (listed robots on whole CUs beside the main pass) is released by a "go" that the context's stream gives when it reaches
+    the call -- polled by a one-thread launch on the side stream, bounded.  Should that gate give up (the caller had more work queued in front of
+    the call than the bound), the planned workgroups must not run on inputs that are not there yet: they leave, and the main pass solves the
+    robots it would have skipped.  A process of its own with the bound at 1 ms (QRGPU_PLAN_GO_MS; the WBC gate's too), ~30 ms of fills queued in
+    front of the tick and the MPC's state array produced by the last copy in that queue."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, QRGPU_PLAN_GO_MS="1", QRGPU_PIPE_GATE_MS="1")
+    r = subprocess.run([sys.executable, "-c", _PLAN_GO_SCRIPT, here], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [l.split()[1:] for l in r.stdout.strip().splitlines() if l.startswith("result")][0]
+    assert int(res[0]) == 0 and int(res[1]) == 1, res
+    assert float(res[2]) < 2e-4, res
+    assert int(res[3]) == 1 and int(res[4]) == 1, res          # (both gates did give up in that tick: the plan was called off, the WBC ran as the second pass)
+
+
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
     K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
