@@ -101,6 +101,11 @@ struct MpcLaunch {
     // leave at once and the main pass solves the robots it would have skipped.  Null: the launch was forked with an event.
     const int *plan_abort;
     int plan_epoch;
+    // Pipelined tick: the trailing list launch does not wait for the planned launch through a stream event (8 us between the main pass and the
+    // trailing launch even when the planned launch has long finished) but polls this count -- every workgroup of the planned launch bumps it
+    // once, behind its written-through stores -- until planned_expect (cumulative, the host's running total).  Null: an event joins the streams.
+    int *planned_done;
+    int planned_expect;
     long long *tl;              // diagnostic (qrgpu_debug_timeline), or null
     int *ftime;                 // pipelined tick: when each robot's solve raised its flag (low word of the 100 MHz clock) -> the WBC launch's order next tick
     int *wbc_order_out;         // (trailing list launch / qr_lpt_order_kernel) that order, written for the next tick

@@ -1761,7 +1761,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (qcm > 64) qcm = 64;
                 big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
             }
-            P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16);
+            if (P.planned_done) __hip_atomic_store(P.cost + rid, (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16);
         }
         QR_TS(6);
 #if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
@@ -1804,6 +1805,15 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         if (LIST && P.rescue_mode == 1) atomicMin(tl + 5, t);
     }
     if constexpr (LIST) {
+        if (P.rescue_mode == 1 && P.planned_done) {
+            // the planned launch beside the main pass must be through before its robots' costs are sorted and its hand-overs re-solved
+            if (threadIdx.x == 0) {
+                const long long t0 = wall_clock64();
+                while ((int)((unsigned)__hip_atomic_load(P.planned_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)P.planned_expect) < 0 && wall_clock64() - t0 < 2000000)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
         const bool planned = P.rescue_mode == 2;
         if (!planned && blockIdx.x < 8) {
             if (P.lpt_order_out) {                     // the histogram borrows the head of the dynamic LDS before a solve carves it
@@ -1845,19 +1855,29 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             // striding over a list cannot allow): entry blockIdx.x of the list the last call's planning left.  The grid is the host's
             // unsynchronised copy of the list's length; should the list be longer, the last workgroup hands the remainder to the trailing list
             // launch, and workgroups past the end of a shorter list leave at once.
-            if (P.plan_abort && *P.plan_abort == P.plan_epoch) return;       // its gate gave up: the main pass solves everybody (below)
+            // (every workgroup of this launch tells the trailing launch when it is done -- planned_done -- whichever way it leaves)
+            auto tell_done = [&]() {
+                if (P.planned_done && threadIdx.x < 64) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (threadIdx.x == 0) __hip_atomic_fetch_add(P.planned_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            if (P.plan_abort && *P.plan_abort == P.plan_epoch) { tell_done(); return; }       // its gate gave up: the main pass solves everybody (below)
             int cnt = P.pre_count[P.rescue_parity];
             cnt = cnt < P.n ? cnt : P.n;
-            if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list)
+            if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list) {
                 for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) {
                     const int r2 = P.pre_list[e2];
-                    P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = r2;
+                    __hip_atomic_store(P.rescue_list + atomicAdd(P.rescue_count + P.rescue_parity, 1), r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // (pipelined tick: the WBC workgroup of a robot handed on like this must not wait for a flag nobody raises -- the main pass
                     //  skips the robot, the trailing launch raises none -- but leave it to the WBC pass behind the trailing launch)
                     if (P.done_flag) __hip_atomic_store(P.done_flag + r2, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            if ((int)blockIdx.x >= cnt) return;
+                __syncthreads();                       // (every wave's hand-over stores are out before wave 0 can tell anybody)
+            }
+            if ((int)blockIdx.x >= cnt) { tell_done(); return; }
             mpc_solve_robot<MAXB, BIG, NTHR>(P, io, P.pre_list[blockIdx.x], smem);
+            tell_done();                               // (wave 0 is the last to return from the solve and the one that stored its results)
             return;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters

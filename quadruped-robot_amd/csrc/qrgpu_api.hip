@@ -296,6 +296,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_planned_done, sizeof(int)) != hipSuccess || hipMemset(c->d_planned_done, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_go, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_go, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_gate_abort, sizeof(int)) != hipSuccess || hipMemset(c->d_gate_abort, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_wbc_finished, sizeof(int)) != hipSuccess || hipMemset(c->d_wbc_finished, 0, sizeof(int)) != hipSuccess ||
@@ -348,6 +349,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
     if (c->d_gate_abort) hipFree(c->d_gate_abort);
     if (c->d_go) hipFree(c->d_go);
+    if (c->d_planned_done) hipFree(c->d_planned_done);
     if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);
     if (c->d_tlr) hipFree(c->d_tlr);
@@ -600,6 +602,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
     // workgroups (each needs a whole CU's LDS) are dispatched first, the main pass's fill the rest of the machine
     static const int planned_mode = [] { const char *e = getenv("QRGPU_PLANNED_MODE"); return e ? atoi(e) : 0; }();
+    bool poll_join = false;
+    P.planned_done = nullptr; P.planned_expect = 0;
     if (have_plan) {
         // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
         P.skip = c->d_skip;
@@ -629,6 +633,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         static const int planned_fork = [] { const char *e = getenv("QRGPU_PLANNED_FORK"); return e ? atoi(e) : 0; }();
         const bool poll_fork = !planned_fork && planned_mode != 1 && gate && one_per_wg;
         P.plan_abort = nullptr; P.plan_epoch = 0; L.plan_abort = nullptr; L.plan_epoch = 0;
+        // ... and, in a pipelined tick, how the trailing launch learns that the planned launch is through (MpcLaunch::planned_done); QRGPU_PLANNED_JOIN=1: an event
+        static const int planned_join = [] { const char *e = getenv("QRGPU_PLANNED_JOIN"); return e ? atoi(e) : 0; }();
+        poll_join = poll_fork && piped && !planned_join;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
             ++c->go_total;
@@ -648,17 +655,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
             g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
             { const int rc_ = mpc_ensure_lds(c, one_var, fl, c->lds_per_cu); if (rc_) return rc_; }
+            if (poll_join) { c->planned_done_total += g3; L.planned_done = c->d_planned_done; }       // (every workgroup of the launch bumps it once)
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(one_var, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
             c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
+
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
-        if (planned_mode != 1) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
         if (gate && gate_expect > 0) {
             hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, poll_fork ? c->d_go : (int *)nullptr);
@@ -674,12 +683,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
-    if (have_plan && planned_mode != 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (rescue) {
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
         R.persist = 0; R.qhead = nullptr; R.qhead_next = nullptr;
+        R.planned_done = poll_join ? c->d_planned_done : nullptr; R.planned_expect = c->planned_done_total;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.done_flag = nullptr; R.main_started = nullptr;      // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass)
         R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)

@@ -69,6 +69,8 @@ struct qrgpu_ctx {
     int main_slots_lds[16][2] = {};
     int *d_go = nullptr;                      // [2]: [0] "go" count of the planned launches' gates (cumulative), [1] plan epoch of a gate that gave up
     int go_total = 0, plan_epoch = 0;
+    int *d_planned_done = nullptr;            // workgroups of planned launches that are through, ever (polled by the trailing launch of a pipelined tick)
+    int planned_done_total = 0;
     int *d_gate_abort = nullptr;              // epoch of the pipelined tick whose WBC gate timed out (0: none)
     int *d_wbc_finished = nullptr;            // waves of pipelined WBC launches whose outputs are in memory, ever (the tick's join); never cleared
     int wbc_finished_total = 0;
