@@ -373,6 +373,46 @@ def test_pipelined_tick_with_a_planned_list_longer_than_the_host_saw_it(pkg, ora
     assert np.all(np.abs(tau_gpu[ok] - tau_o[ok]) <= G.tau_tol(tau_o[ok], 1e-4)), np.abs(tau_gpu[ok] - tau_o[ok]).max()
 
 
+def test_pipelined_ticks_queued_without_a_sync_match_the_serial_ticks(pkg):
+    """A dozen ticks of a temporally coherent sequence queued back to back with no host sync in between -- how `bench.py` and a simulator's step
+    loop drive the library -- on the pipelined form, against the same sequence on the serial form with a sync after every tick.  The host then
+    sizes the planned launches from list lengths several ticks old, the gates, the polled "go" and both polled joins all run against a GPU
+    that is behind the host, and robots move between the main pass, the planned launch and the trailing launch from tick to tick (which changes
+    the last bits of a solve: the comparison is at the solver's tolerance, not bitwise).  Every tick's outputs in buffers of their own."""
+    h, n, T = 10, 512, 12
+    seq = pkg.make_batch_sequence(n, h, "a1", seed=0x7E57, steps=T, frac_all_stance=0.25, excite=1.5)
+    S = pkg.to_soa
+    res = {}
+    for piped in (False, True):
+        ctx = pkg.Context(0, 1024, 16)
+        try:
+            G.setup_a1(ctx, pkg, h)
+            ctx.set_tick_pipeline(piped)
+            ctx.set_torque_epilogue(hip_comp=True, clip=True)
+            d_prev = ctx.alloc((3, n)).upload(S(seq[0]["prev_ori_vel"]))
+            ins = [dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+                        fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"]))) for b in seq]
+            outs = [dict(force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)),
+                         status=ctx.alloc((n,), np.int32).upload(np.full((n,), 0x7f0000ff, np.int32)), qdes=ctx.alloc((24, n))) for _ in seq]
+            ctx.sync()
+            for i, o in zip(ins, outs):
+                ctx.tick_batch(n, i["state"], i["traj"], i["gait"], i["fb"], i["cmd"], d_prev, o["force"], o["tau"], o["status"], qdes=o["qdes"])
+                if not piped:
+                    ctx.sync()
+            ctx.sync()
+            res[piped] = [dict(tau=o["tau"].download().T.copy(), status=o["status"].download(), qdes=o["qdes"].download().T.copy()) for o in outs]
+        finally:
+            ctx.close()
+    for k, (a, b_) in enumerate(zip(res[False], res[True])):
+        assert np.all(G.flags(b_["status"]) & 0x02000000 == 0), k
+        assert np.all(np.isfinite(b_["tau"])), k
+        assert np.array_equal(G.flags(a["status"]), G.flags(b_["status"])), k
+        ok = G.flags(a["status"]) == 0
+        assert ok.mean() > 0.9
+        assert np.all(np.abs(a["tau"][ok] - b_["tau"][ok]) <= G.tau_tol(a["tau"][ok], 1e-4)), (k, np.abs(a["tau"][ok] - b_["tau"][ok]).max())
+        assert np.abs(a["qdes"][ok] - b_["qdes"][ok]).max() < 1e-5, k
+
+
 _GATE_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
