@@ -12,6 +12,9 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 echo stats done
 # the counter passes time one kernel at a time: the serial tick (QRGPU_TICK_PIPELINE=0), so that no launch shares the machine with another
 export QRGPU_TICK_PIPELINE=0
+# (counter collection runs one kernel at a time: a gate that polls for another launch's progress would wait out its bound -- 50 ms, then the plan is
+#  called off and the planned launch's workgroups leave at once -- so the planned launch is forked with an event here, as in rounds 1-2)
+export QRGPU_PLANNED_FORK=1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES"; do
   i=$((i+1))

@@ -33,7 +33,7 @@ out = {"commit": commit,
 for k, v in summ.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         e = {"hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "read_bytes": 2 * v["FETCH_SIZE"] * 1024.0, "written_bytes": v["WRITE_SIZE"] * 1024.0}
-        if "SQ_LDS_BANK_CONFLICT" in v and "SQ_INSTS_LDS" in v: e["lds_bank_conflict_cycles_per_lds_instruction"] = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_INSTS_LDS"]
+        if "SQ_LDS_BANK_CONFLICT" in v and v.get("SQ_INSTS_LDS", 0) > 0: e["lds_bank_conflict_cycles_per_lds_instruction"] = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_INSTS_LDS"]
         if "SQ_LDS_BANK_CONFLICT" in v and "SQ_LDS_IDX_ACTIVE" in v: e["lds_bank_conflict_share_of_lds_active_cycles"] = v["SQ_LDS_BANK_CONFLICT"] / max(1.0, v["SQ_LDS_IDX_ACTIVE"])
         out["kernels"][NAMES.get(k, k)] = e
 json.dump(out, open("profiles/%s_pmc_summary.json" % pre, "w"), indent=1)
