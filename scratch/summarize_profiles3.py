@@ -27,7 +27,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
 commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
 out = {"commit": commit,
        "recipe": "scratch/gpu_round3.sh: rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-side, one run per "
-                 "counter group, serial tick (QRGPU_TICK_PIPELINE=0); 1024 robots per launch; mean over the launches of a run",
+                 "counter group, serial tick (QRGPU_TICK_PIPELINE=0) with the planned launch forked by an event (QRGPU_PLANNED_FORK=1: counter collection runs one kernel at a time); 1024 robots per launch; mean over the launches of a run",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
        "counters": summ, "kernels": {}}
 for k, v in summ.items():
