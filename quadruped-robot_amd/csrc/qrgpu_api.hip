@@ -349,6 +349,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
     if (c->d_gate_abort) hipFree(c->d_gate_abort);
     if (c->d_go) hipFree(c->d_go);
+    if (c->d_gather_done) hipFree(c->d_gather_done);
     if (c->d_planned_done) hipFree(c->d_planned_done);
     if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);

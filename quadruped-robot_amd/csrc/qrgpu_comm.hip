@@ -11,11 +11,26 @@
 // ============================================================================
 #include <dlfcn.h>
 #include <cstring>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 #include "qrgpu_ctx.h"
 
+namespace qrgpu {
+__global__ void qr_gate_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int timed_out_value, int *bump);   // qr_mpc_kernel.hip
+}
+
 namespace {
+
+// The compute stream's wait for a gather (qrgpu_allgather_fence) is a one-thread launch that polls a count bumped by a one-thread launch behind
+// the gather on the communication stream, not a stream event: a wait for an event of another stream costs the waiting stream 5-8 us on this
+// pool even when the event has long happened (the same finding as for the tick's own streams), and the fence sits in
+// front of every tick of a multi-rank run.  QRGPU_COMM_EVENTS=1: the event form.
+bool comm_polls()
+{
+    static const int ev = [] { const char *e = getenv("QRGPU_COMM_EVENTS"); return e ? atoi(e) : 0; }();
+    return ev == 0;
+}
 
 struct Rccl {
     void *handle = nullptr;
@@ -66,6 +81,11 @@ int ensure_comm_stream(qrgpu_ctx *c)
     HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_tick, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_gather[i], hipEventDisableTiming));
+    if (!c->d_gather_done) {
+        HIPCHK(c, hipMalloc(&c->d_gather_done, 2 * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_gather_done, 0, 2 * sizeof(int)));
+        c->gather_total[0] = c->gather_total[1] = 0;
+    }
     return QRGPU_OK;
 }
 
@@ -142,6 +162,13 @@ int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n
     NCCLCHK(c, R, R->AllGather(d_tau, d_tau_all, (size_t)12 * (size_t)n_local, ncclFloat, comm, c->comm_stream));
     // ... and whoever overwrites d_tau (buffer `slot`) later fences on this event
     HIPCHK(c, hipEventRecord(c->ev_gather[slot], c->comm_stream));
+    if (comm_polls()) {
+        // (one thread behind the gather on its stream: bumps the slot's count -- and, the count being what it then expects, leaves at once)
+        ++c->gather_total[slot];
+        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_gather_done + slot, c->gather_total[slot], (long long)0, (int *)nullptr, 0,
+                           c->d_gather_done + slot);
+        HIPCHK(c, hipGetLastError());
+    }
     c->ev_gather_pending[slot] = true;
     return QRGPU_OK;
 }
@@ -156,7 +183,13 @@ int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
     const hipError_t q = hipEventQuery(c->ev_gather[slot]);
     if (q != hipSuccess) {
         (void)hipGetLastError();
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
+        if (comm_polls()) {
+            // bounded (200 ms: a gather that has not finished two ticks later is a hung collective; the stream then goes on and the next
+            // qrgpu_sync / qrgpu_comm_sync is where that shows)
+            hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gather_done + slot, c->gather_total[slot], (long long)20000000, (int *)nullptr, 0,
+                               (int *)nullptr);
+            HIPCHK(c, hipGetLastError());
+        } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
     }
     c->ev_gather_pending[slot] = false;
     return QRGPU_OK;

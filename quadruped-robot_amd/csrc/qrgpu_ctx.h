@@ -67,6 +67,8 @@ struct qrgpu_ctx {
     int qhead_parity = 0;
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
+    int *d_gather_done = nullptr;             // [2] gathers finished per source-buffer slot, ever (qrgpu_allgather_fence polls it)
+    int gather_total[2] = {0, 0};
     int *d_go = nullptr;                      // [2]: [0] "go" count of the planned launches' gates (cumulative), [1] plan epoch of a gate that gave up
     int go_total = 0, plan_epoch = 0;
     int *d_planned_done = nullptr;            // workgroups of planned launches that are through, ever (polled by the trailing launch of a pipelined tick)

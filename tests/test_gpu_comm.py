@@ -52,6 +52,31 @@ def test_allgather_tau_single_rank(pkg, oracle):
         ctx.sync()                                                   # compute stream only
         assert np.array_equal(tau_all.download()[0], tau[1].download())
         ctx.allgather_fence(1)
+        # ten ticks queued with no host sync in between (the host far ahead of the GPU: every fence finds its gather still pending and has to
+        # make the compute stream wait for it), two batches alternating so that an overwritten source buffer would show in the gathered copy
+        b2 = pkg.make_batch(n, h, "a1", seed=32)
+        d2 = dict(state=ctx.alloc((28, n)).upload(S(b2["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b2["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b2["gait"])),
+                  fb=ctx.alloc((37, n)).upload(S(b2["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b2["wbc_cmd"])))
+        alls = [ctx.alloc((1, 12, n)).upload(np.full((1, 12, n), np.nan, np.float32)) for _ in range(10)]
+        pin_prev = ctx.alloc_pinned((3, n)); pin_prev.array[...] = S(b["prev_ori_vel"])
+        ctx.sync()
+        with G.cold_start(ctx):                                   # (no warm start, no planned list, the orientation task's memory put back before every tick:
+            for i in range(10):                                   #  a tick on a batch then gives the same bits whatever ran before it)
+                slot = i & 1
+                src = d if i % 3 else d2
+                ctx.allgather_fence(slot)
+                d["prev"].copy_from_pinned(pin_prev)
+                ctx.tick_batch(n, src["state"], src["traj"], src["gait"], src["fb"], src["cmd"], d["prev"], d["force"], tau[slot], d["status"])
+                ctx.allgather_tau(tau[slot], n, alls[i], slot)
+            ctx.comm_sync()
+            ctx.sync()
+        ga = [a.download()[0] for a in alls]
+        assert all(np.all(np.isfinite(g)) for g in ga)
+        assert np.array_equal(ga[9], tau[1].download()) and np.array_equal(ga[8], tau[0].download())
+        for i in range(10):                                       # every gathered copy is its own tick's torques
+            for j in range(i + 1, 10):
+                same = (i % 3 == 0) == (j % 3 == 0)
+                assert np.array_equal(ga[i], ga[j]) if same else (np.abs(ga[i] - ga[j]).max() > 0.5), (i, j)
         ctx.comm_destroy()
         with pytest.raises(pkg.QrgpuError, match="NOT_SETUP"):
             ctx.allgather_tau(tau[0], n, tau_all, 0)
