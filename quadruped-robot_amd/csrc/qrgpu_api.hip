@@ -637,11 +637,23 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // ... and, in a pipelined tick, how the trailing launch learns that the planned launch is through (MpcLaunch::planned_done); QRGPU_PLANNED_JOIN=1: an event
         static const int planned_join = [] { const char *e = getenv("QRGPU_PLANNED_JOIN"); return e ? atoi(e) : 0; }();
         poll_join = poll_fork && piped && !planned_join;
+        // grid of the one-robot-per-workgroup launch: the list's length as the host last saw it, plus two (below)
+        static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
+        int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
+        g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
+        bool main_gate_queued = false;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
             ++c->go_total;
             if (++c->plan_epoch >= 0x7fffffff) c->plan_epoch = 1;
             P.plan_abort = c->d_go + 1; P.plan_epoch = c->plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
+            // The gate in front of the main pass -- it gives the "go" -- is queued BEFORE the launch that polls for it: should the two streams
+            // ever share a hardware queue (more streams in the process than the device has queues), a poller queued in front of what it polls for
+            // would sit out its whole bound; this way round the worst case is the 30 us of the main pass's own gate.
+            c->started_total += g3;
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, c->d_go);
+            HIPCHK(c, hipGetLastError());
+            main_gate_queued = true;
             hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->side_stream, c->d_go, c->go_total, go_ticks, c->d_go + 1, c->plan_epoch, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else if (planned_mode != 1) {
@@ -652,15 +664,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
             // hands a longer list's tail to the trailing launch)
             L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
-            static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
-            int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
-            g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
             { const int rc_ = mpc_ensure_lds(c, one_var, fl, c->lds_per_cu); if (rc_) return rc_; }
             if (poll_join) { c->planned_done_total += g3; L.planned_done = c->d_planned_done; }       // (every workgroup of the launch bumps it once)
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(one_var, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
-            c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
+            if (!main_gate_queued) c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
 
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
@@ -670,8 +679,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipGetLastError());
         if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
-        if (gate && gate_expect > 0) {
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, poll_fork ? c->d_go : (int *)nullptr);
+        if (gate && gate_expect > 0 && !main_gate_queued) {
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         }
     }
