@@ -550,7 +550,7 @@ def main():
                 dist.all_gather(parts, torch.from_numpy(tau.download()))
                 d_tau_all.upload(torch.stack(parts).numpy())
             else:
-                ctx.allgather_tau(tau, n, d_tau_all, slot)     # RCCL over xGMI on the context's own stream: the only exchange of the path
+                ctx.allgather_tau(tau, n, d_tau_all, slot, of_tick=(args.mode == "tick"))     # RCCL over xGMI on the context's own stream: the only exchange of the path
 
     def fence():
         if world > 1:

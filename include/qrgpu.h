@@ -406,6 +406,11 @@ int qrgpu_comm_info(const qrgpu_ctx *ctx, int *nranks, int *rank);
 int qrgpu_comm_destroy(qrgpu_ctx *ctx);
 int qrgpu_allgather_tau(qrgpu_ctx *ctx, void *nccl_comm /* ncclComm_t, or NULL = the context's */, const float *d_tau /* [12][n_local] */,
                         int n_local, float *d_tau_all /* [nranks][12][n_local] */, int slot);
+/* The same for the torque array that the context's most recent qrgpu_tick_batch produced, when nothing the caller has queued on the context's
+ * stream since writes it: the gather then waits for THAT TICK to be complete (its join bumps a count the communication stream polls) instead of for
+ * an event of the context's stream -- recording one costs that stream several microseconds a tick.  Falls back to qrgpu_allgather_tau's form when
+ * the last tick was not a pipelined one (fewer than 64 robots, qrgpu_set_tick_pipeline off, a stream under graph capture). */
+int qrgpu_allgather_tau_of_tick(qrgpu_ctx *ctx, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot);
 int qrgpu_allgather_fence(qrgpu_ctx *ctx, int slot);
 int qrgpu_allgather_wait(qrgpu_ctx *ctx, int slot);
 int qrgpu_comm_sync(qrgpu_ctx *ctx);

@@ -1972,6 +1972,27 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
     if (timed_out) { *timed_out = timed_out_value; __threadfence_system(); }
 }
 
+// The join of a pipelined tick: waits for the WBC launch's waves (counter / expected_total, as qr_gate_kernel) and, while it is at it, for the
+// all-gathers queued before the tick (g0 / e0, g1 / e1: the counts qrgpu_allgather_tau's one-thread launches bump behind each gather, per
+// source-buffer slot; null when the context has no communicator) -- they were queued a whole tick ago, so this costs the tick nothing, and the
+// fence in front of the next tick (qrgpu_allgather_fence) finds its gather already waited for and queues no launch of its own.
+// `tick_done` (or null) is bumped once the waits are over: the tick is complete in stream order -- the second WBC pass is ahead of this launch on
+// the stream -- which is what the all-gather of its torques polls for (qrgpu_allgather_tau_of_tick).
+__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = (int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) >= 0;
+        if (ok && g0) ok = (int)((unsigned)__hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e0) >= 0;
+        if (ok && g1) ok = (int)((unsigned)__hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e1) >= 0;
+        if (ok) { if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (wall_clock64() - t0 >= max_ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (timed_out) { *timed_out = 1; __threadfence_system(); }
+}
+
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.
 __global__ void qr_selftest_kernel(double *out)
 {

@@ -45,6 +45,7 @@ extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch,
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, MpcIO);
+__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -296,6 +297,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
         hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_tick_done, sizeof(int)) != hipSuccess || hipMemset(c->d_tick_done, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_planned_done, sizeof(int)) != hipSuccess || hipMemset(c->d_planned_done, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_go, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_go, 0, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_gate_abort, sizeof(int)) != hipSuccess || hipMemset(c->d_gate_abort, 0, sizeof(int)) != hipSuccess ||
@@ -350,6 +352,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_gate_abort) hipFree(c->d_gate_abort);
     if (c->d_go) hipFree(c->d_go);
     if (c->d_gather_done) hipFree(c->d_gather_done);
+    if (c->d_tick_done) hipFree(c->d_tick_done);
     if (c->d_planned_done) hipFree(c->d_planned_done);
     if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);
@@ -1064,6 +1067,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
     float *const force = d_force ? d_force : c->d_cmd_tick;
     static const int pipe_env = [] { const char *e = getenv("QRGPU_TICK_PIPELINE"); return e ? atoi(e) : 1; }();
+    c->last_tick_piped = false;
     bool piped = c->pipeline && pipe_env != 0 && n >= 64 && !c->d_dbg_cycles && !c->d_dbg_cycles_wbc;
     if (piped) {         // (not while the stream is being captured into a graph: the WBC launch lives on a stream of the context's own)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1119,8 +1123,13 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     }
     if (pipe_join) {
         c->wbc_finished_total += 2 * n;
-        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2, 1, (int *)nullptr);
+        // (... and for the all-gathers queued before this tick, so that the fence in front of the next tick need not queue a launch: qr_join_kernel)
+        int *g0 = c->d_gather_done, *g1 = c->d_gather_done ? c->d_gather_done + 1 : nullptr;
+        hipLaunchKernelGGL(qr_join_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2,
+                           g0, c->gather_total[0], g1, c->gather_total[1], c->d_tick_done);
         HIPCHK(c, hipGetLastError());
+        c->gather_joined[0] = c->gather_total[0]; c->gather_joined[1] = c->gather_total[1];
+        ++c->tick_done_total; c->last_tick_piped = true;
     } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
     return QRGPU_OK;
 }

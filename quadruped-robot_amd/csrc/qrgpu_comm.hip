@@ -146,7 +146,7 @@ int qrgpu_comm_info(const qrgpu_ctx *c, int *nranks, int *rank)
     return QRGPU_OK;
 }
 
-int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot)
+static int allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot, bool after_tick)
 {
     if (!c || !d_tau || !d_tau_all || n_local <= 0 || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
     ncclComm_t comm = nccl_comm ? (ncclComm_t)nccl_comm : (ncclComm_t)c->comm;
@@ -157,8 +157,17 @@ int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     // the gather starts when everything queued on the compute stream so far (this tick's torques) is complete ...
-    HIPCHK(c, hipEventRecord(c->ev_tick, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_tick, 0));
+    if (after_tick) {
+        // ... of the context's last pipelined tick: a one-thread launch on the communication stream polls the count that tick's join bumps -- no
+        // event on the compute stream (recording one there costs that stream 7 us a tick on this pool).  Bounded (2 s), and a gate that gives up
+        // says so through the word qrgpu_sync looks at: a gather of torques that are not there yet must not pass silently.
+        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_tick_done, c->tick_done_total, (long long)200000000, c->d_pre_hint + 2, 1,
+                           (int *)nullptr);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipEventRecord(c->ev_tick, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_tick, 0));
+    }
     NCCLCHK(c, R, R->AllGather(d_tau, d_tau_all, (size_t)12 * (size_t)n_local, ncclFloat, comm, c->comm_stream));
     // ... and whoever overwrites d_tau (buffer `slot`) later fences on this event
     HIPCHK(c, hipEventRecord(c->ev_gather[slot], c->comm_stream));
@@ -173,6 +182,17 @@ int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n
     return QRGPU_OK;
 }
 
+int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot)
+{
+    return allgather_tau(c, nccl_comm, d_tau, n_local, d_tau_all, slot, false);
+}
+
+int qrgpu_allgather_tau_of_tick(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot)
+{
+    // the gather of the torques of the context's LAST qrgpu_tick_batch: when that was a pipelined tick the gather waits for that tick, not for the stream
+    return allgather_tau(c, nccl_comm, d_tau, n_local, d_tau_all, slot, c && c->last_tick_piped && comm_polls() && c->d_tick_done != nullptr);
+}
+
 int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
@@ -180,6 +200,10 @@ int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
     // (A wait for an event of another stream costs the waiting stream several microseconds even when the event has long happened -- 8 us between
     //  two launches on this pool, against 2 without.  The gather of two steps ago normally HAS happened by the time the host queues this step:
     //  ask first, and put the wait on the stream only when it is still running.  hipErrorNotReady is not an error here.)
+    if (comm_polls() && c->gather_joined[slot] == c->gather_total[slot]) {     // a pipelined tick's join has waited for this gather already
+        c->ev_gather_pending[slot] = false;
+        return QRGPU_OK;
+    }
     const hipError_t q = hipEventQuery(c->ev_gather[slot]);
     if (q != hipSuccess) {
         (void)hipGetLastError();

@@ -67,8 +67,12 @@ struct qrgpu_ctx {
     int qhead_parity = 0;
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
+    int *d_tick_done = nullptr;               // pipelined ticks complete (bumped by their joins), ever: what qrgpu_allgather_tau_of_tick's gate polls
+    int tick_done_total = 0;
+    bool last_tick_piped = false;             // the context's most recent qrgpu_tick_batch was a pipelined one with a polling join
     int *d_gather_done = nullptr;             // [2] gathers finished per source-buffer slot, ever (qrgpu_allgather_fence polls it)
     int gather_total[2] = {0, 0};
+    int gather_joined[2] = {0, 0};            // ... of which a pipelined tick's join has already made the compute stream wait for
     int *d_go = nullptr;                      // [2]: [0] "go" count of the planned launches' gates (cumulative), [1] plan epoch of a gate that gave up
     int go_total = 0, plan_epoch = 0;
     int *d_planned_done = nullptr;            // workgroups of planned launches that are through, ever (polled by the trailing launch of a pipelined tick)

@@ -111,7 +111,7 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_estimator_update_batch", "qrgpu_pack_state_batch", "qrgpu_swing_targets_batch", "qrgpu_swing_velocity_batch", "qrgpu_gait_desc_default", "qrgpu_gait_update_batch",
            "qrgpu_foothold_desc_default", "qrgpu_footholds_batch", "qrgpu_ground_update_batch", "qrgpu_walk_gait_desc_default", "qrgpu_walk_gait_update_batch", "qrgpu_vmc_force_world_batch", "qrgpu_vmc_force_world1",
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
-           "qrgpu_allgather_tau", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
+           "qrgpu_allgather_tau", "qrgpu_allgather_tau_of_tick", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch", "qrgpu_host_alloc", "qrgpu_host_free",
            "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms", "qrgpu_set_tick_pipeline"]
 
@@ -151,6 +151,7 @@ def load_library():
     lib.qrgpu_comm_info.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
     lib.qrgpu_comm_destroy.argtypes = [vp]
     lib.qrgpu_allgather_tau.argtypes = [vp, vp, vp, ip, vp, ip]
+    lib.qrgpu_allgather_tau_of_tick.argtypes = [vp, vp, vp, ip, vp, ip]
     lib.qrgpu_allgather_fence.argtypes = [vp, ip]
     lib.qrgpu_allgather_wait.argtypes = [vp, ip]
     lib.qrgpu_comm_sync.argtypes = [vp]
@@ -536,8 +537,11 @@ class Context:
     def comm_destroy(self):
         self._chk(self._lib.qrgpu_comm_destroy(self._h))
 
-    def allgather_tau(self, tau, n_local, tau_all, slot=0, nccl_comm=None):
-        self._chk(self._lib.qrgpu_allgather_tau(self._h, _dp(nccl_comm), _dp(tau), int(n_local), _dp(tau_all), int(slot)))
+    def allgather_tau(self, tau, n_local, tau_all, slot=0, nccl_comm=None, of_tick=False):
+        """Asynchronous on the context's communication stream; tau_all is [nranks][12][n_local] (rank-major).  of_tick: `tau` is what the
+        context's last tick_batch produced and nothing queued since writes it (qrgpu_allgather_tau_of_tick: no event on the compute stream)."""
+        fn = self._lib.qrgpu_allgather_tau_of_tick if of_tick else self._lib.qrgpu_allgather_tau
+        self._chk(fn(self._h, _dp(nccl_comm), _dp(tau), int(n_local), _dp(tau_all), int(slot)))
 
     def allgather_fence(self, slot=0):
         self._chk(self._lib.qrgpu_allgather_fence(self._h, int(slot)))

@@ -16,15 +16,17 @@ d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 
          force=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32))
 tau = [ctx.alloc((12, n)), ctx.alloc((12, n))]
 tau_all = ctx.alloc((1, 12, n))
-def run(k, gather):
+def run(k, gather, fence=True):
     ctx.sync(); t0 = time.perf_counter()
     for i in range(k):
         slot = i & 1
-        if gather: ctx.allgather_fence(slot)
+        if gather and fence: ctx.allgather_fence(slot)
         ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], tau[slot], d["status"])
-        if gather: ctx.allgather_tau(tau[slot], n, tau_all, slot)
+        if gather: ctx.allgather_tau(tau[slot], n, tau_all, slot, of_tick=OF_TICK)
     if gather: ctx.comm_sync()
     ctx.sync()
     return (time.perf_counter() - t0) / k * 1e3
+import os
+OF_TICK = os.environ.get('OF_TICK', '1') == '1'
 for rep in range(3):
-    print("ms per tick: without gather %.4f, with gather %.4f" % (run(100, False), run(100, True)))
+    print("ms per tick: without gather %.4f, with gather %.4f, with gather but no fence (timing only) %.4f" % (run(100, False), run(100, True), run(100, True, False)))

@@ -67,7 +67,7 @@ def test_allgather_tau_single_rank(pkg, oracle):
                 ctx.allgather_fence(slot)
                 d["prev"].copy_from_pinned(pin_prev)
                 ctx.tick_batch(n, src["state"], src["traj"], src["gait"], src["fb"], src["cmd"], d["prev"], d["force"], tau[slot], d["status"])
-                ctx.allgather_tau(tau[slot], n, alls[i], slot)
+                ctx.allgather_tau(tau[slot], n, alls[i], slot, of_tick=(i >= 4))      # (the last six: the gather waits for its tick's join, not for an event)
             ctx.comm_sync()
             ctx.sync()
         ga = [a.download()[0] for a in alls]
