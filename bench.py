@@ -414,6 +414,16 @@ def main():
     if not launched and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    # The one JSON line is the only thing this program may put on its standard output -- and libraries it loads write there at C level (RCCL
+    # prints a five-line banner when its first communicator comes up, gloo announces its connections): from here on file descriptor 1 IS
+    # standard error, and emit() writes the line to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -432,14 +442,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id.  (gloo announces its connections on the C-level
-        # stdout: keep that off the one JSON line this program prints)
-        sys.stdout.flush()
-        saved = os.dup(1); os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend="gloo")
-        finally:
-            os.dup2(saved, 1); os.close(saved)
+        # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id
+        dist.init_process_group(backend="gloo")
     dry = os.environ.get("QRGPU_BENCH_DRY", "")
     if dry:
         # launcher self-test (tests/test_bench_launch.py, no GPU): rendezvous, one max-reduce, one JSON line; "fail<r>" makes rank r exit 3 first
@@ -450,7 +454,7 @@ def main():
             t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); v = float(t.item())
             dist.barrier(); dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "launcher self-test", "value": v, "n_gpus": world, "dry": True}))
+            emit({"metric": "launcher self-test", "value": v, "n_gpus": world, "dry": True})
         return
 
     pkg = _load_pkg()
@@ -459,7 +463,7 @@ def main():
     if world > 1:
         dist.barrier()
     if args.mode == "single":
-        print(json.dumps(single_mode(args, pkg)))
+        emit(single_mode(args, pkg))
         return
     n, h = args.robots, args.horizon
     ctx = pkg.Context(device_id=local_rank, max_batch=n, horizon_max=16)   # raises without gfx950 / built library
@@ -468,12 +472,17 @@ def main():
 
     if args.mode in ("vmc", "frontend", "estimator"):
         if rank == 0:
-            print(json.dumps(side_mode(args, pkg, ctx)))
+            emit(side_mode(args, pkg, ctx))
         ctx.close()
         return
 
+    # QRGPU_BENCH_FORCE_COMM=1 (one GPU): a one-rank RCCL communicator and the whole exchange of the N > 1 path -- fence, gather behind every tick,
+    # check of the gathered block -- with world = 1: what that path costs a rank's ticks, measured where there is only one GPU
+    comm_on = (world > 1 and not rehearsal) or (world == 1 and os.environ.get("QRGPU_BENCH_FORCE_COMM") == "1")
     if world > 1 and not rehearsal:
         ctx.comm_init_rank(pkg.shard.exchange_comm_id(rank, pkg.qrgpu.comm_unique_id), world, rank)     # RCCL communicator owned by the context
+    elif comm_on:
+        ctx.comm_init_rank(pkg.qrgpu.comm_unique_id(), 1, 0)
     ctx.set_torque_epilogue(hip_comp=True, clip=True)          # K14 tail is part of the tick SURVEY 8(d) defines
     ctx.set_hessian_mode(args.hessian)
 
@@ -524,18 +533,18 @@ def main():
     d_force = dv.zeros((12, n))
     d_qdes = dv.zeros((24, n))
     d_status = dv.zeros((n,), np.int32)
-    d_tau2 = [dv.zeros((12, n)) for _ in range(2 if world > 1 else 1)]
-    d_tau_all = dv.zeros((world, 12, n)) if world > 1 else None   # rank-major
+    d_tau2 = [dv.zeros((12, n)) for _ in range(2 if (world > 1 or comm_on) else 1)]
+    d_tau_all = dv.zeros((world, 12, n)) if (world > 1 or comm_on) else None   # rank-major
     nstep = [0]
     cur = dict(draw=0, k12=True, fixed=None)
 
     def step():
         i = nstep[0]
         nstep[0] += 1
-        slot = i & 1 if world > 1 else 0
+        slot = i & 1 if (world > 1 or comm_on) else 0
         tau = d_tau2[slot]
         ds, dt_, dg, dfb, dcmd = dev_seq[cur["draw"]][cur["fixed"] if cur["fixed"] is not None else walk[i % len(walk)]]
-        if world > 1 and not rehearsal:
+        if comm_on:
             ctx.allgather_fence(slot)                          # the gather of two steps ago has finished reading this buffer
         if args.mode == "tick":
             ctx.tick_batch(n, ds, dt_, dg, dfb, dcmd, d_prev, d_force, tau, d_status, d_type, qdes=d_qdes if cur["k12"] else None)
@@ -543,7 +552,7 @@ def main():
             ctx.mpc_solve_batch(n, ds, dt_, dg, dfb.row(13), d_force, tau, d_status)
         else:
             ctx.wbc_run_batch(n, dfb, dcmd, d_prev, tau, d_qdes, d_status)
-        if world > 1:
+        if world > 1 or comm_on:
             if rehearsal:
                 ctx.sync()
                 parts = [torch.empty((12, n)) for _ in range(world)]
@@ -553,9 +562,9 @@ def main():
                 ctx.allgather_tau(tau, n, d_tau_all, slot, of_tick=(args.mode == "tick"))     # RCCL over xGMI on the context's own stream: the only exchange of the path
 
     def fence():
+        if comm_on:
+            ctx.comm_sync()
         if world > 1:
-            if not rehearsal:
-                ctx.comm_sync()
             ctx.sync()
             dist.barrier()
         ctx.sync()
@@ -602,7 +611,7 @@ def main():
         st_d = d_status.download()          # (outside the timed region: the last step's status words of this draw)
         draw_flags.append(int((pkg.status_flags(st_d) != 0).sum())); draw_itmax.append(int(pkg.status_iterations(st_d).max()))
         draw_itmean.append(float(pkg.status_iterations(st_d).mean()))
-    if world > 1:
+    if world > 1 or comm_on:
         own = d_tau_all.download()[rank]
         if not np.array_equal(own, d_tau2[(nstep[0] - 1) & 1].download()):
             raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
@@ -793,7 +802,7 @@ def main():
                        "draws": D, "ticks_per_s_min": float(min(rates)), "ticks_per_s_max": float(max(rates)), "ticks_per_s_per_draw": [float(r) for r in rates],
                        "ticks_per_s_all_steps": world * n * args.steps / sum(draw_s),
                        "rank_batches": "every rank draws the same populations (control)" if args.same_seed_ranks else "every rank draws its own populations",
-                       "parallelism": "robots sharded over %d GPU(s); qrgpu_allgather_tau (RCCL, context-owned stream) overlapped with the next tick" % world,
+                       "parallelism": ("robots sharded over %d GPU(s); qrgpu_allgather_tau_of_tick (RCCL, context-owned stream) overlapped with the next tick" % world) + (" [QRGPU_BENCH_FORCE_COMM: one-rank communicator, the exchange of the N > 1 path on one GPU]" if (comm_on and world == 1) else ""),
                        "host_plumbing": "no GPU array library: device / pinned buffers, stream, events and the collective behind the C ABI" +
                                         ("; torch.distributed (gloo, CPU) for the launcher's barrier / max-reduce / id hand-over" if world > 1 else "; torch not imported"),
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
@@ -875,7 +884,7 @@ def main():
                             "(qr_mpc_interface.cpp:418-438): these 24 robots are rows 62-85 of tests/golden/mpc_golden.npz, where the full-tick torque is "
                             "checked too; north_star's 1e-4 is not met against this comparator -- nor by the reference against itself (DESIGN.md 2, "
                             "tests/golden/parity_as_called.json, tests/test_gpu_golden.py)"}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
