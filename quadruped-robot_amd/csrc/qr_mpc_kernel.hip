@@ -1981,16 +1981,20 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done)
 {
     if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    for (;;) {
-        bool ok = (int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)expected_total) >= 0;
-        if (ok && g0) ok = (int)((unsigned)__hip_atomic_load(g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e0) >= 0;
-        if (ok && g1) ok = (int)((unsigned)__hip_atomic_load(g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e1) >= 0;
-        if (ok) { if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-        if (wall_clock64() - t0 >= max_ticks) break;
+    auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
+    long long t0 = wall_clock64();
+    while (!reached(counter, expected_total)) {
+        if (wall_clock64() - t0 >= max_ticks) { if (timed_out) { *timed_out = 1; __threadfence_system(); } return; }
         __builtin_amdgcn_s_sleep(16);
     }
-    if (timed_out) { *timed_out = 1; __threadfence_system(); }
+    // the gathers: another rank may be late with its side of the collective (the first one also sets up RCCL's connections), so this wait is
+    // a patient one -- 30 s, then it is a hung collective and is reported as such
+    t0 = wall_clock64();
+    while ((g0 && !reached(g0, e0)) || (g1 && !reached(g1, e1))) {
+        if (wall_clock64() - t0 >= 3000000000LL) { if (timed_out) { *timed_out = 1; __threadfence_system(); } return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

@@ -1372,7 +1372,8 @@ int qrgpu_sync(qrgpu_ctx *c)
         // the join of a pipelined tick waited 20 ms for its WBC launch and went on without it: outputs of that tick are incomplete
         c->h_pre_count[2] = 0;
         (void)hipStreamSynchronize(c->wbc_stream);
-        c->err = "pipelined tick: the WBC launch did not finish within 20 ms of its join (outputs of that tick were incomplete when the stream went on)";
+        c->err = "a bounded device-side wait gave up: the WBC launch of a pipelined tick did not finish within 20 ms of its join, or an all-gather did not finish "
+                 "(or its tick did not) within 30 s: outputs of that call were incomplete when the stream went on";
         return QRGPU_ERR_LAUNCH;
     }
     return QRGPU_OK;

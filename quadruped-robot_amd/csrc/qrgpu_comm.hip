@@ -159,9 +159,9 @@ static int allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int 
     // the gather starts when everything queued on the compute stream so far (this tick's torques) is complete ...
     if (after_tick) {
         // ... of the context's last pipelined tick: a one-thread launch on the communication stream polls the count that tick's join bumps -- no
-        // event on the compute stream (recording one there costs that stream 7 us a tick on this pool).  Bounded (2 s), and a gate that gives up
+        // event on the compute stream (recording one there costs that stream 7 us a tick on this pool).  Bounded (30 s), and a gate that gives up
         // says so through the word qrgpu_sync looks at: a gather of torques that are not there yet must not pass silently.
-        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_tick_done, c->tick_done_total, (long long)200000000, c->d_pre_hint + 2, 1,
+        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_tick_done, c->tick_done_total, (long long)3000000000LL, c->d_pre_hint + 2, 1,
                            (int *)nullptr);
         HIPCHK(c, hipGetLastError());
     } else {
@@ -208,10 +208,10 @@ int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
     if (q != hipSuccess) {
         (void)hipGetLastError();
         if (comm_polls()) {
-            // bounded (200 ms: a gather that has not finished two ticks later is a hung collective; the stream then goes on and the next
-            // qrgpu_sync / qrgpu_comm_sync is where that shows)
-            hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gather_done + slot, c->gather_total[slot], (long long)20000000, (int *)nullptr, 0,
-                               (int *)nullptr);
+            // bounded (30 s: another rank may be late with its side of the collective, and the first gather also sets up RCCL's connections; beyond
+            // that it is a hung collective, the stream goes on and qrgpu_sync reports it)
+            hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gather_done + slot, c->gather_total[slot], (long long)3000000000LL,
+                               c->d_pre_hint + 2, 1, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
     }
