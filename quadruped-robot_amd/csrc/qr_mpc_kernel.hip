@@ -1011,6 +1011,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // phases 0-3 may run on more than four waves (NTHR / 64: one block of a trotting robot's Hessian per thread); the active set is a
     // four-wave protocol, so the others are done here (a wave that has ended no longer counts at the workgroup's barriers)
     if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) { if (PERSIST) QR_IDLE(); return; }
+#ifdef QR_AS_PRIO        // (A/B: issue priority for the four waves of the latency-bound active set over a co-resident workgroup's build and sweep)
+    __builtin_amdgcn_s_setprio(QR_AS_PRIO);
+#endif
     if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
     if (QR_PFLOPS) {
