@@ -413,6 +413,44 @@ def test_pipelined_ticks_queued_without_a_sync_match_the_serial_ticks(pkg):
         assert np.abs(a["qdes"][ok] - b_["qdes"][ok]).max() < 1e-5, k
 
 
+def test_pipelined_ticks_of_changing_batch_size_queued_without_a_sync(pkg):
+    """Ticks of 1024, 256, 1024, 64 (the smallest pipelined size), 1024, 96 and 1024 robots queued back to back on one context without a sync: the
+    gates, joins and flags are cumulative counts and epochs that must survive a change of the batch size from one call to the next (grids,
+    expected counts, the planned and rescue lists' histories all change).  Against the same calls on the serial form, at the solver's tolerance."""
+    h = 10
+    sizes = [1024, 256, 1024, 64, 1024, 96, 1024]
+    batches = [pkg.make_batch(n, h, "a1", seed=0xB5 + k, frac_all_stance=0.15, excite=1.3) for k, n in enumerate(sizes)]
+    S = pkg.to_soa
+    res = {}
+    for piped in (False, True):
+        ctx = pkg.Context(0, 1024, 16)
+        try:
+            G.setup_a1(ctx, pkg, h)
+            ctx.set_tick_pipeline(piped)
+            io = []
+            for b in batches:
+                n = b["n"]
+                io.append(dict(n=n, state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+                               fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])),
+                               force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)),
+                               status=ctx.alloc((n,), np.int32).upload(np.full((n,), 0x7f0000ff, np.int32))))
+            ctx.sync()
+            for d in io:
+                ctx.tick_batch(d["n"], d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], d["force"], d["tau"], d["status"])
+                if not piped:
+                    ctx.sync()
+            ctx.sync()
+            res[piped] = [(d["tau"].download().T.copy(), d["status"].download()) for d in io]
+        finally:
+            ctx.close()
+    for k, ((ta, sa), (tb, sb)) in enumerate(zip(res[False], res[True])):
+        assert np.all(np.isfinite(tb)) and np.all(G.flags(sb) & 0x02000000 == 0), k
+        assert np.array_equal(G.flags(sa), G.flags(sb)), k
+        ok = G.flags(sa) == 0
+        assert ok.mean() > 0.9, k
+        assert np.all(np.abs(ta[ok] - tb[ok]) <= G.tau_tol(ta[ok], 1e-4)), (k, np.abs(ta[ok] - tb[ok]).max())
+
+
 _GATE_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
