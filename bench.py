@@ -450,6 +450,8 @@ def main():
         if dry == "fail%d" % rank:
             sys.exit(3)
         v = float(rank + 1)
+        if os.environ.get("QRGPU_BENCH_DRY_NOISE"):
+            os.write(1, b"a library's banner on file descriptor 1\n")      # what RCCL does when its first communicator comes up (the launcher test)
         if world > 1:
             t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); v = float(t.item())
             dist.barrier(); dist.destroy_process_group()

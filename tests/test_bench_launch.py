@@ -48,3 +48,15 @@ def test_single_process_dry_run_does_not_import_torch():
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
+
+
+def test_the_json_line_is_alone_on_stdout_even_when_a_library_writes_there():
+    """RCCL prints a five-line banner on the C-level standard output when its first communicator comes up -- in front of the one JSON line the
+    driver parses.  bench.py points file descriptor 1 at standard error and writes its line to the real standard output; the dry run imitates
+    the banner (QRGPU_BENCH_DRY_NOISE) on every rank."""
+    for args in (["--gpus", "1"], ["--gpus", "2", "--steps", "4", "--warmup", "1"]):
+        r = _run(args, "1", dict(QRGPU_BENCH_DRY_NOISE="1"))
+        assert r.returncode == 0, r.stderr.decode()
+        lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1 and json.loads(lines[0])["dry"] is True, lines
+        assert b"banner on file descriptor 1" in r.stderr
