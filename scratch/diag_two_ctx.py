@@ -26,8 +26,10 @@ def run(K, steps=200, warm=20):
     for c in ctxs: c.sync()
     t0 = time.perf_counter()
     for i in range(warm, warm + steps): step(i)
+    t_enq = time.perf_counter() - t0
     for c in ctxs: c.sync()
     el = time.perf_counter() - t0
+    print("   (K = %d: host enqueue %.1f us per tick_batch call; %.1f us per step in all)" % (K, t_enq / steps / K * 1e6, el / steps * 1e6))
     flags = sum(int((G.flags(D["st"].download()) != 0).sum()) for D in data)
     for c in ctxs: c.close()
     return N * steps / el, flags
