@@ -139,8 +139,11 @@ void qrgpu_vmc_desc_default(qrgpu_vmc_desc *d);
 /* device_id: HIP device ordinal.  max_batch: largest n of any batched call. */
 int  qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out);
 void qrgpu_destroy(qrgpu_ctx *ctx);
-/* Launch on this hipStream_t (NULL = the default stream). */
+/* The compute stream: every batched call is queued on it and completes in its order.  A context starts with a non-blocking stream of its own
+ * (qrgpu_get_stream hands it out, for a caller that wants to queue its own work in order with the library's); qrgpu_set_stream names another
+ * hipStream_t -- NULL = the default (null) stream, on which several contexts of one process serialise each other's launches. */
 int  qrgpu_set_stream(qrgpu_ctx *ctx, void *hip_stream);
+void *qrgpu_get_stream(qrgpu_ctx *ctx);
 /* Longest-first dispatch of the batched MPC solve (default on): robot i's solve time in one call orders the workgroup
  * dispatch of the next call with the same n (control ticks are temporally coherent).  Scheduling only -- results do not
  * depend on it; a batch whose robots were reshuffled between calls merely loses the speed-up.  Turning it on or off

@@ -84,6 +84,7 @@ int ensure_comm_stream(qrgpu_ctx *c)
     if (!c->d_gather_done) {
         HIPCHK(c, hipMalloc(&c->d_gather_done, 2 * sizeof(int)));
         HIPCHK(c, hipMemset(c->d_gather_done, 0, 2 * sizeof(int)));
+        HIPCHK(c, hipDeviceSynchronize());
         c->gather_total[0] = c->gather_total[1] = 0;
     }
     return QRGPU_OK;

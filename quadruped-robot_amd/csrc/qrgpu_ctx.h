@@ -15,6 +15,7 @@ struct qrgpu_ctx {
     int max_batch = 0;
     int horizon_max = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
     MpcLaunch mpc{};
     bool mpc_ready[QR_MAX_TYPES] = {false, false, false, false};
     bool wbc_ready[QR_MAX_TYPES] = {false, false, false, false};

@@ -103,7 +103,7 @@ def lib_path():
     return os.environ.get("QRGPU_LIB") or os.path.join(_HERE, "libqrgpu.so")
 
 
-EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_set_stream", "qrgpu_last_error",
+EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_set_stream", "qrgpu_get_stream", "qrgpu_last_error",
            "qrgpu_device_info", "qrgpu_mpc_setup", "qrgpu_wbc_setup", "qrgpu_mpc_solve_batch", "qrgpu_wbc_run_batch",
            "qrgpu_tick_batch", "qrgpu_mpc_solve1", "qrgpu_wbc_run1", "qrgpu_mpc_assemble_batch", "qrgpu_fb_debug_batch",
            "qrgpu_sync", "qrgpu_enable_timing", "qrgpu_get_timing", "qrgpu_malloc", "qrgpu_free", "qrgpu_memcpy_h2d",

@@ -5,6 +5,8 @@ sys.path.insert(0, '/root/repo/tests')
 from conftest import load_pkg
 import gpu_helpers as G
 pkg = load_pkg()
+import os
+MODE = os.environ.get('MODE', 'tick')
 h, N = 10, 1024
 S = pkg.to_soa
 def run(K, steps=200, warm=20):
@@ -21,7 +23,9 @@ def run(K, steps=200, warm=20):
     def step(i):
         for ctx, D in zip(ctxs, data):
             d = D["dev"][walk[i % len(walk)]]
-            ctx.tick_batch(D["n"], d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], D["prev"], D["force"], D["tau"], D["st"], qdes=D["qd"])
+            if MODE == "mpc": ctx.mpc_solve_batch(D["n"], d["state"], d["traj"], d["gait"], d["fb"].row(13), D["force"], D["tau"], D["st"])
+            elif MODE == "wbc": ctx.wbc_run_batch(D["n"], d["fb"], d["cmd"], D["prev"], D["tau"], D["qd"], D["st"])
+            else: ctx.tick_batch(D["n"], d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], D["prev"], D["force"], D["tau"], D["st"], qdes=D["qd"])
     for i in range(warm): step(i)
     for c in ctxs: c.sync()
     t0 = time.perf_counter()
