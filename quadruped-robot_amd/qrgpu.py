@@ -129,6 +129,8 @@ def load_library():
     lib.qrgpu_create.argtypes = [ip, ip, ip, C.POINTER(vp)]
     lib.qrgpu_destroy.argtypes = [vp]; lib.qrgpu_destroy.restype = None
     lib.qrgpu_set_stream.argtypes = [vp, vp]
+    lib.qrgpu_get_stream.argtypes = [vp]
+    lib.qrgpu_get_stream.restype = vp
     lib.qrgpu_set_lpt_schedule.argtypes = [vp, ip]
     lib.qrgpu_set_rescue_pass.argtypes = [vp, ip]
     lib.qrgpu_set_warm_start.argtypes = [vp, ip]
@@ -307,6 +309,10 @@ class Context:
     # -- setup ---------------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
         self._chk(self._lib.qrgpu_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
+
+    def get_stream(self):
+        """The hipStream_t (as an integer) the context queues on: a non-blocking stream of its own unless set_stream named another."""
+        return int(self._lib.qrgpu_get_stream(self._h) or 0)
 
     def device_info(self):
         buf = C.create_string_buffer(256); lds = C.c_int(0)

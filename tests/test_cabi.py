@@ -98,6 +98,15 @@ def test_error_returns(gpu_ctx, pkg):
             ctx.vmc_force_batch(8, a, None, f)
         with pytest.raises(pkg.QrgpuError, match="BAD_ARG"):
             ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), 17)                    # horizon beyond K_MAX_GAIT_SEGMENTS
+        # the compute stream: a non-blocking stream of the context's own, a different one per context; set_stream(None) = the default stream
+        other = pkg.Context(device_id=0, max_batch=8, horizon_max=16)
+        try:
+            assert ctx.get_stream() != 0 and other.get_stream() != 0 and ctx.get_stream() != other.get_stream()
+            own = other.get_stream()
+            other.set_stream(None); assert other.get_stream() == 0
+            other.set_stream(own); assert other.get_stream() == own
+        finally:
+            other.close()
         for v in (a, t, g, f):
             v.free()
     finally:
