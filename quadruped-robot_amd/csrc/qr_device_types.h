@@ -68,6 +68,9 @@ struct MpcLaunch {
     unsigned char *skip;
     int big_nls;                // 0 = no class rule
     int big_margin;             // a solve that ends within this many rows of what the main pass's LDS holds puts its robot on the planned list
+    int planned_stride;         // planned launch of the h <= 16 whole-CU kernel: workgroup b takes entries b, b + grid, ... (a list longer than the CUs it may have)
+    int big_cost, big_cost_stay; // (0 = off) smoothed cost, in units of 256 cycles, from which a main-pass solve puts its robot on the planned list,
+                                // and from which a list solve keeps it there (QRGPU_H16_TWO: the long poles of a tick get a whole CU)
     int lds_main;               // the main pass's LDS allotment (bytes), for the `big` decision of a solve that runs in a list launch
     // the rescue launch also carries the longest-first sort of the next call (workgroups 0-7) when both are on: one launch fewer
     const int *lpt_cost_in;

@@ -482,8 +482,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     const int tail_doubles = (BIG && !xr2_in_floats) ? 256 : 0;
     constexpr int QMAX = BIG ? QR_QH : 64;          // working-set positions the per-lane registers hold
     int qcap;
+    bool m_fits;                        // the block-packed inverse Hessian itself fits this launch's LDS allotment
     {   // rows of S^-1 that fit behind M
         const long long rem = (long long)(P.lds_bytes / 8) - (long long)(Mb - smem) - (long long)npairs * 9 - tail_doubles;
+        m_fits = rem >= 0;
         int qc = 0;
         if (rem > 0) { qc = (int)((__builtin_sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5); while (tri(qc) > rem) --qc; }
         qcap = qc < QMAX ? qc : QMAX;
@@ -494,7 +496,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         // (the pointer is then generic and the S^-1 accesses of these variants compile to flat_* instructions: a few per cent at
         // h = 16, nothing at h <= 11 whose variants never take this branch)
         const int want = ns < QMAX ? ns : QMAX;
-        if (P.sinv_spill && qcap < want && qcap < 64) { Sinv = P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH); qcap = want; spilled = true; }
+        if (P.sinv_spill && m_fits && qcap < want && qcap < 64) { Sinv = P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH); qcap = want; spilled = true; }
     }
     // What is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the iteration that added it),
     // so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to z = w - M (N_A r) for good once the
@@ -1762,7 +1764,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 int qcm = 0;
                 if (remm > 0) { qcm = (int)((__builtin_sqrt(8.0 * (double)remm + 1.0) - 1.0) * 0.5); while (tri(qcm) > remm) --qcm; }
                 if (qcm > 64) qcm = 64;
-                big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)) ? 1 : 0;
+                big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)
+                       || (P.big_cost > 0 && cfine >= (P.rescue_mode == 0 ? P.big_cost : P.big_cost_stay))) ? 1 : 0;
             }
             if (P.planned_done) __hip_atomic_store(P.cost + rid, (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16);
@@ -1794,8 +1797,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 //   LIST = true:  workgroups 0-7 first sort the next call's dispatch order, then workgroup b re-solves entries b, b + grid, b + 2 grid ...
 //                 of the rescue list (robots whose working set outgrew the main pass's registers or LDS) with this launch's larger LDS
 //                 allotment and the BIG register set.
-template <int MAXB, bool BIG, bool LIST, int NTHR>
-__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !LIST && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
+//   MINW (0 = by the rule below): waves per SIMD the register allocation must leave room for.  The h <= 16 four-wave kernels take AGPRs on top of
+//                 their 256 VGPRs under the default of one wave per SIMD, so two of their workgroups never share a CU; MINW = 2 is the build that can.
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0>
+__global__ __launch_bounds__(NTHR, (MINW ? MINW : ((MAXB <= 4 && !LIST && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1))))
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
@@ -1868,6 +1873,18 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             if (P.plan_abort && *P.plan_abort == P.plan_epoch) { tell_done(); return; }       // its gate gave up: the main pass solves everybody (below)
             int cnt = P.pre_count[P.rescue_parity];
             cnt = cnt < P.n ? cnt : P.n;
+            if constexpr (MAXB == 5) {
+                // (QRGPU_H16_TWO: a tenth of a mixed h = 16 batch is listed -- more robots than the launch may take CUs.  The workgroup keeps its CU
+                //  and goes down the list; the waves its sweep no longer needs are parked as in the persistent main pass.)
+                if (P.planned_stride) {
+                    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+                        mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, P.pre_list[e], smem);
+                        __syncthreads();
+                    }
+                    tell_done();
+                    return;
+                }
+            }
             if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list) {
                 for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) {
                     const int r2 = P.pre_list[e2];
@@ -1899,8 +1916,8 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 #ifndef QR_FLOPS_BUILD
 // Persistent main pass (MpcLaunch::persist): one workgroup per resident slot; robots come off the queue of the workgroup's own XCD (slot
 // order of its chunk = the longest-first order), then off the others'; every robot taken counts for the WBC launch's gate.
-template <int MAXB, bool BIG, int NTHR>
-__global__ __launch_bounds__(NTHR, ((MAXB <= 4 && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1)))
+template <int MAXB, bool BIG, int NTHR, int MINW = 0>
+__global__ __launch_bounds__(NTHR, (MINW ? MINW : ((MAXB <= 4 && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1))))
 void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
 {
     extern __shared__ double smem[];
@@ -1942,7 +1959,8 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
 }
 template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
 template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
-template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);     // h <= 16, two four-wave workgroups per CU (no parked waves: every wave is in the active set)
+template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);     // h <= 16 on four waves (no parked waves: every wave is in the active set)
+template __global__ void qr_mpc_persist_kernel<9, true, 256, 2>(MpcLaunch, MpcIO);  // the same within 256 registers: two workgroups per CU (QRGPU_H16_TWO)
 #endif
 
 template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);     // h <= 11, main pass: eight waves build and sweep (128 VGPRs), four solve
@@ -1950,6 +1968,7 @@ template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO); 
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
 template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);       // h <= 16, list launches (whole CU's LDS, 96 rows)
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
+template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);   // h <= 16, four waves within 256 registers: two workgroups per CU (QRGPU_H16_TWO)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
 

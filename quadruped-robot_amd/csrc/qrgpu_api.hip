@@ -24,25 +24,28 @@ struct MpcIO {
     int force_stride;
     long long *dbgT;
 };
-template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);
-template <int MAXB, bool BIG, int NTHR> __global__ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io);
+template <int MAXB, bool BIG, int NTHR, int MINW = 0> __global__ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_persist_kernel<9, true, 256, 2>(MpcLaunch, MpcIO);
 // the same kernels with the executed-arithmetic counters compiled in (qr_mpc_kernel_fl.hip)
-template <int MAXB, bool BIG, bool LIST, int NTHR> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<4, true, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, MpcIO);
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done);
@@ -83,6 +86,8 @@ static const void *mpc_fn(int var, bool fl)
     case 7: return (const void *)qr_mpc_persist_kernel<5, true, 512>;
     case 8: return fl ? (const void *)qr_mpc_kernel_fl<9, true, true, 256> : (const void *)qr_mpc_kernel<9, true, true, 256>;     // h > 11, list launches
     case 9: return (const void *)qr_mpc_persist_kernel<9, true, 256>;       // persistent form of 1
+    case 10: return fl ? (const void *)qr_mpc_kernel_fl<9, true, false, 256, 2> : (const void *)qr_mpc_kernel<9, true, false, 256, 2>;   // 1 within 256 registers (two per CU)
+    case 11: return (const void *)qr_mpc_persist_kernel<9, true, 256, 2>;   // persistent form of 10
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
 }
@@ -91,7 +96,7 @@ static const void *mpc_fn(int var, bool fl)
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
     static std::mutex mu;
-    static int configured[16][2][10];          // [device][counting build][variant], zero-initialised
+    static int configured[16][2][12];          // [device][counting build][variant], zero-initialised
     std::lock_guard<std::mutex> lk(mu);
     int &have = configured[c->device & 15][fl ? 1 : 0][var];
     if (have >= bytes) return QRGPU_OK;
@@ -525,18 +530,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const bool tiny = small && n < 64 && !dH && tiny_whole_cu != 0;
     if (tiny) P.lds_bytes = c->lds_per_cu;
     // rescue pass for the h <= 11 main pass (not for inspection launches or tiny batches)
-    // h > 11, QRGPU_H16_TWO=1 (an experiment, off by default): the main pass runs TWO four-wave workgroups per CU on half the LDS each -- a
-    // trotting robot's inverse Hessian (40 stance leg-steps at h = 16: 59 KB) and a working set of up to ~45 rows fit -- and everything bigger
-    // (all-stance and three-leg robots, larger working sets: 15 % of the mixed shard) goes the way of the h <= 11 main pass: planned list beside
-    // the main pass, trailing list launch behind it, on the whole-CU kernels.  A solve is half sweep, half active set; the active set is a
-    // latency-bound four-wave protocol whatever the workgroup's size, and one workgroup per CU leaves the CU to it alone for that half.
-    // Measured on the mixed shard (scratch/diag_h16_two.py): robots that fit cost 190 us two to a CU (sweep 239 k cycles on four waves,
-    // 154 k on eight) against 150 us one to a CU -- 1.6 x per CU -- but 150-170 robots per tick are on the planned list at 330-400 us each on
-    // the striding four-wave list kernel, and 5-14 a tick outgrow the main pass unannounced and are re-solved BEHIND it: span 1.05 ms
-    // against 0.72 ms, 0.48 against 1.37 M ticks/s.  What it would take is in DESIGN.md 8.
-    static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 0; }();
-    const bool two = !small && h16_two != 0 && !dH && n >= 64;
-    if (two) { P.lds_bytes = (c->lds_per_cu / 2) & ~15; P.sinv_spill = nullptr; }
+    // h > 11, batches of 3.5 robots per CU and more (QRGPU_H16_TWO=0: never, =2: from 64 robots on): the main pass runs TWO four-wave workgroups per
+    // CU on half the LDS each, through a build of the four-wave kernel that keeps within 256 registers (<9, BIG, ., 256, 2>: under the default of
+    // one wave per SIMD the compiler takes AGPRs on top of the 256 VGPRs and two workgroups never share a CU -- what the first attempts at this
+    // measured without knowing).  A trotting robot's inverse Hessian (40 stance leg-steps at h = 16: 59 KB) fits; S^-1 of every robot of the main
+    // pass lives in the global scratch (qcap 96 whatever the LDS holds: nobody outgrows the main pass unannounced).  On whole CUs beside the main
+    // pass, one robot per eight-wave workgroup (planned list): the robots whose inverse Hessian does not fit half a CU (three-leg and all-stance
+    // gaits: a class known from the gait table, 10 % of the mixed shard) and the tick's long poles -- robots whose smoothed cost says 450 us
+    // and more two to a CU (60-80 active rows over the spilled S^-1), which stay listed while they cost 300 us and more on a whole CU.
+    // Mixed h = 16 shard: 1.37 -> 1.45 M ticks/s at 1024 robots, 1.46 -> 1.68 M at 2048, 1.50 -> 1.76 M at 8192; below 3.5 robots per CU one
+    // workgroup per CU is faster (1.27 against 1.17 M at 768: fewer rounds than slots).
+    static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
+    const bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2);
+    if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
     const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;
     P.rescue_count = rescue ? c->d_rescue : nullptr;
@@ -556,7 +562,22 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.pre_hint = planned ? c->d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
-    { static const int bm = [] { const char *e = getenv("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = bm; }
+    if (two && P.big_nls == 0) {
+        // the class that cannot be solved on half a CU: stance leg-steps whose block-packed inverse Hessian does not fit the main pass's LDS
+        const long long room = (long long)P.lds_bytes - (long long)mpc_lds_fixed_bytes(P.horizon, true);
+        int k = 1;
+        while (k <= 4 * P.horizon && (long long)k * (k + 1) / 2 * 72 <= room) ++k;
+        P.big_nls = k;
+    }
+    { static const int bm = [] { const char *e = getenv("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = two ? -1000 : bm; }
+    P.big_cost = P.big_cost_stay = 0; P.planned_stride = 0;
+    if (two) {
+        // the long poles: a robot whose solve takes most of the tick's span two to a CU (a large working set over the spilled S^-1: 600-800 us
+        // against a mean of 200) is planned onto a whole CU, and stays there while its solve costs more than QRGPU_H16_BIG_STAY_US there
+        static const int big_us = [] { const char *e = getenv("QRGPU_H16_BIG_US"); return e ? atoi(e) : 450; }();
+        static const int stay_us = [] { const char *e = getenv("QRGPU_H16_BIG_STAY_US"); return e ? atoi(e) : 300; }();
+        P.big_cost = (int)((long long)big_us * 2250 / 256); P.big_cost_stay = (int)((long long)stay_us * 2250 / 256);
+    }
     P.lds_main = P.lds_bytes;
     P.started = nullptr;
     if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
@@ -568,7 +589,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : ((h16_threads == 256 || two) ? 1 : 0));
+    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (two ? 10 : (h16_threads == 256 ? 1 : 0)));
     const int list_var = small ? 4 : 8;             // striding list kernel (trailing launch, long planned lists)
     const int one_var = small ? 5 : 0;              // one listed robot per whole-CU eight-wave workgroup
     // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
@@ -587,12 +608,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     int main_grid = 8 * ((n + 7) / 8);
     P.persist = 0; P.qhead = nullptr; P.qhead_next = nullptr;
     const void *main_fn = fn;
-    if (persist_on && !fl && !tiny && (var == 0 || var == 1 || (var == 3 && persist_on >= 2))) {
-        const int pvar = var == 3 ? 6 : (var == 1 ? 9 : 7);
+    if (persist_on && !fl && !tiny && (var == 0 || var == 1 || (var == 10 && persist_on >= 2) || (var == 3 && persist_on >= 2))) {
+        const int pvar = var == 3 ? 6 : (var == 1 ? 9 : (var == 10 ? 11 : 7));
         { const int rc_ = mpc_ensure_lds(c, pvar, false, P.lds_bytes); if (rc_) return rc_; }
         if (c->main_slots[pvar][0] == 0 || c->main_slots_lds[pvar][0] != P.lds_bytes) {
             int nb = 0;
-            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_fn(pvar, false), var == 1 ? 256 : 512, (size_t)P.lds_bytes));
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_fn(pvar, false), (var == 1 || var == 10) ? 256 : 512, (size_t)P.lds_bytes));
             c->main_slots[pvar][0] = nb > 0 ? nb : 1; c->main_slots_lds[pvar][0] = P.lds_bytes;
         }
         const int slots = 8 * ((c->main_slots[pvar][0] * c->num_cu + 7) / 8);
@@ -636,7 +657,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
-        const bool one_per_wg = planned_waves == 8 && n <= 2048 && c->h_pre_count[c->rescue_parity] <= c->num_cu / 4;
+        // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
+        const int g3_cap = two ? 3 * c->num_cu / 4 : c->num_cu;
+        const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && c->h_pre_count[c->rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
         // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
         // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and
         // the first workgroup of the next main pass on ticks that have a plan, against 2 on ticks that have none (the kernels' stamps).  Instead: a
@@ -650,9 +673,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         static const int planned_join = [] { const char *e = getenv("QRGPU_PLANNED_JOIN"); return e ? atoi(e) : 0; }();
         poll_join = poll_fork && piped && !planned_join;
         // grid of the one-robot-per-workgroup launch: the list's length as the host last saw it, plus two (below)
-        static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : 2; }();
-        int g3 = c->h_pre_count[c->rescue_parity] + g3_extra;
-        g3 = g3 < 1 ? 1 : (g3 > c->num_cu ? c->num_cu : g3);
+        // (h > 11 two to a CU: the cost rule's share of the list comes and goes with the robots' smoothed costs, a dozen entries a tick -- and a
+        //  robot handed to the trailing launch is a whole solve BEHIND the main pass: 1.10 M ticks/s with eight spare workgroups, 1.43 M with 24 or 48)
+        static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
+        int g3 = c->h_pre_count[c->rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
+        L.planned_stride = (two && g3 > g3_cap) ? 1 : 0;
+        g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
         bool main_gate_queued = false;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();

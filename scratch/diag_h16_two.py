@@ -35,5 +35,7 @@ for t, k in enumerate(list(range(8)) + [6, 5, 4]):
     print("t%d: lists (rescue p0 p1, planned p0 p1) %s | span %.0f us | robots by nls: %s" % (t, cnt.tolist(), t1.max(), {int(v): int((nls == v).sum()) for v in np.unique(nls)}))
     print("     all robots: mean solve %.0f us, mean q %.1f, q > 40: %d, q > 45: %d; phases (k cycles) load %.1f H %.1f sweep %.1f x0 %.1f AS %.1f out %.1f; flags %d" % (
         d.mean(), q.mean(), int((q > 40).sum()), int((q > 45).sum()), *ph.mean(0), int((G.flags(out["status"]) != 0).sum())))
+    print("     solve length (us): p50 %.0f p90 %.0f p99 %.0f max %.0f; > 300: %d, > 400: %d, > 500: %d; sum %.1f ms" % (
+        np.percentile(d, 50), np.percentile(d, 90), np.percentile(d, 99), d.max(), int((d > 300).sum()), int((d > 400).sum()), int((d > 500).sum()), d.sum() / 1000.0))
     late = np.argsort(-t1)[:4]
     print("     last to end: " + " | ".join("robot %d start %.0f len %.0f q %d nls %d it %d" % (r, t0[r], d[r], q[r], nls[r], it[r]) for r in late))

@@ -173,6 +173,43 @@ def test_full_tick_h16_mixed_a1_lite3(gpu_ctx, pkg, oracle):
     G.setup_a1(gpu_ctx, pkg, 10)
 
 
+def test_full_tick_h16_1024_two_workgroups_per_cu(pkg, oracle):
+    """BASELINE.json configs[4] at full size (1024 robots, A1 and Lite3 interleaved, horizon 16): from 3.5 robots per CU on, the h > 11 main pass
+    runs two four-wave workgroups per CU on half the LDS each; robots whose inverse Hessian does not fit half a CU (a class known from the gait
+    table) and the tick's long poles (smoothed cost) are planned onto whole CUs beside it.  Four ticks on the same inputs -- no plan, the plan
+    coming into being, the planned form twice -- every robot of every tick against the threaded oracle; by the last tick the planned list is
+    there and nobody is re-solved behind the main pass."""
+    import ctypes as C
+    h, n = 16, 1024
+    ctx = pkg.Context(0, n, h)
+    try:
+        for r, t in (("a1", 0), ("lite3", 1)):
+            ctx.mpc_setup_packed(t, pkg.mpc_cfg(r), h); ctx.wbc_setup_packed(t, pkg.model_desc(r))
+        ba = pkg.make_batch(n // 2, h, "a1", seed=1601); bl = pkg.make_batch(n // 2, h, "lite3", seed=1602)
+        b = dict(ba)
+        for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+            b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+        b["n"] = n
+        tid = pkg.shard.interleave_types(n, 2)
+        f = np.zeros((n, 12), np.float32); tau = np.zeros((n, 12), np.float32); st = np.zeros(n, np.int32)
+        for r, t in (("a1", 0), ("lite3", 1)):
+            m = tid == t
+            f[m], tau[m], st[m] = oracle.tick_batch(1, pkg.mpc_cfg(r), h, pkg.model_desc(r)[:3], pkg.model_desc(r), b["mpc_state"][m], b["traj"][m],
+                                                    b["gait"][m], b["fb_state"][m], b["wbc_cmd"][m], b["prev_ori_vel"][m].copy(), nthreads=8)[:3]
+        assert np.all(st == 0)
+        lists = np.zeros(8, np.int32); ctx._lib.qrgpu_debug_lists.argtypes = [C.c_void_p, C.c_void_p]
+        for tick in range(4):
+            out = G.run_tick(ctx, pkg, b, type_id=tid)
+            assert np.all(G.flags(out["status"]) == 0), (tick, np.unique(G.flags(out["status"])))
+            assert np.all(np.abs(out["force"] - f).max(1) <= 1e-5 * np.maximum(1.0, np.abs(f).max(1))), tick
+            assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), (tick, np.abs(out["tau"] - tau).max())
+            assert ctx._lib.qrgpu_debug_lists(ctx._h, lists.ctypes.data) == 0
+        assert lists[2] > 0 and lists[3] > 0, lists            # the planned list, both parities
+        assert lists[0] == 0 and lists[1] == 0, lists          # nobody handed to the trailing launch
+    finally:
+        ctx.close()
+
+
 def test_full_tick_1024_with_projection_and_motor_tail(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[2] at full size: 1024 A1 robots, h = 10, the whole tick of SURVEY 8(d) -- K12 (kinematic projection) on and
     the K14 motor tail (abad +-0.9 N m, +-23 N m clip) applied -- every robot against the threaded oracle."""
