@@ -274,7 +274,7 @@ struct MpcIO {
 // One robot's MPC tick by one workgroup of NTHR threads.  MAXB: 3x3 blocks a thread keeps in registers during the sweep (MAXB * NTHR >= number of
 // stance leg-step pairs).  BIG: working-set positions 64 .. 95 live in a second set of per-lane registers.  Every wave returns from here
 // (the workers at their exit command, wave 0 after the outputs), so a workgroup may solve several robots in a row (list mode below).
-template <int MAXB, bool BIG, int NTHR, bool PERSIST = false>
+template <int MAXB, bool BIG, int NTHR, bool PERSIST = false, bool H16 = (MAXB > 4)>
 __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO &io, const int rid, double *smem)
 {
     int tid_ = threadIdx.x;
@@ -315,8 +315,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     float *sTraj = sSt + 28;           // [12h]
     float *sGait = sTraj + NV;         // [4h]
     float *sV = sGait + NL;            // [13h]
-    float *sJ = (MAXB <= 4) ? sV + 13 * h : nullptr;   // [12][3] columns of the leg Jacobians (the torque map of phase 6, computed while the data loads; h <= 11)
-    int *sLs = (int *)(sV + 13 * h + (MAXB <= 4 ? 36 : 0));   // [NL] free leg-step -> original leg-step
+    float *sJ = !H16 ? sV + 13 * h : nullptr;   // [12][3] columns of the leg Jacobians (the torque map of phase 6, computed while the data loads; h <= 11)
+    int *sLs = (int *)(sV + 13 * h + (!H16 ? 36 : 0));   // [NL] free leg-step -> original leg-step
     int *sAct = sLs + NL;              // [QH] (unused since the single-wave loop went; keeps the carve of mpc_lds_fixed_bytes)
     short *sPos = (short *)(sAct + QR_QH);   // [6 NL] constraint id -> working-set position, or -1
     int *sMisc = (int *)(sPos + 6 * NL + ((6 * NL) & 1));   // [16]: [0] free leg-steps, [8..13] control block
@@ -492,7 +492,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (qcap > ns) qcap = ns;
     }
     bool spilled = false;
-    if constexpr (MAXB > 4) {
+    if constexpr (H16) {
         // (the pointer is then generic and the S^-1 accesses of these variants compile to flat_* instructions: a few per cent at
         // h = 16, nothing at h <= 11 whose variants never take this branch)
         const int want = ns < QMAX ? ns : QMAX;
@@ -549,7 +549,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // The torque map's Jacobian columns (AnalyticalLegJacobian, QS/robots/qr_robot.cpp:148-172) on twelve lanes of the second-to-last wave (the
     // snake below deals it the cheapest units): lane 3 leg + m takes the sine and cosine of ONE angle -- abad, hip + knee / 2, knee -- and
     // the three lanes of a leg trade them by shuffles, instead of every lane evaluating its column's six to eight sinf / cosf itself.
-    if (MAXB <= 4 && io.g_tau && (tid & ~63) == NTHR - 128) {
+    if (!H16 && io.g_tau && (tid & ~63) == NTHR - 128) {
         const int l12 = lane < 12 ? lane : 0;
         const int leg = (l12 * 21846) >> 16, m = l12 - 3 * leg;
         const float t0 = io.g_q[(size_t)(3 * leg) * n + rid], t1 = io.g_q[(size_t)(3 * leg + 1) * n + rid], t2 = io.g_q[(size_t)(3 * leg + 2) * n + rid];
@@ -1129,10 +1129,37 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #if defined(QR_DIAG_REFAC)
             const long long tb0 = clock64();
 #endif
-            double el[NE];
-            int eij[NE];
+            // (the 128-register h > 11 variant keeps the elements a 67-row set needs in registers, as the 64-row variants do; what a larger set
+            //  adds is swept in place in S^-1's own storage -- slower per pivot, for the one robot in a hundred that gets there unannounced)
+            constexpr int NER = (BIG && H16 && MAXB <= 4) ? 9 : NE;
+            auto elem_ij = [&](const int e, int &i, int &j) {
+                i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+                while (tri(i + 1) <= e) ++i;
+                while (tri(i) > e) --i;
+                j = e - tri(i);
+            };
+            double el[NER];
+            int eij[NER];
+            if constexpr (NER < NE) {
+                for (int m = NER; QR_AS_THREADS * m < ne; ++m) {
+                    const int e = tid + QR_AS_THREADS * m;
+                    if (e < ne) {
+                        int i, j; elem_ij(e, i, j);
+                        const int ci = sAct[i], cj = sAct[j];
+                        const int ki = (ci * 10923) >> 16, kj = (cj * 10923) >> 16;
+                        Blk B; load_block(Mb, ki, kj, B);
+                        double a0, a1, a2, b0, b1, b2;
+                        cons_vec(ci - 6 * ki, im, a0, a1, a2); cons_vec(cj - 6 * kj, im, b0, b1, b2);
+                        const double v = a0 * (B.m[0] * b0 + B.m[1] * b1 + B.m[2] * b2) + a1 * (B.m[3] * b0 + B.m[4] * b1 + B.m[5] * b2)
+                                       + a2 * (B.m[6] * b0 + B.m[7] * b1 + B.m[8] * b2);
+                        Sinv[e] = v;
+                        if (j == 0) colp[i] = v;
+                        if (i == j) diag0[i] = v;
+                    }
+                }
+            }
 #pragma unroll
-            for (int m = 0; m < NE; ++m) {
+            for (int m = 0; m < NER; ++m) {
                 el[m] = 0.0; eij[m] = 0;
                 if (QR_AS_THREADS * m < ne) {                                  // (uniform)
                     const int e = tid + QR_AS_THREADS * m;
@@ -1165,8 +1192,23 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const double d = cur[p];
                 if (!(d > 1e-11 * diag0[p])) { ok = false; break; }          // (the same value in every thread: a uniform exit)
                 const double ip = QR_RCP_PIVOT(d);
+                if constexpr (NER < NE) {
+                    for (int m = NER; QR_AS_THREADS * m < ne; ++m) {
+                        const int e = tid + QR_AS_THREADS * m;
+                        if (e < ne) {
+                            int i, j; elem_ij(e, i, j);
+                            const double ci = cur[i], cj = cur[j];
+                            const bool ip_ = (i == p), jp_ = (j == p);
+                            const double sp_ = (ip_ && jp_) ? -ip : (ip_ ? cj : ci) * ip;
+                            const double v = (ip_ || jp_) ? sp_ : Sinv[e] - ci * cj * ip;
+                            Sinv[e] = v;
+                            const bool c1 = (j == p + 1);
+                            if (c1 || i == p + 1) nxt[c1 ? i : j] = v;
+                        }
+                    }
+                }
 #pragma unroll
-                for (int m = 0; m < NE; ++m) {
+                for (int m = 0; m < NER; ++m) {
                     if (QR_AS_THREADS * m < ne) {                              // (uniform; threads past the last element work on a zero at (0, 0))
                         const int i = eij[m] >> 8, j = eij[m] & 255;
                         const double ci = cur[i], cj = cur[j];
@@ -1186,7 +1228,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #endif
             if (ok) {
 #pragma unroll
-                for (int m = 0; m < NE; ++m) { const int e = tid + QR_AS_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
+                for (int m = 0; m < NER; ++m) { const int e = tid + QR_AS_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
+                if constexpr (NER < NE) { for (int e = tid + QR_AS_THREADS * NER; e < ne; e += QR_AS_THREADS) Sinv[e] = -Sinv[e]; }
                 if (qW > 0 && q <= qW) {
                     for (int i = wv; i < q; i += 4) {
                         const int ci = sAct[i];
@@ -1799,7 +1842,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 //                 allotment and the BIG register set.
 //   MINW (0 = by the rule below): waves per SIMD the register allocation must leave room for.  The h <= 16 four-wave kernels take AGPRs on top of
 //                 their 256 VGPRs under the default of one wave per SIMD, so two of their workgroups never share a CU; MINW = 2 is the build that can.
-template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0>
+//   H16: the h > 11 form of the solve (no early copy of the torque map's Jacobians in LDS, S^-1 may live in the global scratch) -- every MAXB > 4
+//                 variant, and the eight-wave two-blocks-per-thread kernel when it runs a trotting h = 16 robot on half a CU (MINW = 4)
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0, bool H16 = (MAXB > 4)>
 __global__ __launch_bounds__(NTHR, (MINW ? MINW : ((MAXB <= 4 && !LIST && !BIG) ? (NTHR >= 384 ? 4 : QR_MAIN_WAVES_PER_SIMD) : (NTHR >= 512 ? 2 : 1))))
 void qr_mpc_kernel(MpcLaunch P, MpcIO io)
 {
@@ -1853,7 +1898,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         int cnt = planned ? P.pre_count[P.rescue_parity] : P.rescue_count[P.rescue_parity];
         cnt = cnt < P.n ? cnt : P.n;
         for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-            mpc_solve_robot<MAXB, BIG, NTHR>(P, io, list[e], smem);
+            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, list[e], smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
         if (QR_P_TL && threadIdx.x == 0 && P.rescue_mode == 1) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 6, wall_clock64());
@@ -1896,7 +1941,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                 __syncthreads();                       // (every wave's hand-over stores are out before wave 0 can tell anybody)
             }
             if ((int)blockIdx.x >= cnt) { tell_done(); return; }
-            mpc_solve_robot<MAXB, BIG, NTHR>(P, io, P.pre_list[blockIdx.x], smem);
+            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, P.pre_list[blockIdx.x], smem);
             tell_done();                               // (wave 0 is the last to return from the solve and the one that stored its results)
             return;
         }
@@ -1909,7 +1954,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
         // solved by the planned list launch, beside this one -- unless that launch's gate gave up waiting for this one's stream (plan_abort)
         if (P.skip && P.skip[rid] && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) return;
-        mpc_solve_robot<MAXB, BIG, NTHR>(P, io, rid, smem);
+        mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, rid, smem);
     }
 }
 
@@ -1970,6 +2015,8 @@ template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);   
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);   // h <= 16, four waves within 256 registers: two workgroups per CU (QRGPU_H16_TWO)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
+template __global__ void qr_mpc_kernel<2, false, false, 512, 4, true>(MpcLaunch, MpcIO);
+template __global__ void qr_mpc_kernel<2, true, false, 512, 4, true>(MpcLaunch, MpcIO);   // h <= 16 two to a CU: a trotting robot (<= 42 stance leg-steps) on eight waves within 128 registers
 template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);      // h <= 11, planned list: one robot per workgroup, whole CU's LDS, 96 rows, eight waves build and sweep
 
 #ifndef QR_FLOPS_BUILD

@@ -24,11 +24,13 @@ struct MpcIO {
     int force_stride;
     long long *dbgT;
 };
-template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0, bool H16 = (MAXB > 4)> __global__ void qr_mpc_kernel(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<2, true, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<2, true, false, 512, 4, true>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<2, false, false, 512, 4, true>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
@@ -39,11 +41,13 @@ extern template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, M
 extern template __global__ void qr_mpc_persist_kernel<9, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_persist_kernel<9, true, 256, 2>(MpcLaunch, MpcIO);
 // the same kernels with the executed-arithmetic counters compiled in (qr_mpc_kernel_fl.hip)
-template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
+template <int MAXB, bool BIG, bool LIST, int NTHR, int MINW = 0, bool H16 = (MAXB > 4)> __global__ void qr_mpc_kernel_fl(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<4, false, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<4, true, true, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<2, true, false, 512, 4, true>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel_fl<2, false, false, 512, 4, true>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
@@ -88,6 +92,8 @@ static const void *mpc_fn(int var, bool fl)
     case 9: return (const void *)qr_mpc_persist_kernel<9, true, 256>;       // persistent form of 1
     case 10: return fl ? (const void *)qr_mpc_kernel_fl<9, true, false, 256, 2> : (const void *)qr_mpc_kernel<9, true, false, 256, 2>;   // 1 within 256 registers (two per CU)
     case 11: return (const void *)qr_mpc_persist_kernel<9, true, 256, 2>;   // persistent form of 10
+    case 13: return fl ? (const void *)qr_mpc_kernel_fl<2, false, false, 512, 4, true> : (const void *)qr_mpc_kernel<2, false, false, 512, 4, true>;   // ... 64 working-set positions
+    case 12: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512, 4, true> : (const void *)qr_mpc_kernel<2, true, false, 512, 4, true>;   // h <= 16 two to a CU on eight waves
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
 }
@@ -96,7 +102,7 @@ static const void *mpc_fn(int var, bool fl)
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
     static std::mutex mu;
-    static int configured[16][2][12];          // [device][counting build][variant], zero-initialised
+    static int configured[16][2][14];          // [device][counting build][variant], zero-initialised
     std::lock_guard<std::mutex> lk(mu);
     int &have = configured[c->device & 15][fl ? 1 : 0][var];
     if (have >= bytes) return QRGPU_OK;
@@ -530,16 +536,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const bool tiny = small && n < 64 && !dH && tiny_whole_cu != 0;
     if (tiny) P.lds_bytes = c->lds_per_cu;
     // rescue pass for the h <= 11 main pass (not for inspection launches or tiny batches)
-    // h > 11, batches of 3.5 robots per CU and more (QRGPU_H16_TWO=0: never, =2: from 64 robots on): the main pass runs TWO four-wave workgroups per
-    // CU on half the LDS each, through a build of the four-wave kernel that keeps within 256 registers (<9, BIG, ., 256, 2>: under the default of
-    // one wave per SIMD the compiler takes AGPRs on top of the 256 VGPRs and two workgroups never share a CU -- what the first attempts at this
-    // measured without knowing).  A trotting robot's inverse Hessian (40 stance leg-steps at h = 16: 59 KB) fits; S^-1 of every robot of the main
-    // pass lives in the global scratch (qcap 96 whatever the LDS holds: nobody outgrows the main pass unannounced).  On whole CUs beside the main
-    // pass, one robot per eight-wave workgroup (planned list): the robots whose inverse Hessian does not fit half a CU (three-leg and all-stance
-    // gaits: a class known from the gait table, 10 % of the mixed shard) and the tick's long poles -- robots whose smoothed cost says 450 us
-    // and more two to a CU (60-80 active rows over the spilled S^-1), which stay listed while they cost 300 us and more on a whole CU.
-    // Mixed h = 16 shard: 1.37 -> 1.45 M ticks/s at 1024 robots, 1.46 -> 1.68 M at 2048, 1.50 -> 1.76 M at 8192; below 3.5 robots per CU one
-    // workgroup per CU is faster (1.27 against 1.17 M at 768: fewer rounds than slots).
+    // h > 11, batches of 3.5 robots per CU and more (QRGPU_H16_TWO=0: never, =2: from 64 robots on): the main pass runs TWO workgroups per CU on half
+    // the LDS each.  A trotting robot's inverse Hessian (<= 42 stance leg-steps at h = 16: <= 65 KB) fits, and its 903 blocks are two per thread
+    // of the EIGHT-wave build and sweep of the h <= 11 main pass -- <2, BIG, ., 512, 4, H16>, within 128 registers (four waves leave after the
+    // sweep; QRGPU_H16_TWO_WAVES=4: the four-wave kernel within 256 registers, <9, BIG, ., 256, 2> -- under that kernel's default of one wave
+    // per SIMD the compiler takes AGPRs on top of the 256 VGPRs and two workgroups never share a CU, which is what the earlier attempts at
+    // this measured without knowing).  S^-1 of every robot of the main pass lives in the global scratch (qcap 96 whatever the LDS holds: nobody
+    // outgrows the main pass unannounced).  On whole CUs beside the main pass, one robot per eight-wave 256-register workgroup (planned list):
+    // the robots whose inverse Hessian does not fit half a CU (three-leg and all-stance gaits: a class known from the gait table, 10 % of the
+    // mixed shard) and the tick's long poles -- robots whose smoothed cost says 450 us and more two to a CU (60-80 active rows over the
+    // spilled S^-1), which stay listed while they cost 300 us and more on a whole CU.
+    // Mixed h = 16 shard, one workgroup per CU -> four waves two to a CU -> eight waves two to a CU: 1.37 -> 1.45 -> 1.52 M ticks/s at 1024
+    // robots, 1.45 -> 1.68 -> 1.83 M at 2048, 1.50 -> 1.76 -> 1.97 M at 8192; below 3.5 robots per CU one workgroup per CU is faster (1.28
+    // against 1.18 M at 768: fewer rounds than slots).
     static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
     const bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2);
     if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
@@ -589,7 +598,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
     static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
-    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (two ? 10 : (h16_threads == 256 ? 1 : 0)));
+    static const int two_waves = [] { const char *e = getenv("QRGPU_H16_TWO_WAVES"); return e ? atoi(e) : 8; }();
+    const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (two ? (two_waves == 8 ? 12 : (two_waves == 9 ? 13 : 10)) : (h16_threads == 256 ? 1 : 0)));
     const int list_var = small ? 4 : 8;             // striding list kernel (trailing launch, long planned lists)
     const int one_var = small ? 5 : 0;              // one listed robot per whole-CU eight-wave workgroup
     // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
@@ -727,7 +737,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         const dim3 grid(main_grid);
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
-        const int threads = (var == 3 || var == 0 || var == 5) ? 512 : 256;
+        const int threads = (var == 3 || var == 0 || var == 5 || var == 12 || var == 13) ? 512 : 256;
         HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
