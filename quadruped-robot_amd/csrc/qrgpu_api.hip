@@ -550,7 +550,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // robots, 1.45 -> 1.68 -> 1.83 M at 2048, 1.50 -> 1.76 -> 1.97 M at 8192; below 3.5 robots per CU one workgroup per CU is faster (1.28
     // against 1.18 M at 768: fewer rounds than slots).
     static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
-    const bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2);
+    // (it needs the list launches -- a robot of the big class has nowhere else to go -- and the cost words that carry the plan)
+    const bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && lpt;
     if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
     const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;

@@ -206,6 +206,15 @@ def test_full_tick_h16_1024_two_workgroups_per_cu(pkg, oracle):
             assert ctx._lib.qrgpu_debug_lists(ctx._h, lists.ctypes.data) == 0
         assert lists[2] > 0 and lists[3] > 0, lists            # the planned list, both parities
         assert lists[0] == 0 and lists[1] == 0, lists          # nobody handed to the trailing launch
+        # without the list launches, the plan or the cost words there is nowhere for the big class to go: the batch runs one workgroup per CU again
+        for off in (lambda: ctx.set_planned_list(False), lambda: ctx.set_rescue_pass(False), lambda: ctx.set_lpt_schedule(False)):
+            off()
+            for tick in range(2):
+                out = G.run_tick(ctx, pkg, b, type_id=tid)
+                assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
+                assert np.all(np.abs(out["force"] - f).max(1) <= 1e-5 * np.maximum(1.0, np.abs(f).max(1)))
+                assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), np.abs(out["tau"] - tau).max()
+            ctx.set_planned_list(True); ctx.set_rescue_pass(True); ctx.set_lpt_schedule(True)
     finally:
         ctx.close()
 
