@@ -475,7 +475,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     const int nls = __builtin_amdgcn_readfirstlane(sMisc[0]);
     const int ns = 3 * nls;
     const int npairs = tri(nls);
-    double *Sinv = Mb + npairs * 9;
+    // (the eight-wave h > 11 kernel that runs two to a CU keeps S^-1 of every robot in the global scratch: typed as a global pointer its accesses are
+    //  global_* with a scalar base and a 32-bit offset instead of flat_* on 64-bit addresses -- the generic pointer of the other H16 variants costs
+    //  44 spilled VGPRs within 128 registers)
+    constexpr bool SG = H16 && MAXB <= 4;
+    typedef __attribute__((address_space(1))) double gdouble;
+    typedef typename std::conditional<SG, gdouble *, double *>::type SinvPtr;
+    SinvPtr Sinv = (SinvPtr)(Mb + npairs * 9);
     // BIG at a horizon whose phase 0-2 float arrays are too small for the second half of the r exchange (h < 14): 256 doubles at the very
     // end of the workgroup's LDS
     const bool xr2_in_floats = (100 + 29 * h) * 4 >= 2048;
@@ -496,7 +502,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         // (the pointer is then generic and the S^-1 accesses of these variants compile to flat_* instructions: a few per cent at
         // h = 16, nothing at h <= 11 whose variants never take this branch)
         const int want = ns < QMAX ? ns : QMAX;
-        if (P.sinv_spill && m_fits && qcap < want && qcap < 64) { Sinv = P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH); qcap = want; spilled = true; }
+        if constexpr (SG) {
+            if (P.sinv_spill && m_fits) { Sinv = (SinvPtr)(P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH)); qcap = want; spilled = true; }
+            else qcap = 0;                      // (to the list launches, below)
+        } else {
+            if (P.sinv_spill && m_fits && qcap < want && qcap < 64) { Sinv = (SinvPtr)(P.sinv_spill + (size_t)rid * (size_t)tri(QR_QH)); qcap = want; spilled = true; }
+        }
     }
     // What is left behind S^-1 caches W_A = M N_A, one 3*nls vector per working-set position (the `w` of the iteration that added it),
     // so that z = w - W_A r needs no block products.  qW positions fit; the solve falls back to z = w - M (N_A r) for good once the
