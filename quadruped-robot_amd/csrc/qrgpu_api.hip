@@ -551,7 +551,18 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // against 1.18 M at 768: fewer rounds than slots).
     static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
     // (it needs the list launches -- a robot of the big class has nowhere else to go -- and the cost words that carry the plan)
-    const bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && lpt;
+    bool two = !small && h16_two != 0 && !dH && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && lpt;
+    if (two) {
+        // A shard in which most robots stand is a list, not a main pass: all stance is the class that cannot share a CU, and 1024 of them strided over by
+        // the planned launch's workgroups (parked waves, three quarters of the CUs) run at 0.59 M ticks/s against 0.94 M one workgroup per CU
+        // (60 % standing: 1.16 against 1.29 M; 30 %: 1.96 against 1.56 M; scratch/ab_h16_stand.py).  So when the list the host last saw is more
+        // than 45 % of the batch the calls go back to one workgroup per CU for 31 calls; nobody plans meanwhile, so the call after them runs two
+        // to a CU whatever the old count says (on the old plan: consistent, if stale) and the one after that decides on the fresh count.
+        static const int hold_calls = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
+        if (c->two_hold > 0) { --c->two_hold; two = false; }
+        else if (c->two_probe) c->two_probe = false;
+        else if (hold_calls > 0 && c->plan_n == n && 20 * (long long)c->h_pre_count[c->rescue_parity] > 9 * (long long)n) { c->two_hold = hold_calls; c->two_probe = true; two = false; }
+    }
     if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
     const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;
@@ -669,7 +680,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
         // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
-        const int g3_cap = two ? 3 * c->num_cu / 4 : c->num_cu;
+        // (... unless most of the batch is listed -- a shard of standing robots: then the list is the launch, and it gets every CU)
+        const int g3_cap = (two && 2 * c->h_pre_count[c->rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
         const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && c->h_pre_count[c->rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
         // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
         // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and

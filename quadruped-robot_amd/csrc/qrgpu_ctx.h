@@ -66,6 +66,8 @@ struct qrgpu_ctx {
     int last_rescue_parity = 0;
     int *d_qhead = nullptr;                   // [2][8] queue heads of the persistent main pass, ping-pong (a launch zeroes the other half)
     int qhead_parity = 0;
+    int two_hold = 0;                         // h > 11 two to a CU: calls left on one workgroup per CU after the planned list outgrew 45 % of the batch
+    bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
     int *d_tick_done = nullptr;               // pipelined ticks complete (bumped by their joins), ever: what qrgpu_allgather_tau_of_tick's gate polls

@@ -219,6 +219,29 @@ def test_full_tick_h16_1024_two_workgroups_per_cu(pkg, oracle):
         ctx.close()
 
 
+def test_h16_standing_shard_goes_back_to_one_workgroup_per_cu_and_returns(pkg, oracle):
+    """h = 16, 1024 robots that all stand: all stance is the class that cannot share a CU, so the planned list is the whole batch and the calls go
+    back to one workgroup per CU (31 calls, then one call two to a CU on the old plan to get a fresh one, and so on); when the robots start to
+    trot the calls return to two workgroups per CU.  Every tick of both phases -- across the switches, the stale plans and the probes -- against
+    the threaded oracle."""
+    h, n = 16, 1024
+    ctx = pkg.Context(0, n, h)
+    try:
+        G.setup_a1(ctx, pkg, h)
+        for phase, kw, ticks in (("standing", dict(frac_all_stance=1.0, frac_three_leg=0.0), 40), ("trotting", dict(frac_all_stance=0.0, frac_three_leg=0.0), 72)):
+            b = pkg.make_batch(n, h, "a1", seed=1611, **kw)
+            f, tau, st = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"], b["gait"],
+                                           b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=8)[:3]
+            assert np.all(st == 0)
+            for tick in range(ticks):
+                out = G.run_tick(ctx, pkg, b)
+                assert np.all(G.flags(out["status"]) == 0), (phase, tick, np.unique(G.flags(out["status"])))
+                assert np.all(np.abs(out["force"] - f).max(1) <= 1e-5 * np.maximum(1.0, np.abs(f).max(1))), (phase, tick)
+                assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), (phase, tick, np.abs(out["tau"] - tau).max())
+    finally:
+        ctx.close()
+
+
 def test_full_tick_1024_with_projection_and_motor_tail(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[2] at full size: 1024 A1 robots, h = 10, the whole tick of SURVEY 8(d) -- K12 (kinematic projection) on and
     the K14 motor tail (abad +-0.9 N m, +-23 N m clip) applied -- every robot against the threaded oracle."""
