@@ -809,7 +809,9 @@ def main():
                                         ("; torch.distributed (gloo, CPU) for the launcher's barrier / max-reduce / id hand-over" if world > 1 else "; torch not imported"),
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "status_flags_nonzero_per_draw": draw_flags, "max_active_set_changes_per_draw": draw_itmax,
-                       "dispatch": "longest-first from each robot's solve time of the previous steps, smoothed (running mean, weight 1/2: a prediction -- consecutive steps see different batches)",
+                       "dispatch": "longest-first from each robot's solve time of the previous steps, smoothed (running mean, weight 1/2: a prediction -- consecutive steps see different batches)"
+                                   + ("; h > 11 from 3.5 robots per CU on: two workgroups per CU for robots whose inverse Hessian fits half a CU's LDS, the others and the "
+                                      "tick's long poles (by that smoothed cost) on whole CUs beside them (QRGPU_H16_TWO)" if h > 11 and n >= 896 else ""),
                        "tick_form": "pipelined: the WBC launch of a tick runs on a stream of the context's own beside that tick's MPC launches and takes each robot's "
                                     "forces when its solve raises the robot's flag (qrgpu_set_tick_pipeline, default); outputs complete in stream order as before",
                        **side},
