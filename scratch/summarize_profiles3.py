@@ -10,9 +10,10 @@ ks = max(glob.glob(os.path.join(src, "prof", "*", "*_kernel_stats.csv")), key=os
 shutil.copy(ks, "profiles/%s_rocprofv3_kernel_stats.csv" % pre)
 NAMES = {"mpc_main": "qr_mpc_kernel", "wbc": "qr_wbc_kernel"}
 def key(k):
-    if "qr_mpc_kernel<2, false, false, 512>" in k: return "mpc_main"
-    if "qr_mpc_kernel<4, true, true, 256>" in k: return "mpc_list"
-    if "qr_mpc_kernel<2, true, false, 512>" in k: return "mpc_planned"
+    # (template arguments beyond the fourth -- MINW, H16 -- are at their defaults in these three)
+    if "qr_mpc_kernel<2, false, false, 512, 0" in k or "qr_mpc_kernel<2, false, false, 512>" in k: return "mpc_main"
+    if "qr_mpc_kernel<4, true, true, 256" in k: return "mpc_list"
+    if "qr_mpc_kernel<2, true, false, 512, 0" in k or "qr_mpc_kernel<2, true, false, 512>" in k: return "mpc_planned"
     if "qr_wbc_kernel" in k: return "wbc"
     return None
 summ = {}
