@@ -583,12 +583,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.pre_hint = planned ? c->d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
-    if (two && P.big_nls == 0) {
+    if (two) {
         // the class that cannot be solved on half a CU: stance leg-steps whose block-packed inverse Hessian does not fit the main pass's LDS
         const long long room = (long long)P.lds_bytes - (long long)mpc_lds_fixed_bytes(P.horizon, true);
         int k = 1;
         while (k <= 4 * P.horizon && (long long)k * (k + 1) / 2 * 72 <= room) ++k;
-        P.big_nls = k;
+        if (k > 45) k = 45;                 // (and the eight-wave kernel holds two blocks per thread: 1024 >= tri(44))
+        if (P.big_nls <= 0 || P.big_nls > k) P.big_nls = k;        // (a caller's own, stricter class rule stands: qrgpu_set_planned_list)
     }
     { static const int bm = [] { const char *e = getenv("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = two ? -1000 : bm; }
     P.big_cost = P.big_cost_stay = 0; P.planned_stride = 0;

@@ -219,6 +219,28 @@ def test_full_tick_h16_1024_two_workgroups_per_cu(pkg, oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("h", [12, 13, 14])
+def test_full_tick_two_workgroups_per_cu_other_horizons(pkg, oracle, h):
+    """The h > 11 main pass two to a CU at the horizons between the two the bench runs: below h = 14 the 96-position kernels keep the second half
+    of the r exchange in 256 doubles at the end of the workgroup's LDS (here: of HALF a CU's), and the class that cannot share a CU starts at a
+    different stance count at every horizon.  1024 A1 robots of every gait, three ticks (no plan, the plan coming, planned), all against the oracle."""
+    n = 1024
+    ctx = pkg.Context(0, n, h)
+    try:
+        G.setup_a1(ctx, pkg, h)
+        b = pkg.make_batch(n, h, "a1", seed=1620 + h)
+        f, tau, st = oracle.tick_batch(1, pkg.mpc_cfg("a1"), h, pkg.model_desc("a1")[:3], pkg.model_desc("a1"), b["mpc_state"], b["traj"], b["gait"],
+                                       b["fb_state"], b["wbc_cmd"], b["prev_ori_vel"].copy(), nthreads=8)[:3]
+        assert np.all(st == 0)
+        for tick in range(3):
+            out = G.run_tick(ctx, pkg, b)
+            assert np.all(G.flags(out["status"]) == 0), (tick, np.unique(G.flags(out["status"])))
+            assert np.all(np.abs(out["force"] - f).max(1) <= 1e-5 * np.maximum(1.0, np.abs(f).max(1))), tick
+            assert np.all(np.abs(out["tau"] - tau) <= G.tau_tol(tau, 1e-4)), (tick, np.abs(out["tau"] - tau).max())
+    finally:
+        ctx.close()
+
+
 def test_h16_standing_shard_goes_back_to_one_workgroup_per_cu_and_returns(pkg, oracle):
     """h = 16, 1024 robots that all stand: all stance is the class that cannot share a CU, so the planned list is the whole batch and the calls go
     back to one workgroup per CU (31 calls, then one call two to a CU on the old plan to get a fresh one, and so on); when the robots start to
