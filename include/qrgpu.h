@@ -163,12 +163,16 @@ int  qrgpu_set_warm_start(qrgpu_ctx *ctx, int on);
  * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling only: which launch solves a robot does not change its result.
  * The host learns the list's length through pinned memory without a sync; so that a caller which queues calls faster than the GPU runs
  * them still gets its first plans, the first two batched calls after the history was reset (a new n, qrgpu_set_lpt_schedule) end with a
- * hipStreamSynchronize on the context's stream.  Every later call stays asynchronous. */
+ * hipStreamSynchronize on the context's stream.  Every later call stays asynchronous.
+ * At h > 11 and 3.5 robots per CU or more the main pass runs two workgroups per CU on half the LDS each, and the list is also where the robots
+ * go whose inverse Hessian does not fit half a CU (43 stance leg-steps and more at h = 16; a smaller big_nls of the caller's stands) and those
+ * whose solves are the longest of the tick; with the planned list, the rescue pass or the longest-first schedule switched off such batches
+ * run one workgroup per CU.  Scheduling only, here too. */
 int  qrgpu_set_planned_list(qrgpu_ctx *ctx, int on, int big_nls);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
  * Hessian at h = 10 leaves room for 56 rows): they are re-solved by the same kernel with the whole CU's LDS in a second, normally
- * empty launch, at most 64 robots per call (the rest keep QRGPU_ST_MPC_OVERFLOW), h <= 11 only (at h = 16 such robots keep S^-1 in a global scratch instead).
+ * empty launch, at most 64 robots per call (the rest keep QRGPU_ST_MPC_OVERFLOW), h <= 11 and the two-workgroups-per-CU main pass of h > 11 (otherwise at h = 16 such robots keep S^-1 in a global scratch instead).
  * A robot nothing can hold keeps QRGPU_ST_MPC_OVERFLOW. */
 int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
 /* Pipelined tick (default on; batches of 64 robots and more): qrgpu_tick_batch queues its WBC launch on a stream of the context's own
