@@ -198,10 +198,13 @@ int qrgpu_wbc_setup(qrgpu_ctx *ctx, int type_id, const qrgpu_model_desc *desc);
  *   QRGPU_HESSIAN_BF16X3  BASELINE.json configs[4] ("fp32 QP + bf16 Hessian MFMA"): every fp32 operand cut into three bf16 limbs, the six
  *                         leading cross products per term summed in fp32 by v_mfma_f32_16x16x32_bf16.  H comes out within an ulp or two of the
  *                         exact fp32 assembly (measured 7.5e-9 absolute: the size of the exact H's own asymmetry) but not bit-identical, and on
- *                         this QP an ulp of H is amplified by 1 / (2 alpha): forces move as they do between the reference's own answers for H
- *                         and H^T.  Stated tolerance against the default mode (tests/test_gpu_mpc.py::test_bf16x3_hessian): median force
- *                         deviation <= 1e-4 of the force scale; worst robot <= 2e-3 (forces) / 5e-2 max(1, |tau|) at h = 10 and 3e-2 / 0.3 at h = 16.
- *                         Slower than the default here (the limb cuts dominate); it exists because that configuration names it. */
+ *                         this QP an ulp of H is amplified by 1 / (2 alpha), so the mode states ANOTHER QP, a rounding away, and solves that
+ *                         one exactly: forces within 1e-5 max(1, |f|) and full-tick torque within 1e-4 max(1, |tau|) of the CPU oracle's solve
+ *                         of the very (H, g) this mode assembles, every robot of the configs[4] per-GPU shard
+ *                         (tests/test_gpu_mpc.py::test_bf16x3_solve_vs_oracle_on_its_own_hessian).  Against the default mode's answer the
+ *                         forces move as the reference's own do between H and H^T.  The default stays QRGPU_HESSIAN_F32 for every
+ *                         configuration, configs[4] included: it is bit-exact against the reference's fp32 GEMM AND faster here (the limb
+ *                         cuts dominate the operand generation); this mode exists because that configuration names it. */
 #define QRGPU_HESSIAN_F32    0
 #define QRGPU_HESSIAN_BF16X3 1
 int qrgpu_mpc_set_hessian_mode(qrgpu_ctx *ctx, int mode);

@@ -153,6 +153,16 @@ def mpc_solve(cfg, horizon, state28, traj, gait, literal=False):
     return u, dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])), rc
 
 
+def mpc_solve_hg(cfg, horizon, gait, H, g):
+    """The stated QP solved from a given fp32 (H, g) (whatever assembled them) with the bounds / friction rows of `gait` and `cfg`.  -> u, stats, rc"""
+    n = 12 * horizon
+    u = np.zeros(n); st = np.zeros(4, np.int32)
+    H = np.ascontiguousarray(H, _f); g = np.ascontiguousarray(g, _f); gait = np.ascontiguousarray(gait, _f)
+    assert H.shape == (n, n) and g.shape == (n,)
+    rc = lib().qro_mpc_solve_hg(_fp(cfg), horizon, _fp(gait), _fp(H), _fp(g), _dp(u), _ip(st))
+    return u, dict(iters=int(st[0]), adds=int(st[1]), drops=int(st[2]), n_active=int(st[3])), rc
+
+
 def mpc_force_to_torque(geom, quat, q12, f12):
     tau = np.zeros(12, _f)
     lib().qro_mpc_force_to_torque(_fp(np.ascontiguousarray(geom, _f)), _fp(np.ascontiguousarray(quat, _f)),

@@ -190,6 +190,29 @@ int qro_mpc_solve(const float *cfg, int horizon, const float *state28, const flo
     return rc;
 }
 
+// The stated QP of qr_mpc_interface.cpp:396-438 solved from a GIVEN (H, g) -- fp32, n x n row-major and n, as any assembly left them (the
+// kernel's bf16-limb Hessian mode of BASELINE configs[4] among them: tests/test_gpu_mpc.py) -- instead of the oracle's own assembly.
+// Bounds and friction rows come from the gait table and the configuration exactly as mpc_assemble sets them (:222-240, :386-389); entries of
+// H / g that belong to swing variables are never read (mpc_solve_qp eliminates them), so they may hold anything.
+int qro_mpc_solve_hg(const float *cfg, int horizon, const float *gait, const float *H, const float *g, double *u, int *stats)
+{
+    MpcConfig c = unpack_cfg(cfg, horizon);
+    MpcAssembly a;
+    a.n = 12 * horizon; a.m = 20 * horizon;
+    a.H.assign(H, H + (size_t)a.n * a.n);
+    a.g.assign(g, g + a.n);
+    a.ub.assign(a.m, 0.f);
+    for (int k = 0; k < 4 * horizon; ++k) {
+        for (int r = 0; r < 4; ++r) a.ub[5 * k + r] = 5e10f;
+        a.ub[5 * k + 4] = gait[k] * c.fmax;
+    }
+    a.invmu = 1.f / c.mu;
+    QpStats st;
+    int rc = mpc_solve_qp(a, gait, horizon, u, &st);
+    pack_stats(st, stats);
+    return rc;
+}
+
 void qro_mpc_force_to_torque(const float *geom3, const float *quat, const float *q12, const double *f12, float *tau12)
 {
     LegGeom g; g.hip_l = geom3[0]; g.upper_l = geom3[1]; g.lower_l = geom3[2];

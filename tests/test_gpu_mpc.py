@@ -441,45 +441,58 @@ def test_plan_survives_single_robot_and_small_calls_in_between(gpu_ctx, pkg, ora
         gpu_ctx.set_warm_start(True)
 
 
-def test_bf16x3_hessian(gpu_ctx, pkg, oracle):
-    """BASELINE.json configs[4]'s arithmetic ("fp32 QP + bf16 Hessian MFMA") in small: horizon 16, A1 and Lite3 interleaved, the Hessian
-    contraction on v_mfma_f32_16x16x32_bf16 with three bf16 limbs per fp32 operand.  What this mode guarantees, and what it cannot:
-      * the assembled H is the exact fp32 assembly to the last bit or two: |dH| <= 4e-7 max|H| (measured 7.5e-9 absolute on typical robots, one ulp of the
-        largest entries -- the size of the exact H's own asymmetry H - H^T);
-      * but it is not bit-identical, and on this QP one ulp of H is amplified by 1 / (2 alpha) = 1.25e5: the forces move as they do between
-        the reference's own answers for H and H^T (tests/golden/parity_as_called.json: up to 2.5e-3 of the force scale and 4.5e-2 relative
-        torque at h = 16 on 19 rows).  Stated tolerance against the default mode: median force deviation <= 1e-4 of the force scale, worst
-        robot <= 3e-2 (forces) and 0.3 * max(1, |tau|) (torques) at h = 16; <= 2e-3 / 5e-2 at h = 10."""
+@pytest.mark.parametrize("h,n,mixed", [(10, 256, False), (16, 1024, True)])
+def test_bf16x3_solve_vs_oracle_on_its_own_hessian(gpu_ctx, pkg, oracle, h, n, mixed):
+    """BASELINE.json configs[4]'s arithmetic ("fp32 QP + bf16 Hessian MFMA"): the Hessian contraction of qr_mpc_interface.cpp:396-412 on
+    v_mfma_f32_16x16x32_bf16 with three bf16 limbs per fp32 operand, on the configs[4] per-GPU shard (512 A1 + 512 Lite3 interleaved, h = 16)
+    and on configs[1]'s size (256 A1, h = 10).  The mode is ANOTHER ROUNDING of H -- within an ulp or two of the exact fp32 assembly, not
+    bit-identical -- and an ulp of H is worth up to 1e-3 of force on this QP (alpha = 4e-6), so the comparator is not the f32 mode's answer but
+    the optimum of the QP that this mode states: the (H, g) the kernel assembled are downloaded and the ORACLE solves exactly that data
+    (oracle.mpc_solve_hg: the solve of :428-438 as the oracle states it; bounds and friction rows from the gait table).  Asserted for every robot:
+      * |dH| <= 4e-7 max|H| against the exact fp32 assembly, the gradient bit-identical (it stays on the fp32 vector path);
+      * forces  <= 1e-5 max(1, |f|max)  against the oracle's solve of the mode's own (H, g);
+      * full-tick K14 torque  <= 1e-4 max(1, |tau|)  against the oracle's tick tail fed with those oracle forces (north_star's bar)."""
+    gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+    gpu_ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h); gpu_ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
     try:
-        for h, mixed, ftol, ttol in ((10, False, 2e-3, 5e-2), (16, True, 3e-2, 0.3)):
-            n = 64
-            gpu_ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); gpu_ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
-            gpu_ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h); gpu_ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
-            ba = pkg.make_batch(n // 2, h, "a1", seed=601); bl = pkg.make_batch(n // 2, h, "lite3" if mixed else "a1", seed=602)
-            b = dict(ba)
-            for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
-                b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
-            b["n"] = n
-            tid = pkg.shard.interleave_types(n, 2) if mixed else np.zeros(n, np.int32)
-            with G.cold_start(gpu_ctx):
-                gpu_ctx.set_hessian_mode("f32")
-                exact = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
-                Hx, gx = G.run_assemble(gpu_ctx, pkg, b, type_id=tid)
-                gpu_ctx.set_hessian_mode("bf16x3")
-                split = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
-                Hs, gs = G.run_assemble(gpu_ctx, pkg, b, type_id=tid)
-            assert np.all(G.flags(split["status"]) == 0) and np.all(G.flags(exact["status"]) == 0)
-            differs = 0
-            for i in range(n):
-                m = np.isfinite(Hx[i])
-                assert np.array_equal(m, np.isfinite(Hs[i]))
-                assert np.abs(Hs[i][m].astype(np.float64) - Hx[i][m]).max() <= 4e-7 * np.abs(Hx[i][m]).max(), i
-                differs += not np.array_equal(Hs[i][m], Hx[i][m])
-                assert np.array_equal(gs[i][np.isfinite(gx[i])], gx[i][np.isfinite(gx[i])])     # the gradient stays on the fp32 vector path
-            assert differs > n // 2                                                  # (it really is another arithmetic)
-            fdev = np.abs(split["force"] - exact["force"]).max(1) / np.maximum(1.0, np.abs(exact["force"]).max(1))
-            assert np.median(fdev) <= 1e-4 and fdev.max() <= ftol, (h, np.median(fdev), fdev.max())
-            assert np.all(np.abs(split["tau"] - exact["tau"]) <= ttol * np.maximum(1.0, np.abs(exact["tau"]))), h
+        ba = pkg.make_batch(n // 2, h, "a1", seed=0xA1 + 4); bl = pkg.make_batch(n // 2, h, "lite3" if mixed else "a1", seed=0xA1 + 4 + 0xD2)
+        b = dict(ba)
+        for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+            b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+        b["n"] = n
+        tid = pkg.shard.interleave_types(n, 2) if mixed else np.zeros(n, np.int32)
+        gpu_ctx.set_torque_epilogue(hip_comp=True, clip=True)
+        with G.cold_start(gpu_ctx):
+            gpu_ctx.set_hessian_mode("f32")
+            Hx, gx = G.run_assemble(gpu_ctx, pkg, b, type_id=tid)
+            gpu_ctx.set_hessian_mode("bf16x3")
+            Hs, gs = G.run_assemble(gpu_ctx, pkg, b, type_id=tid)
+            out = G.run_tick(gpu_ctx, pkg, b, type_id=tid)
+        assert np.all(G.flags(out["status"]) == 0), np.unique(G.flags(out["status"]))
+        differs = 0
+        worst_f = worst_t = 0.0
+        for i in range(n):
+            robot = "a1" if tid[i] == 0 else "lite3"
+            cfg, md = pkg.mpc_cfg(robot), pkg.model_desc(robot)
+            m = np.isfinite(Hx[i])
+            assert np.array_equal(m, np.isfinite(Hs[i]))
+            assert np.abs(Hs[i][m].astype(np.float64) - Hx[i][m]).max() <= 4e-7 * np.abs(Hx[i][m]).max(), i
+            differs += not np.array_equal(Hs[i][m], Hx[i][m])
+            assert np.array_equal(gs[i][np.isfinite(gx[i])], gx[i][np.isfinite(gx[i])])
+            u, st, rc = oracle.mpc_solve_hg(cfg, h, b["gait"][i], Hs[i], gs[i])
+            assert rc == 0, (i, rc)
+            f_o = u[:12]
+            ef = np.abs(out["force"][i] - f_o).max() / max(1.0, np.abs(f_o).max())
+            worst_f = max(worst_f, ef)
+            assert ef <= 1e-5, (i, ef, st)
+            tau_o, _ = oracle.tick_from_forces(md[:3], md, b["fb_state"][i], b["wbc_cmd"][i], b["prev_ori_vel"][i], f_o, mode=1, epilogue=3)
+            et = np.abs(out["tau"][i] - tau_o) / np.maximum(1.0, np.abs(tau_o))
+            worst_t = max(worst_t, et.max())
+            assert np.all(et <= 1e-4), (i, et.max(), st)
+        assert differs > n // 2                                                      # (it really is another arithmetic)
+        print("bf16x3 h=%d n=%d: worst rel force %.2e, worst rel full-tick torque %.2e vs the oracle on the mode's own (H, g); %d of %d Hessians differ "
+              "from the exact fp32 assembly" % (h, n, worst_f, worst_t, differs, n))
     finally:
         gpu_ctx.set_hessian_mode("f32")
+        gpu_ctx.set_torque_epilogue(False, False)
         G.setup_a1(gpu_ctx, pkg, 10)

@@ -181,3 +181,35 @@ def test_leg_kinematics(oracle, pkg):
             dq = q.copy(); dq[3 * leg + j] += 1e-3
             num = (oracle.foot_positions(geom, hip, dq).astype(np.float64) - p0)[3 * leg:3 * leg + 3] / 1e-3
             assert np.abs(num - J[:, j]).max() < 2e-3
+
+
+def test_solve_from_given_hessian_and_gradient(oracle, pkg):
+    """mpc_solve_hg -- the checker of BASELINE configs[4]'s bf16-limb Hessian mode (tests/test_gpu_mpc.py::test_bf16x3_solve_vs_oracle_on_its_own_hessian):
+    the stated QP solved from a GIVEN fp32 (H, g).  Handed the oracle's own assembly it is mpc_solve bit for bit; entries of swing variables are
+    never read; another rounding of H (one ulp on every entry) gives that other QP's optimum -- which the compiled qpOASES confirms on the
+    symmetrised data when oracle/_ref is there."""
+    ref_ok = oracle.ref() is not None
+    for name, h, seed in (("a1", 10, 41), ("lite3", 16, 42)):
+        cfg = pkg.mpc_cfg(name)
+        b = pkg.make_batch(4, h, name, seed=seed)
+        for i in range(4):
+            s, traj, gait = b["mpc_state"][i], b["traj"][i], b["gait"][i]
+            H, g, ub = oracle.mpc_assemble(cfg, h, s, traj, gait)
+            u0, _, rc0 = oracle.mpc_solve(cfg, h, s, traj, gait)
+            u1, _, rc1 = oracle.mpc_solve_hg(cfg, h, gait, H, g)
+            assert rc0 == 0 and rc1 == 0 and np.array_equal(u0, u1)
+            free = np.repeat(gait > 0, 3)
+            Hn = H.copy(); gn = g.copy()
+            Hn[~free, :] = np.nan; Hn[:, ~free] = np.nan; gn[~free] = np.nan
+            u2, _, rc2 = oracle.mpc_solve_hg(cfg, h, gait, Hn, gn)
+            assert rc2 == 0 and np.array_equal(u0, u2)
+            # another rounding of H: every entry one ulp up
+            Hp = np.nextafter(H, np.float32(np.inf))
+            u3, _, rc3 = oracle.mpc_solve_hg(cfg, h, gait, Hp, g)
+            assert rc3 == 0 and np.all(np.isfinite(u3))
+            if ref_ok and i < 2:
+                Hs = 0.5 * (Hp.astype(np.float64) + Hp.astype(np.float64).T)
+                A = oracle.mpc_constraint_matrix(h, float(cfg[1]))
+                xq, info = oracle.ref_qpoases_mpc(Hs, g.astype(np.float64), A, np.zeros(20 * h), ub.astype(np.float64), nWSR=2000)
+                assert info["init_rc"] == 0
+                assert np.abs(xq - u3).max() <= 2e-6 * max(1.0, np.abs(u3).max()), (name, i, np.abs(xq - u3).max())
