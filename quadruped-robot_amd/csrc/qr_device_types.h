@@ -115,6 +115,18 @@ struct MpcLaunch {
     unsigned *done_flag;
     unsigned done_epoch;
     int *main_started;
+    // Overlapped ticks (qrgpu_set_tick_overlap): tick t + 1's launches run on another stream set and start in the slots tick t's drain leaves empty.
+    // What a robot carries from one solve to the next -- the warm-start words and the smoothed cost -- is handed over PER ROBOT: a solve stores
+    // them written through (sc1), waits for the stores and leaves its tick's epoch in solved[robot]; the robot's next solve polls that word for
+    // prev_epoch (bounded: 20 ms, then the robot starts cold and carries QRGPU_ST_PIPE_TIMEOUT -- the warm start is speed only) right before it
+    // reads the words, with loads of the same kind.  cost_in: the buffer the previous tick's solves wrote (the smoothing reads it; this tick
+    // writes `cost`, which the tick's trailing launch sorts while the NEXT tick's solves already write the other one).  All null / equal to
+    // `cost`: every other launch.
+    const int *cost_in;
+    unsigned *solved;
+    unsigned solved_epoch;
+    const unsigned *prev_solved;
+    unsigned prev_epoch;
 };
 #define QRGPU_ST_PIPE_TIMEOUT_D 0x02000000   // pipelined tick: the WBC gave up waiting for this robot's MPC forces (never seen; never silent)
 
@@ -200,6 +212,12 @@ struct WbcPipe {
     int *tlr;                   // diagnostic: [4][n] per robot, low word of the clock: WBC workgroup started, flag seen, done (last tick only), or null
     long long *tl;              // diagnostic (qrgpu_debug_timeline): [64 epochs][8] first / last moments of a tick's launches on the 100 MHz clock, or null
     const int *order;           // slot -> robot inside each XCD chunk: the robots in the order their solves ended in the last tick (MpcLaunch::ftime), or null
+    // Overlapped ticks: the orientation task's memory (g_prev, quirk 4) is the one thing a robot's WBC carries from tick to tick, and the second
+    // pass of tick t (its stream: the lane's) is not ordered against the first pass of tick t + 1 (the WBC stream).  So a workgroup leaves its
+    // tick's epoch in wbc_done[robot] behind its written-through g_prev, and -- wait_epoch != 0 -- polls that word for the previous tick's epoch
+    // (bounded, flagged) before it reads g_prev.  Null / 0: every other launch.
+    unsigned *wbc_done;
+    unsigned wait_epoch;
 };
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)

@@ -532,6 +532,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (tid == 0) {
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            else if (P.solved) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody solves it again this tick)
             if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
@@ -633,6 +634,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (tid == 0) {
             if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
             if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+            else if (P.solved) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody solves it again this tick)
             if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
@@ -1410,9 +1412,24 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         int refac = 0;                                    // re-factorisations spent on a failed exit check (at most two)
         int iter_at_rebuild = 0;                          // (periodic refresh of S^-1, below)
         unsigned char *warm = (P.warm && nls > 0) ? P.warm + (size_t)rid * QR_WARM_STRIDE : nullptr;
-        if (warm && warm[QR_WARM_STRIDE - 1] == (unsigned char)h) {
+        // Overlapped ticks: this robot's previous solve -- last tick's, on another stream set -- may still be running on another CU.  What it hands
+        // over (the warm-start words here, the cost word at the end) it stores written through and then raises solved[robot] to its epoch: poll
+        // for that (agent-scope loads; bounded at 20 ms of the 100 MHz clock: then the solve starts cold -- the guess is speed only -- and the
+        // robot carries QRGPU_ST_PIPE_TIMEOUT) and read the words with loads of the same kind.  Only this wave reads them.
+        const bool xtick = P.prev_solved != nullptr;
+        bool warm_ok = true;
+        if (xtick) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(P.prev_solved + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.prev_epoch) {
+                if (wall_clock64() - t0 > 2000000) { st |= QRGPU_ST_PIPE_TIMEOUT_D; warm_ok = false; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        auto warm_ld = [&](const unsigned char *p_) -> unsigned { return xtick ? (unsigned)__hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)*p_; };
+        if (warm && warm_ok && warm_ld(warm + QR_WARM_STRIDE - 1) == (unsigned)(unsigned char)h) {
             const unsigned long long cur = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
-            const unsigned long long old = *(const unsigned long long *)(warm + 64);
+            const unsigned long long old = xtick ? __hip_atomic_load((const unsigned long long *)(warm + 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : *(const unsigned long long *)(warm + 64);
             int sh = 0, best = 1 << 30;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1422,7 +1439,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (miss < best) { best = miss; sh = k; }
             }
             const int src = own ? sLs[kme] + 4 * sh : NL;
-            unsigned gm = (src < NL) ? (unsigned)warm[src] & 0x3fu : 0u;
+            unsigned gm = (src < NL) ? warm_ld(warm + src) & 0x3fu : 0u;
             // positions row-type-major: rows t of every leg-step, then rows t + 1 ...
             int base = 0;
             unsigned long long pk = 0;
@@ -1754,7 +1771,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (warm && !to_rescue) {                         // (a robot on its way to the list pass keeps last tick's guess for that pass)
             // this tick's final working set, by original leg-step, for the next tick of this robot slot (only a converged solve is worth it)
             const bool good = (st & 0xff) == 0;
-            warm[lane] = 0;
+            // (overlapped ticks: written through -- the robot's next solve may read them from another CU while this launch still runs)
+            auto warm_st = [&](unsigned char *p_, unsigned char v_) { if (P.solved) __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p_ = v_; };
+            warm_st(warm + lane, 0);
             wave_sync();
             unsigned keep = amask;
             if (P.warm_uthr > 0.0) {
@@ -1769,10 +1788,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     if (((amask >> t) & 1u) && !(ut > thr_u)) keep &= ~(1u << t);
                 }
             }
-            if (own && good) warm[sLs[kme]] = (unsigned char)keep;
+            if (own && good) warm_st(warm + sLs[kme], (unsigned char)keep);
             if (lane == 0) {
-                *(unsigned long long *)(warm + 64) = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
-                warm[QR_WARM_STRIDE - 1] = good ? (unsigned char)h : 0;
+                const unsigned long long tbl = ((unsigned long long)(unsigned)sMisc[3] << 32) | (unsigned)sMisc[2];
+                if (P.solved) __hip_atomic_store((unsigned long long *)(warm + 64), tbl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *(unsigned long long *)(warm + 64) = tbl;
+                warm_st(warm + QR_WARM_STRIDE - 1, good ? (unsigned char)h : (unsigned char)0);
             }
         }
         wave_sync();
@@ -1807,7 +1828,10 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // order from last tick's cost alone ends 10 us later than one from the running mean (scratch/analyze_predict.py)
             long long c = (clock64() - t_begin) >> 8;
             if (c > 0xffff) c = 0xffff;
-            if (P.cost_ema) c = (c + ((P.cost[rid] >> 16) & 0xffff) + 1) >> 1;
+            if (P.cost_ema) {
+                const int prevc = P.prev_solved ? __hip_atomic_load(P.cost_in + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.cost_in[rid];
+                c = (c + ((prevc >> 16) & 0xffff) + 1) >> 1;
+            }
             const int cfine = (int)c;
             c >>= 4;
             int big = 0;
@@ -1821,8 +1845,14 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 big = ((st & QRGPU_ST_MPC_OVERFLOW_D) || q + P.big_margin >= qcm || (P.big_nls > 0 && nls >= P.big_nls)
                        || (P.big_cost > 0 && cfine >= (P.rescue_mode == 0 ? P.big_cost : P.big_cost_stay))) ? 1 : 0;
             }
-            if (P.planned_done) __hip_atomic_store(P.cost + rid, (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.planned_done || P.solved) __hip_atomic_store(P.cost + rid, (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else P.cost[rid] = (c > 255 ? 255 : (int)c) | (big << 8) | (cfine << 16);
+        }
+        if (P.solved && !to_rescue) {
+            // overlapped ticks: the warm-start words and the cost word of this robot are on their way to memory (write-through stores of this
+            // very wave): wait for them, then tell the robot's next solve (a robot on its way to the list pass is told by that pass's solve)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         QR_TS(6);
 #if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
@@ -2058,12 +2088,14 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
 // fence in front of the next tick (qrgpu_allgather_fence) finds its gather already waited for and queues no launch of its own.
 // `tick_done` (or null) is bumped once the waits are over: the tick is complete in stream order -- the second WBC pass is ahead of this launch on
 // the stream -- which is what the all-gather of its torques polls for (qrgpu_allgather_tau_of_tick).
-__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done)
+// (`lane_done` / `lane_expect`, or null: an overlapped tick's launches on its lane's stream -- trailing list launch, second WBC pass -- are through.)
+__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
+                               int *lane_done, int lane_expect)
 {
     if (threadIdx.x != 0) return;
     auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
     long long t0 = wall_clock64();
-    while (!reached(counter, expected_total)) {
+    while (!reached(counter, expected_total) || (lane_done && !reached(lane_done, lane_expect))) {
         if (wall_clock64() - t0 >= max_ticks) { if (timed_out) { *timed_out = 1; __threadfence_system(); } return; }
         __builtin_amdgcn_s_sleep(16);
     }
@@ -2075,6 +2107,41 @@ __global__ void qr_join_kernel(int *counter, int expected_total, long long max_t
         __builtin_amdgcn_s_sleep(16);
     }
     if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The gate in front of an OVERLAPPED tick's launches (qrgpu_set_tick_overlap): tick t + 1 is queued on another stream set and may start in the
+// slots tick t's drain leaves empty -- but not before every workgroup of tick t's main pass has started (c0 / e0: the count the WBC launch's
+// gate polls too) and every workgroup of its planned launch (c1 / e1, or null): a workgroup of tick t + 1 waits, per robot, for that robot's
+// tick-t solve, and must never hold a slot that solve still needs to START.  Bounded; giving up is harmless (the per-robot waits are bounded
+// too, and a solve whose wait gives up starts cold and is flagged).
+__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
+    const long long t0 = wall_clock64();
+    while (!reached(c0, e0) || (c1 && !reached(c1, e1))) {
+        if (wall_clock64() - t0 >= max_ticks) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+// ... and the count its join polls: everything queued before this launch on the lane's stream is through.
+__global__ void qr_bump_kernel(int *counter)
+{
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Probe of qrgpu_set_tick_overlap: do two streams of this process run side by side?  `wait` spins until `flag` is set (by `set`, queued
+// afterwards on the other stream) or the bound passes, and says which in out[0].
+__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    int ok = 0;
+    while (!(ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+    out[0] = ok ? 1 : 2;
+}
+__global__ void qr_probe_set_kernel(int *flag)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

@@ -734,6 +734,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     real *qc0 = qu_ + 32;          // 32 constraint offsets
     real *qx = qc0 + 32;           // 18 z
     __shared__ int sI[64];         // active list of the QP
+    __shared__ int sPipe;          // overlapped ticks: wave 1's wait for the robot's previous WBC pass gave up (read by wave 0 behind the meeting barrier)
+    if (threadIdx.x == 0) sPipe = 0;
 
     // ---------------- load (wave 0: state, wave 1: commands) ----------------
     if (wv == 0) {
@@ -1076,7 +1078,22 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             if (fabs(theta) < 0.0000001) so3 = mk(0, 0, 0);
             else { const real sn = sin(theta / 2.0); so3 = (1.0 / sn) * so3; so3 = theta * so3; }
             // vel_err = Rot^T (desiredVel_prev - omega_body)   (quirk 4)
-            const v3 pv = mk((real)g_prev[(size_t)0 * n + rid], (real)g_prev[(size_t)1 * n + rid], (real)g_prev[(size_t)2 * n + rid]);
+            // (overlapped ticks: the robot's last WBC pass -- last tick's, possibly that tick's second pass on another stream -- leaves its epoch in
+            //  wbc_done[robot] behind its written-through g_prev: poll for it, bounded and flagged, and read g_prev with agent-scope loads)
+            if (pipe.wait_epoch) {
+                const long long t0 = wall_clock64();
+                int late = 0;
+                while (__hip_atomic_load(pipe.wbc_done + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pipe.wait_epoch) {
+                    if (wall_clock64() - t0 > 2000000) { late = 1; break; }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                if (lane == 0) sPipe = late;
+            }
+            auto prev_ld = [&](int i_) -> real {
+                const float *p_ = g_prev + (size_t)i_ * n + rid;
+                return (real)(pipe.wait_epoch ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_);
+            };
+            const v3 pv = mk(prev_ld(0), prev_ld(1), prev_ld(2));
             const v3 ve = mul(RotT, pv - mk(bv[0], bv[1], bv[2]));
             const real so[3] = {so3.x, so3.y, so3.z}, vev[3] = {ve.x, ve.y, ve.z};
 #pragma unroll
@@ -1334,8 +1351,14 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         if (lane < 12) cm[51 + lane] = (real)__hip_atomic_load(g_fr + (size_t)lane * n + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wsync();
     }
+    if (pipe.wait_epoch && ((volatile int *)&sPipe)[0]) pipe_st = QRGPU_ST_PIPE_TIMEOUT_D;
     wbc_qp_and_store(lane, rid, n, K, nc, cpack, bad_type, eq_dependent, A, JC, cm, W, sI, g_tau, g_status, merge_tau, status_or | (pipe_st ? 2 : 0), epilogue, dbgT, g_qp,
-                     pipe.flag != nullptr, g_prev);
+                     pipe.flag != nullptr || pipe.wbc_done != nullptr, g_prev);
+    if (pipe.wbc_done) {
+        // overlapped ticks: g_prev of this robot is on its way to memory (written through by this wave): wait, then tell the robot's next WBC pass
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(pipe.wbc_done + rid, pipe.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     wbc_signal_done(pipe.finished, lane);
     if (QW_P_TL && lane == 0) atomicMax(QW_P_TL + (pipe.epoch & 63u) * 8 + (pipe.second ? 7 : 4), wall_clock64());
     if (QW_P_TLR && lane == 0 && !pipe.second) QW_P_TLR[2 * n + rid] = (int)wall_clock64();

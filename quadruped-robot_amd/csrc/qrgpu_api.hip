@@ -52,7 +52,12 @@ extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256>(MpcLaunch,
 extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, MpcIO);
-__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done);
+__global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
+                               int *lane_done, int lane_expect);
+__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks);
+__global__ void qr_bump_kernel(int *counter);
+__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks);
+__global__ void qr_probe_set_kernel(int *flag);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -258,6 +263,46 @@ static hipError_t create_side_stream(hipStream_t *s)
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
+// A lane's buffers, counters and (lanes 1, 2) streams.  Counters start at zero and are never cleared.
+static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream)
+{
+    if (L.d_order) return QRGPU_OK;
+    const size_t nb = (size_t)c->max_batch;
+    auto zalloc = [](auto **p, size_t bytes) { return hipMalloc((void **)p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
+    bool ok = hipMalloc(&L.d_order, sizeof(int) * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (nb + 4)) &&
+              zalloc(&L.d_skip, nb) && hipHostMalloc((void **)&L.h_pre_count, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&L.d_pre_hint, L.h_pre_count, 0) == hipSuccess && zalloc(&L.d_started, sizeof(int)) &&
+              create_side_stream(&L.side_stream) == hipSuccess && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
+              zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) &&
+              hipMalloc(&L.d_cmd_tick, sizeof(float) * 12 * nb) == hipSuccess &&
+              hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
+    if (ok && own_stream) { ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess; L.own_stream = ok; }
+    if (ok) { L.h_pre_count[0] = L.h_pre_count[1] = L.h_pre_count[2] = L.h_pre_count[3] = 0; }       // ([2] of lane 0: a pipelined tick's join gave up waiting)
+    (void)hipDeviceSynchronize();          // (the fills went to the default stream: none of the context's streams waits for that one)
+    return ok ? QRGPU_OK : QRGPU_ERR_ALLOC;
+}
+static void lane_destroy(Lane &L)
+{
+    if (L.stream && L.own_stream) { (void)hipStreamSynchronize(L.stream); }
+    if (L.side_stream) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }
+    if (L.stream && L.own_stream) hipStreamDestroy(L.stream);
+    if (L.d_order) hipFree(L.d_order);
+    if (L.d_rescue) hipFree(L.d_rescue);
+    if (L.d_pre) hipFree(L.d_pre);
+    if (L.d_skip) hipFree(L.d_skip);
+    if (L.h_pre_count) hipHostFree(L.h_pre_count);
+    if (L.d_started) hipFree(L.d_started);
+    if (L.d_done_flag) hipFree(L.d_done_flag);
+    if (L.d_qhead) hipFree(L.d_qhead);
+    if (L.d_planned_done) hipFree(L.d_planned_done);
+    if (L.d_go) hipFree(L.d_go);
+    if (L.d_lane_done) hipFree(L.d_lane_done);
+    if (L.d_cmd_tick) hipFree(L.d_cmd_tick);
+    if (L.ev_fork) hipEventDestroy(L.ev_fork);
+    if (L.ev_join) hipEventDestroy(L.ev_join);
+    L = Lane{};
+}
+
 int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
 {
     if (!out || max_batch <= 0 || horizon_max <= 0 || horizon_max > QRGPU_MAX_HORIZON) return QRGPU_ERR_BAD_ARG;
@@ -294,37 +339,29 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
         stage_ok = hipMalloc(&c->d_in1, in1 * sizeof(float)) == hipSuccess && hipMalloc(&c->d_out1, 64 * sizeof(float)) == hipSuccess &&
                    hipMalloc(&c->d_st1, 4 * sizeof(int)) == hipSuccess;
     }
-    if (!stage_ok || hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) != hipSuccess ||
-        hipMalloc(&c->d_cmd_tick, sizeof(float) * 67 * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_order, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_cost, sizeof(int) * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_rescue, sizeof(int) * (size_t)(max_batch + 2)) != hipSuccess || hipMemset(c->d_rescue, 0, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_pre, sizeof(int) * (size_t)(max_batch + 4)) != hipSuccess || hipMalloc(&c->d_skip, (size_t)max_batch) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_pre_count, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void **)&c->d_pre_hint, c->h_pre_count, 0) != hipSuccess ||
-        hipMalloc(&c->d_started, sizeof(int)) != hipSuccess || hipMemset(c->d_started, 0, sizeof(int)) != hipSuccess ||
-        create_side_stream(&c->side_stream) != hipSuccess || hipStreamCreateWithFlags(&c->wbc_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_wbc_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_wbc_join, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&c->d_done_flag, sizeof(unsigned) * (size_t)max_batch) != hipSuccess || hipMemset(c->d_done_flag, 0, sizeof(unsigned) * (size_t)max_batch) != hipSuccess ||
-        hipMalloc(&c->d_main_started, sizeof(int)) != hipSuccess || hipMemset(c->d_main_started, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_qhead, 16 * sizeof(int)) != hipSuccess || hipMemset(c->d_qhead, 0, 16 * sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_tick_done, sizeof(int)) != hipSuccess || hipMemset(c->d_tick_done, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_planned_done, sizeof(int)) != hipSuccess || hipMemset(c->d_planned_done, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_go, 2 * sizeof(int)) != hipSuccess || hipMemset(c->d_go, 0, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_gate_abort, sizeof(int)) != hipSuccess || hipMemset(c->d_gate_abort, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_wbc_finished, sizeof(int)) != hipSuccess || hipMemset(c->d_wbc_finished, 0, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_ftime, sizeof(int) * (size_t)max_batch) != hipSuccess || hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * (size_t)max_batch) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    auto zalloc = [](auto **p, size_t bytes) { return hipMalloc((void **)p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
+    bool ok = stage_ok && hipMalloc(&c->d_wbc, sizeof(WbcConst) * QR_MAX_TYPES) == hipSuccess;
+    const size_t nb = (size_t)max_batch;
+    ok = ok && zalloc(&c->d_cost[0], sizeof(int) * nb) && zalloc(&c->d_cost[1], sizeof(int) * nb) && hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * nb) == hipSuccess &&
+         hipStreamCreateWithFlags(&c->wbc_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_wbc_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_wbc_join, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_ov_fence, hipEventDisableTiming) == hipSuccess &&
+         zalloc(&c->d_main_started, sizeof(int)) && zalloc(&c->d_tick_done, sizeof(int)) && zalloc(&c->d_gate_abort, QR_ABORT_RING * sizeof(int)) &&
+         zalloc(&c->d_wbc_finished, sizeof(int)) && zalloc(&c->d_solved, sizeof(unsigned) * nb) && zalloc(&c->d_wbc_done, sizeof(unsigned) * nb) &&
+         hipMalloc(&c->d_ftime, sizeof(int) * nb) == hipSuccess && hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * nb) == hipSuccess;
+    // lane 0 always; lanes 1 and 2 (streams of their own) when overlapped ticks are first switched on (qrgpu_set_tick_overlap)
+    ok = ok && lane_create(c, c->lane[0], false) == QRGPU_OK;
+    if (!ok) {
         qrgpu_destroy(c);
         return QRGPU_ERR_ALLOC;
     }
-    c->h_pre_count[0] = c->h_pre_count[1] = c->h_pre_count[2] = c->h_pre_count[3] = 0;       // ([2]: a pipelined tick's join gave up waiting)
     {   // The compute stream is the context's own (non-blocking) unless the caller names one (qrgpu_set_stream; NULL there = the default stream).  On the
         // default stream two contexts of one process serialise each other's launches: 16.9 against 34.7 M WBC calls/s for two contexts of 512 robots.
         // QRGPU_OWN_STREAM=0: rounds 1-3's default.
         static const int own = [] { const char *e = getenv("QRGPU_OWN_STREAM"); return e ? atoi(e) : 1; }();
         if (own && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess) c->stream = c->own_stream;
     }
+    c->lane[0].stream = c->stream;
     (void)hipDeviceSynchronize();          // (the fills of the counters above went to the default stream: none of the context's streams waits for that one)
     memset(&c->mpc, 0, sizeof(c->mpc));
     memset(c->wbc_host, 0, sizeof(c->wbc_host));
@@ -339,6 +376,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->wbc_stream) (void)hipStreamSynchronize(c->wbc_stream);
     qrgpu_comm_destroy(c);
+    for (int l = 0; l < QR_LANES; ++l) lane_destroy(c->lane[l]);         // (synchronises the lanes' own and side streams first)
     for (int k = 0; k < 2; ++k) for (auto &e : c->ev[k]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto &e : c->marks) hipEventDestroy(e);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -348,36 +386,26 @@ void qrgpu_destroy(qrgpu_ctx *c)
         if (c->d_st1) hipFree(c->d_st1);
     }
     if (c->d_wbc) hipFree(c->d_wbc);
-    if (c->d_cmd_tick) hipFree(c->d_cmd_tick);
-    if (c->d_order) hipFree(c->d_order);
-    if (c->d_cost) hipFree(c->d_cost);
-    if (c->d_rescue) hipFree(c->d_rescue);
+    if (c->d_cost[0]) hipFree(c->d_cost[0]);
+    if (c->d_cost[1]) hipFree(c->d_cost[1]);
     if (c->d_warm) hipFree(c->d_warm);
     if (c->d_flops) hipFree(c->d_flops);
-    if (c->d_pre) hipFree(c->d_pre);
-    if (c->d_skip) hipFree(c->d_skip);
-    if (c->h_pre_count) hipHostFree(c->h_pre_count);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->wbc_stream) hipStreamDestroy(c->wbc_stream);
     if (c->ev_wbc_fork) hipEventDestroy(c->ev_wbc_fork);
     if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
-    if (c->d_done_flag) hipFree(c->d_done_flag);
+    if (c->ev_ov_fence) hipEventDestroy(c->ev_ov_fence);
     if (c->d_main_started) hipFree(c->d_main_started);
     if (c->d_ftime) hipFree(c->d_ftime);
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
     if (c->d_gate_abort) hipFree(c->d_gate_abort);
-    if (c->d_go) hipFree(c->d_go);
+    if (c->d_solved) hipFree(c->d_solved);
+    if (c->d_wbc_done) hipFree(c->d_wbc_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     if (c->d_gather_done) hipFree(c->d_gather_done);
     if (c->d_tick_done) hipFree(c->d_tick_done);
-    if (c->d_planned_done) hipFree(c->d_planned_done);
-    if (c->d_qhead) hipFree(c->d_qhead);
     if (c->d_timeline) hipFree(c->d_timeline);
     if (c->d_tlr) hipFree(c->d_tlr);
     if (c->d_wbc_order) hipFree(c->d_wbc_order);
-    if (c->d_started) hipFree(c->d_started);
     if (c->d_sinv_spill) hipFree(c->d_sinv_spill);
     delete c;
 }
@@ -424,7 +452,7 @@ int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
     c->plan_n = 0;
     return QRGPU_OK;
 }
-int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; return QRGPU_OK; }
+int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; c->lane[0].stream = c->stream; c->ov_chain = false; return QRGPU_OK; }
 void *qrgpu_get_stream(qrgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
 const char *qrgpu_last_error(const qrgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
 int qrgpu_device_info(const qrgpu_ctx *c, char *name, int len, int *lds)
@@ -475,10 +503,15 @@ static int upload_wbc(qrgpu_ctx *c)
 
 static int ready_mask(const bool *r) { int m = 0; for (int t = 0; t < QR_MAX_TYPES; ++t) if (r[t]) m |= 1 << t; return m; }
 
+// What an overlapped tick adds to its MPC launches (qrgpu_tick_batch): the epoch its solves leave in d_solved, whether they wait -- per robot -- for
+// the previous tick's (chained), and the cost buffers they read and write.
+struct OvLaunch { unsigned epoch; bool chained; unsigned prev_epoch; };
+
 static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_traj, const float *d_gait,
                       const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc, int epilogue = 0,
-                      bool piped = false)
+                      bool piped = false, int lane_id = 0, const OvLaunch *ov = nullptr)
 {
+    Lane &L = c->lane[lane_id];
     if (!c || n <= 0 || n > c->max_batch || !d_state || !d_traj || !d_gait || !d_force) return QRGPU_ERR_BAD_ARG;
     if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
     // without a type array every robot is type 0; with one, the kernel flags robots whose type was never set up (QRGPU_ST_BAD_TYPE)
@@ -489,7 +522,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.type_ready = ready_mask(c->mpc_ready);
     P.epilogue = epilogue;
     // pipelined tick: the solves raise per-robot flags for the WBC launch that runs beside them (qrgpu_tick_batch)
-    P.done_flag = piped ? c->d_done_flag : nullptr;
+    P.done_flag = piped ? L.d_done_flag : nullptr;
     P.done_epoch = c->tick_epoch;
     P.main_started = piped ? c->d_main_started : nullptr;
     P.tl = piped ? c->d_timeline : nullptr;
@@ -511,15 +544,15 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
     P.warm = (c->warm && !dH) ? c->d_warm : nullptr;
     if (P.warm && c->warm_n != n) {
-        HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, L.stream));
         c->warm_n = n;
     }
     P.lds_bytes = mpc_lds_bytes(c, P.horizon, dH != nullptr);      // (inspection launches have no list pass behind them)
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
-    P.order = (lpt && c->lpt_n == n) ? c->d_order : nullptr;
+    P.order = (lpt && L.lpt_n == n) ? L.d_order : nullptr;
     P.cost = lpt ? c->d_cost : nullptr;
-    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && c->lpt_n == n && ema) ? 1 : 0; }
+    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && L.lpt_n == n && ema) ? 1 : 0; }
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
     P.sinv_spill = nullptr;
@@ -559,16 +592,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // than 45 % of the batch the calls go back to one workgroup per CU for 31 calls; nobody plans meanwhile, so the call after them runs two
         // to a CU whatever the old count says (on the old plan: consistent, if stale) and the one after that decides on the fresh count.
         static const int hold_calls = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
-        if (c->two_hold > 0) { --c->two_hold; two = false; }
-        else if (c->two_probe) c->two_probe = false;
-        else if (hold_calls > 0 && c->plan_n == n && 20 * (long long)c->h_pre_count[c->rescue_parity] > 9 * (long long)n) { c->two_hold = hold_calls; c->two_probe = true; two = false; }
+        if (L.two_hold > 0) { --L.two_hold; two = false; }
+        else if (L.two_probe) L.two_probe = false;
+        else if (hold_calls > 0 && L.plan_n == n && 20 * (long long)L.h_pre_count[L.rescue_parity] > 9 * (long long)n) { L.two_hold = hold_calls; L.two_probe = true; two = false; }
     }
     if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
     const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;
-    P.rescue_count = rescue ? c->d_rescue : nullptr;
-    P.rescue_list = rescue ? c->d_rescue + 2 : nullptr;
-    P.rescue_parity = c->rescue_parity;
+    P.rescue_count = rescue ? L.d_rescue : nullptr;
+    P.rescue_list = rescue ? L.d_rescue + 2 : nullptr;
+    P.rescue_parity = L.rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     // rows enter the next tick's guess only when their multiplier exceeds 2 % of the solve's largest (weakly held rows are the ones that do
     // not persist: measured 0.2446 -> 0.2211 ms per launch at h = 10, neutral at h = 5; at h = 16, where a missing row costs 7-13 k cycles
@@ -578,9 +611,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
-    P.pre_count = planned ? c->d_pre : nullptr;
-    P.pre_list = planned ? c->d_pre + 4 : nullptr;
-    P.pre_hint = planned ? c->d_pre_hint : nullptr;
+    P.pre_count = planned ? L.d_pre : nullptr;
+    P.pre_list = planned ? L.d_pre + 4 : nullptr;
+    P.pre_hint = planned ? L.d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
     if (two) {
@@ -602,9 +635,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     }
     P.lds_main = P.lds_bytes;
     P.started = nullptr;
-    if (planned && c->plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
-        HIPCHK(c, hipMemsetAsync(c->d_pre, 0, 4 * sizeof(int), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_skip, 0, (size_t)n, c->stream));
+    if (planned && L.plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
+        HIPCHK(c, hipMemsetAsync(L.d_pre, 0, 4 * sizeof(int), L.stream));
+        HIPCHK(c, hipMemsetAsync(L.d_skip, 0, (size_t)n, L.stream));
     }
     // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 2 = the same on four waves
     // (QRGPU_MAIN_THREADS=256, for A/B runs; six waves were measured too: the second workgroup of a CU then often cannot be placed until
@@ -642,8 +675,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         const int slots = 8 * ((c->main_slots[pvar][0] * c->num_cu + 7) / 8);
         if (main_grid > slots) {
             P.persist = 1;
-            P.qhead = c->d_qhead + 8 * c->qhead_parity; P.qhead_next = c->d_qhead + 8 * (c->qhead_parity ^ 1);
-            c->qhead_parity ^= 1;
+            P.qhead = L.d_qhead + 8 * L.qhead_parity; P.qhead_next = L.d_qhead + 8 * (L.qhead_parity ^ 1);
+            L.qhead_parity ^= 1;
             main_grid = slots;
             main_fn = mpc_fn(pvar, false);
         }
@@ -653,8 +686,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
     // the planned launch (and its two stream events) is only worth issuing when the last plan listed somebody: the list's length comes back
     // through pinned memory without a sync.  A stale zero just means the main pass solves everybody (P.skip stays null): consistent either way.
-    if (planned && c->plan_n != n) { c->h_pre_count[0] = c->h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); c->plan_sync_left = ps; }
-    const bool have_plan = planned && c->plan_n == n && c->h_pre_count[c->rescue_parity] > 0;
+    if (planned && L.plan_n != n) { L.h_pre_count[0] = L.h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); L.plan_sync_left = ps; }
+    const bool have_plan = planned && L.plan_n == n && L.h_pre_count[L.rescue_parity] > 0;
     // QRGPU_PLANNED_MODE: 0 = planned list on the context's side stream (fork / join events), 1 = planned list and main pass on the SAME
     // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
     // workgroups (each needs a whole CU's LDS) are dispatched first, the main pass's fill the rest of the machine
@@ -663,7 +696,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.planned_done = nullptr; P.planned_expect = 0;
     if (have_plan) {
         // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
-        P.skip = c->d_skip;
+        P.skip = L.d_skip;
         MpcLaunch L = P;
         L.persist = 0; L.qhead = nullptr; L.qhead_next = nullptr;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
@@ -671,19 +704,19 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         L.sinv_spill = c->d_sinv_spill;               // (null at h <= 11; the whole-CU kernels of h > 11 put S^-1 there when an all-stance robot's M leaves no room)
         static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
         const bool gate = gate_on && planned_mode != 1;
-        L.started = gate ? c->d_started : nullptr;
+        L.started = gate ? L.d_started : nullptr;
         int gate_expect = 0;
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
-        hipStream_t ls = planned_mode == 1 ? c->stream : c->side_stream;
+        hipStream_t ls = planned_mode == 1 ? L.stream : L.side_stream;
         // QRGPU_PLANNED_WAVES=4: the four-wave list kernel, a workgroup striding over the list (this round's first form)
         static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
         // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
         // (... unless most of the batch is listed -- a shard of standing robots: then the list is the launch, and it gets every CU)
-        const int g3_cap = (two && 2 * c->h_pre_count[c->rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
-        const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && c->h_pre_count[c->rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
+        const int g3_cap = (two && 2 * L.h_pre_count[L.rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
+        const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && L.h_pre_count[L.rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
         // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
         // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and
         // the first workgroup of the next main pass on ticks that have a plan, against 2 on ticks that have none (the kernels' stamps).  Instead: a
@@ -700,38 +733,38 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // (h > 11 two to a CU: the cost rule's share of the list comes and goes with the robots' smoothed costs, a dozen entries a tick -- and a
         //  robot handed to the trailing launch is a whole solve BEHIND the main pass: 1.10 M ticks/s with eight spare workgroups, 1.43 M with 24 or 48)
         static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
-        int g3 = c->h_pre_count[c->rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
+        int g3 = L.h_pre_count[L.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
         L.planned_stride = (two && g3 > g3_cap) ? 1 : 0;
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
         bool main_gate_queued = false;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-            ++c->go_total;
-            if (++c->plan_epoch >= 0x7fffffff) c->plan_epoch = 1;
-            P.plan_abort = c->d_go + 1; P.plan_epoch = c->plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
+            ++L.go_total;
+            if (++L.plan_epoch >= 0x7fffffff) L.plan_epoch = 1;
+            P.plan_abort = L.d_go + 1; P.plan_epoch = L.plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
             // The gate in front of the main pass -- it gives the "go" -- is queued BEFORE the launch that polls for it: should the two streams
             // ever share a hardware queue (more streams in the process than the device has queues), a poller queued in front of what it polls for
             // would sit out its whole bound; this way round the worst case is the 30 us of the main pass's own gate.
-            c->started_total += g3;
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, c->d_go);
+            L.started_total += g3;
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.stream, L.d_started, L.started_total, (long long)3000, (int *)nullptr, 0, L.d_go);
             HIPCHK(c, hipGetLastError());
             main_gate_queued = true;
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->side_stream, c->d_go, c->go_total, go_ticks, c->d_go + 1, c->plan_epoch, (int *)nullptr);
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.side_stream, L.d_go, L.go_total, go_ticks, L.d_go + 1, L.plan_epoch, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else if (planned_mode != 1) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            HIPCHK(c, hipEventRecord(L.ev_fork, L.stream));
+            HIPCHK(c, hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
         }
         if (one_per_wg) {
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
             // hands a longer list's tail to the trailing launch)
             L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
             { const int rc_ = mpc_ensure_lds(c, one_var, fl, c->lds_per_cu); if (rc_) return rc_; }
-            if (poll_join) { c->planned_done_total += g3; L.planned_done = c->d_planned_done; }       // (every workgroup of the launch bumps it once)
+            if (poll_join) { L.planned_done_total += g3; L.planned_done = L.d_planned_done; }       // (every workgroup of the launch bumps it once)
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(one_var, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
-            if (!main_gate_queued) c->started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
+            if (!main_gate_queued) L.started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
 
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
@@ -739,10 +772,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
-        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(L.ev_join, L.side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
         if (gate && gate_expect > 0 && !main_gate_queued) {
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_started, c->started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.stream, L.d_started, L.started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -752,20 +785,20 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
         const int threads = (var == 3 || var == 0 || var == 5 || var == 12 || var == 13) ? 512 : 256;
-        HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, c->stream, nullptr, nullptr, flags));
+        HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, L.stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
-    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(L.stream, L.ev_join, 0));
     if (rescue) {
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
         R.persist = 0; R.qhead = nullptr; R.qhead_next = nullptr;
-        R.planned_done = poll_join ? c->d_planned_done : nullptr; R.planned_expect = c->planned_done_total;
+        R.planned_done = poll_join ? L.d_planned_done : nullptr; R.planned_expect = L.planned_done_total;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
         R.done_flag = nullptr; R.main_started = nullptr;      // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass)
-        R.skip = planned ? c->d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
-        R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? c->d_order : nullptr;
+        R.skip = planned ? L.d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
+        R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? L.d_order : nullptr;
         R.lds_bytes = c->lds_per_cu;
         R.sinv_spill = c->d_sinv_spill;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
@@ -774,21 +807,21 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         void *rargs[2] = {(void *)&R, (void *)&io};
-        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, c->stream, nullptr, nullptr, 0));
+        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, L.stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
         // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
         // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
-        c->plan_n = planned ? n : 0;
-        c->last_rescue_parity = c->rescue_parity;
-        c->rescue_parity ^= 1;
+        L.plan_n = planned ? n : 0;
+        L.last_rescue_parity = L.rescue_parity;
+        L.rescue_parity ^= 1;
     }
-    c->last_rescue_active = rescue;
+    L.last_rescue_active = rescue;
     if (piped) c->main_started_total += P.persist ? n : (int)(8 * ((n + 7) / 8));      // (persistent: one count per robot taken off a queue)
-    if (lpt && rescue) c->lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
+    if (lpt && rescue) L.lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {
-        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, c->stream, n, c->d_cost, c->d_order, (const int *)P.ftime, P.wbc_order_out);
+        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, L.stream, n, c->d_cost, L.d_order, (const int *)P.ftime, P.wbc_order_out);
         HIPCHK(c, hipGetLastError());
-        c->lpt_n = n;
+        L.lpt_n = n;
     }
     // (the WBC order is sorted by the launch behind the main pass -- the trailing list launch or qr_lpt_order_kernel; any other MPC launch on
     //  this context in between leaves the halves as they are and the next pipelined tick starts from slot order)
@@ -799,11 +832,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
     // The first two calls after a history reset (one per parity) therefore end with a stream sync.
     // (Not while the stream is being captured into a graph: a sync is illegal there, and a replayed graph has a fixed launch shape anyway.)
-    if (planned && c->plan_sync_left > 0) {
-        --c->plan_sync_left;
+    if (planned && L.plan_sync_left > 0) {
+        --L.plan_sync_left;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
-        if (cap == hipStreamCaptureStatusNone) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hipStreamIsCapturing(L.stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+        if (cap == hipStreamCaptureStatusNone) HIPCHK(c, hipStreamSynchronize(L.stream));
     }
     return QRGPU_OK;
 }
@@ -1184,7 +1217,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
         c->wbc_finished_total += 2 * n;
         // (... and for the all-gathers queued before this tick, so that the fence in front of the next tick need not queue a launch: qr_join_kernel)
         int *g0 = c->d_gather_done, *g1 = c->d_gather_done ? c->d_gather_done + 1 : nullptr;
-        hipLaunchKernelGGL(qr_join_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->d_pre_hint + 2,
+        hipLaunchKernelGGL(qr_join_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->lane[0].d_pre_hint + 2,
                            g0, c->gather_total[0], g1, c->gather_total[1], c->d_tick_done);
         HIPCHK(c, hipGetLastError());
         c->gather_joined[0] = c->gather_total[0]; c->gather_joined[1] = c->gather_total[1];
@@ -1427,9 +1460,9 @@ int qrgpu_sync(qrgpu_ctx *c)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->h_pre_count && c->h_pre_count[2]) {
+    if (c->lane[0].h_pre_count && c->lane[0].h_pre_count[2]) {
         // the join of a pipelined tick waited 20 ms for its WBC launch and went on without it: outputs of that tick are incomplete
-        c->h_pre_count[2] = 0;
+        c->lane[0].h_pre_count[2] = 0;
         (void)hipStreamSynchronize(c->wbc_stream);
         c->err = "a bounded device-side wait gave up: the WBC launch of a pipelined tick did not finish within 20 ms of its join, or an all-gather did not finish "
                  "(or its tick did not) within 30 s: outputs of that call were incomplete when the stream went on";

@@ -162,7 +162,7 @@ static int allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int 
         // ... of the context's last pipelined tick: a one-thread launch on the communication stream polls the count that tick's join bumps -- no
         // event on the compute stream (recording one there costs that stream 7 us a tick on this pool).  Bounded (30 s), and a gate that gives up
         // says so through the word qrgpu_sync looks at: a gather of torques that are not there yet must not pass silently.
-        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_tick_done, c->tick_done_total, (long long)3000000000LL, c->d_pre_hint + 2, 1,
+        hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_tick_done, c->tick_done_total, (long long)3000000000LL, c->lane[0].d_pre_hint + 2, 1,
                            (int *)nullptr);
         HIPCHK(c, hipGetLastError());
     } else {
@@ -212,7 +212,7 @@ int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
             // bounded (30 s: another rank may be late with its side of the collective, and the first gather also sets up RCCL's connections; beyond
             // that it is a hung collective, the stream goes on and qrgpu_sync reports it)
             hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gather_done + slot, c->gather_total[slot], (long long)3000000000LL,
-                               c->d_pre_hint + 2, 1, (int *)nullptr);
+                               c->lane[0].d_pre_hint + 2, 1, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather[slot], 0));
     }

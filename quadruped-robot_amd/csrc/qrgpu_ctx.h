@@ -10,6 +10,49 @@
 
 using namespace qrgpu;
 
+// One "lane" of MPC launch scheduling: everything a sequence of MPC launches on ONE stream carries from launch to launch -- the longest-first
+// order, the rescue and planned lists with their ping-pong parities and pinned length hints, the cumulative counters its gates poll, the
+// per-robot flags its solves raise for the WBC launch running beside them.  Lane 0 is the context's own stream (every call but an overlapped
+// tick).  Lanes 1 and 2 have streams of their own and alternate between consecutive OVERLAPPED ticks (qrgpu_set_tick_overlap): tick t + 1's
+// launches are queued on the other lane and start filling the slots tick t's drain leaves empty; what a robot carries from tick to tick
+// (warm-start words, cost word, the orientation task's memory) is handed over per robot (MpcLaunch::solved, WbcPipe::wbc_done).
+#define QR_LANES 3
+#define QR_ABORT_RING 8            // give-up words are rings indexed by epoch: several ticks may be in flight behind a backlog
+struct Lane {
+    hipStream_t stream = nullptr;             // (lane 0: mirrors qrgpu_ctx::stream)
+    bool own_stream = false;
+    hipStream_t side_stream = nullptr;        // the planned list launch beside the main pass
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int *d_order = nullptr;                   // [max_batch] longest-first dispatch order of the next MPC launch of this lane
+    int lpt_n = 0;                            // batch size d_order is valid for (0 = no history yet)
+    int *d_rescue = nullptr;                  // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
+    int rescue_parity = 0;
+    bool last_rescue_active = false;          // did the last launch_mpc carry a trailing list launch (so that flags may say "on the rescue list")?
+    int last_rescue_parity = 0;
+    // planned list (launched beside the main pass on side_stream): [4] counters + [max_batch] robot ids; skip flags; batch size the plan is for
+    int *d_pre = nullptr;
+    unsigned char *d_skip = nullptr;
+    int plan_n = 0;
+    int *d_pre_hint = nullptr;                // device-side address of h_pre_count
+    int *h_pre_count = nullptr;               // pinned: [0], [1] the planned list's length as of the last call, by parity (stale by a call or two at worst)
+    int plan_sync_left = 0;                   // calls after a history reset that still end with a stream sync (so that the host sees the first plans' lengths)
+    int *d_started = nullptr;                 // workgroups of planned list launches that have started, ever (qr_gate_kernel); never cleared
+    unsigned started_total = 0;               // what that counter reaches once every planned launch issued so far has started (wraps like the counter)
+    int *d_go = nullptr;                      // [0] "go" count of the planned launches' gates (cumulative); [1 + (plan epoch & 7)]: plan epoch of a gate that gave up
+    unsigned go_total = 0;
+    int plan_epoch = 0;
+    int *d_planned_done = nullptr;            // workgroups of planned launches that are through, ever (polled by the trailing launch of a pipelined tick)
+    unsigned planned_done_total = 0;
+    int *d_qhead = nullptr;                   // [2][8] queue heads of the persistent main pass, ping-pong (a launch zeroes the other half)
+    int qhead_parity = 0;
+    int two_hold = 0;                         // h > 11 two to a CU: calls left on one workgroup per CU after the planned list outgrew 45 % of the batch
+    bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
+    unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by this lane's solves for the WBC launch
+    float *d_cmd_tick = nullptr;              // [12][max_batch] force scratch of a tick whose caller passes no force array
+    int *d_lane_done = nullptr;               // overlapped ticks of this lane whose launches on the lane's stream are through, ever (the tick's join polls it)
+    unsigned lane_done_total = 0;
+};
+
 struct qrgpu_ctx {
     int device = 0;
     int max_batch = 0;
@@ -36,60 +79,50 @@ struct qrgpu_ctx {
     void *h_stage = nullptr;      // the pinned block
     bool zero_copy = false;
     int type_stage = 0;           // (copy path) the type word in flight
-    int *d_order = nullptr;       // [max_batch] longest-first dispatch order of the next MPC launch (qr_lpt_order_kernel)
-    int *d_cost = nullptr;        // [max_batch] what each robot cost in the last MPC launch
+    Lane lane[QR_LANES];
+    // what each robot cost in the last MPC launch: [0] every launch of lane 0, in place; an overlapped tick of epoch e writes [e & 1] and smooths
+    // with [(e & 1) ^ 1], its predecessor's (the trailing launch of tick t sorts a buffer that tick t + 1's solves do not write)
+    int *d_cost[2] = {nullptr, nullptr};
+    int cost_n[2] = {0, 0};       // batch size each holds the costs of a whole overlapped tick for (0: not)
     double *d_sinv_spill = nullptr;   // [max_batch][tri(QR_QH)] S^-1 scratch of the h > 11 variants, allocated at first use
-    int *d_rescue = nullptr;      // [2] counters (ping-pong by call parity) + [max_batch] robot ids of the MPC rescue pass
-    int rescue_parity = 0;
-    // planned list (launched beside the main pass on side_stream): [2] counters + [max_batch] robot ids; skip flags; batch size the plan is for
-    int *d_pre = nullptr;
-    unsigned char *d_skip = nullptr;
-    int plan_n = 0;
-    int *d_pre_hint = nullptr;    // device-side address of h_pre_count
-    int *h_pre_count = nullptr;   // pinned: the planned list's length as of the last call (copied back without a sync; stale by a call or two at worst)
     bool planned = true;
     int big_nls = 0;
-    int plan_sync_left = 0;        // calls after a history reset that still end with a stream sync (so that the host sees the first plans' lengths)
-    int *d_started = nullptr;                 // workgroups of planned list launches that have started, ever (qr_gate_kernel); never cleared
-    int started_total = 0;                    // what that counter reaches once every planned launch issued so far has started (wraps like the counter)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // pipelined tick (qrgpu_set_tick_pipeline, default on): the WBC launch of a tick runs on wbc_stream beside that tick's MPC launches
     bool pipeline = true;
     hipStream_t wbc_stream = nullptr;
     hipEvent_t ev_wbc_fork = nullptr, ev_wbc_join = nullptr;
-    unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by the MPC solves
     int *d_main_started = nullptr;            // main-pass workgroups started, ever (the WBC launch's gate); never cleared
-    int main_started_total = 0;
+    unsigned main_started_total = 0;
     unsigned tick_epoch = 0;
-    bool last_rescue_active = false;          // did the last launch_mpc carry a trailing list launch (so that flags may say "on the rescue list")?
-    int last_rescue_parity = 0;
-    int *d_qhead = nullptr;                   // [2][8] queue heads of the persistent main pass, ping-pong (a launch zeroes the other half)
-    int qhead_parity = 0;
-    int two_hold = 0;                         // h > 11 two to a CU: calls left on one workgroup per CU after the planned list outgrew 45 % of the batch
-    bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
     int main_slots[16][2] = {};               // resident workgroups per CU of each main-pass variant at the LDS size it was last configured for (0: not asked yet)
     int main_slots_lds[16][2] = {};
     int *d_tick_done = nullptr;               // pipelined ticks complete (bumped by their joins), ever: what qrgpu_allgather_tau_of_tick's gate polls
-    int tick_done_total = 0;
+    unsigned tick_done_total = 0;
     bool last_tick_piped = false;             // the context's most recent qrgpu_tick_batch was a pipelined one with a polling join
     int *d_gather_done = nullptr;             // [2] gathers finished per source-buffer slot, ever (qrgpu_allgather_fence polls it)
-    int gather_total[2] = {0, 0};
-    int gather_joined[2] = {0, 0};            // ... of which a pipelined tick's join has already made the compute stream wait for
-    int *d_go = nullptr;                      // [2]: [0] "go" count of the planned launches' gates (cumulative), [1] plan epoch of a gate that gave up
-    int go_total = 0, plan_epoch = 0;
-    int *d_planned_done = nullptr;            // workgroups of planned launches that are through, ever (polled by the trailing launch of a pipelined tick)
-    int planned_done_total = 0;
-    int *d_gate_abort = nullptr;              // epoch of the pipelined tick whose WBC gate timed out (0: none)
+    unsigned gather_total[2] = {0, 0};
+    unsigned gather_joined[2] = {0, 0};            // ... of which a pipelined tick's join has already made the compute stream wait for
+    int *d_gate_abort = nullptr;              // [QR_ABORT_RING] word (epoch & 7): epoch of the pipelined tick whose WBC gate timed out (0: none)
     int *d_wbc_finished = nullptr;            // waves of pipelined WBC launches whose outputs are in memory, ever (the tick's join); never cleared
-    int wbc_finished_total = 0;
+    unsigned wbc_finished_total = 0;
+    // overlapped ticks (qrgpu_set_tick_overlap): consecutive pipelined ticks alternate between lanes 1 and 2
+    int overlap = 0;                          // 0 off, 1 on (the caller's promise about inputs and output buffers: include/qrgpu.h)
+    int ov_next = 0;                          // which of lanes 1 / 2 the next overlapped tick takes
+    bool ov_chain = false;                    // the context's last launch was an overlapped tick (the next one may start under it)
+    int ov_n = 0;                             // ... of this batch size
+    unsigned ov_epoch = 0, ov_main_total = 0; // ... with this epoch, after which d_main_started reaches this
+    const void *ov_out[4] = {nullptr, nullptr, nullptr, nullptr};   // ... writing these output arrays (force, tau, qdes, status)
+    const void *ov_prev_ori = nullptr;        // ... and this orientation-task memory
+    int ov_lane_last = 0;                     // ... on this lane
+    hipEvent_t ev_ov_fence = nullptr;
+    unsigned *d_solved = nullptr;             // [max_batch] epoch of the overlapped tick whose solve of the robot has left its warm-start and cost words in memory
+    unsigned *d_wbc_done = nullptr;           // [max_batch] ... whose WBC pass has left the orientation task's memory (prev_ori) in memory
     int *d_tlr = nullptr;                     // diagnostic: [4][max_batch] per-robot WBC moments of the last pipelined tick
     long long *d_timeline = nullptr;          // diagnostic (qrgpu_debug_timeline): [64][8], or null
     int *d_ftime = nullptr;                   // [max_batch] when each robot's solve ended in the last pipelined tick (100 MHz clock, low word)
     int *d_wbc_order = nullptr;               // [2][max_batch] the WBC launch's slot -> robot map from those times, ping-pong: a tick's WBC launch reads one
     int wbc_order_parity = 0;                 //   half while the launch behind its main pass writes the other
     int wbc_order_n = 0;                      // batch size the half to be read next was written for (0: none)
-    int lpt_n = 0;                // batch size d_order is valid for (0 = no history yet)
     bool lpt = true;
     bool rescue = true;
     int epilogue = 0;             // QRGPU_EPILOGUE_* bits
@@ -99,7 +132,6 @@ struct qrgpu_ctx {
     bool warm = true;             // warm start of the MPC active set from the slot's previous solve
     unsigned char *d_warm = nullptr;   // [max_batch][QR_WARM_STRIDE]
     int warm_n = 0;               // batch size d_warm is valid for (0 = nothing yet)
-    float *d_cmd_tick = nullptr;  // [67][max_batch] wbc_cmd copy whose Fr_des rows the MPC kernel fills
     void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
     int lds_per_cu = 0, num_cu = 0;
