@@ -532,10 +532,18 @@ def main():
     if args.walk == "forward":
         walk = list(range(SEQ))                                  # 0 1 .. S-1 | 0 1 ..: time only runs forwards, one discontinuity per SEQ steps
     d_prev = dv.zeros((3, n))
-    d_force = dv.zeros((12, n))
-    d_qdes = dv.zeros((24, n))
-    d_status = dv.zeros((n,), np.int32)
-    d_tau2 = [dv.zeros((12, n)) for _ in range(2 if (world > 1 or comm_on) else 1)]
+    # Output arrays are double-buffered by step parity: consecutive ticks write different arrays, which is what lets the library start tick
+    # t + 1's solves in the slots tick t's drain leaves empty (qrgpu_set_tick_overlap, include/qrgpu.h; QRGPU_BENCH_OVERLAP=0: one set of
+    # arrays, the mode off -- rounds 1-3's form).  The mode is a promise about INPUTS too: every batch of every sequence is resident in HBM
+    # before the first timed step (above), and nothing is queued on the context's stream between ticks.
+    want_overlap = args.mode == "tick" and os.environ.get("QRGPU_BENCH_OVERLAP", "1") != "0"
+    overlap_on = want_overlap and ctx.set_tick_overlap(True, strict=False)
+    nbuf = 2 if (overlap_on or world > 1 or comm_on) else 1
+    d_force2 = [dv.zeros((12, n)) for _ in range(nbuf)]
+    d_qdes2 = [dv.zeros((24, n)) for _ in range(nbuf)]
+    d_status2 = [dv.zeros((n,), np.int32) for _ in range(nbuf)]
+    d_force, d_qdes, d_status = d_force2[0], d_qdes2[0], d_status2[0]
+    d_tau2 = [dv.zeros((12, n)) for _ in range(nbuf)]
     d_tau_all = dv.zeros((world, 12, n)) if (world > 1 or comm_on) else None   # rank-major
     nstep = [0]
     cur = dict(draw=0, k12=True, fixed=None)
@@ -543,8 +551,9 @@ def main():
     def step():
         i = nstep[0]
         nstep[0] += 1
-        slot = i & 1 if (world > 1 or comm_on) else 0
+        slot = i & 1 if nbuf == 2 else 0
         tau = d_tau2[slot]
+        d_force, d_qdes, d_status = d_force2[slot], d_qdes2[slot], d_status2[slot]
         ds, dt_, dg, dfb, dcmd = dev_seq[cur["draw"]][cur["fixed"] if cur["fixed"] is not None else walk[i % len(walk)]]
         if comm_on:
             ctx.allgather_fence(slot)                          # the gather of two steps ago has finished reading this buffer
@@ -562,6 +571,9 @@ def main():
                 d_tau_all.upload(torch.stack(parts).numpy())
             else:
                 ctx.allgather_tau(tau, n, d_tau_all, slot, of_tick=(args.mode == "tick"))     # RCCL over xGMI on the context's own stream: the only exchange of the path
+
+    def last_slot():
+        return (nstep[0] - 1) & 1 if nbuf == 2 else 0
 
     def fence():
         if comm_on:
@@ -610,19 +622,19 @@ def main():
     cur["ktime"] = ktime
     for d in range(D):
         draw_s.append(timed(share[d], args.warmup, d))
-        st_d = d_status.download()          # (outside the timed region: the last step's status words of this draw)
+        st_d = d_status2[last_slot()].download()          # (outside the timed region: the last step's status words of this draw)
         draw_flags.append(int((pkg.status_flags(st_d) != 0).sum())); draw_itmax.append(int(pkg.status_iterations(st_d).max()))
         draw_itmean.append(float(pkg.status_iterations(st_d).mean()))
     if world > 1 or comm_on:
         own = d_tau_all.download()[rank]
-        if not np.array_equal(own, d_tau2[(nstep[0] - 1) & 1].download()):
+        if not np.array_equal(own, d_tau2[last_slot()].download()):
             raise RuntimeError("rank %d: all-gathered torques differ from the local ones" % rank)
     mpc_ms, mpc_cnt = ctx.get_timing(0)
     wbc_ms, wbc_cnt = ctx.get_timing(1)
     if not mpc_cnt and not wbc_cnt: mpc_ms = wbc_ms = float("nan")            # (QRGPU_BENCH_KERNEL_TIMING=0)
     ctx.enable_timing(False)
     cur["ktime"] = 0
-    status = d_status.download()
+    status = d_status2[last_slot()].download()
     rates = [world * n * share[d] / draw_s[d] for d in range(D)]
     value = float(np.median(rates))
 
@@ -692,6 +704,20 @@ def main():
         side["ticks_per_s_slot_order_dispatch"] = n * ks / timed(ks, 3, 0, lpt=False)          # no scheduling history at all
         side["ticks_per_s_without_k12"] = n * ks / timed(ks, args.warmup, 0, k12=False)
         side["ticks_per_s_same_batch_replayed"] = n * ks / timed(ks, args.warmup, 0, fixed=0)   # round 1's methodology (history = replay)
+        if overlap_on:
+            # the same draw with consecutive ticks NOT overlapped (every tick waits for its predecessor's join: round 3's pipelined tick)
+            ctx.set_tick_overlap(False)
+            side["ticks_per_s_no_tick_overlap"] = n * ks / timed(ks, args.warmup, 0)
+            ctx.set_tick_overlap(True)
+        # one tick on its own, from its call to its join on the context's stream (stream marks; warm history, nothing queued behind it): what a caller
+        # that needs tick t's torques before it can state tick t + 1 waits for.  `value` is a rate of ticks in flight, not the reciprocal of this.
+        timed(3, args.warmup, 0)
+        lat = []
+        for _ in range(12):
+            ctx.tick_fence() if overlap_on else None
+            ctx.mark(0); step(); ctx.mark(1); ctx.sync()
+            lat.append(ctx.mark_elapsed_ms(0, 1))
+        side["tick_latency_ms"] = float(np.median(lat))
         # the serial tick (WBC launch behind the MPC launches on one stream, rounds 1-2's form) on the same draw, with the two kernels' own times
         ctx.set_tick_pipeline(False)
         ctx.enable_timing(4); ctx.enable_timing(-1)
@@ -715,7 +741,7 @@ def main():
             for hsrc, ddst in zip(host_in, dev_seq[0][0]):
                 ddst.copy_from_pinned(hsrc)
             step()
-            d_tau2[0].copy_to_pinned(host_tau)
+            d_tau2[last_slot()].copy_to_pinned(host_tau)
             ctx.sync()
         side["pcie_inclusive_ticks_per_s"] = n * 20 / (time.perf_counter() - tp0)
         # SURVEY 8f kernels in front of the tick, timed on their own (never part of `value`)
@@ -813,7 +839,12 @@ def main():
                                    + ("; h > 11 from 3.5 robots per CU on: two workgroups per CU for robots whose inverse Hessian fits half a CU's LDS, the others and the "
                                       "tick's long poles (by that smoothed cost) on whole CUs beside them (QRGPU_H16_TWO)" if h > 11 and n >= 896 else ""),
                        "tick_form": "pipelined: the WBC launch of a tick runs on a stream of the context's own beside that tick's MPC launches and takes each robot's "
-                                    "forces when its solve raises the robot's flag (qrgpu_set_tick_pipeline, default); outputs complete in stream order as before",
+                                    "forces when its solve raises the robot's flag (qrgpu_set_tick_pipeline, default); outputs complete in stream order as before"
+                                    + ("; consecutive ticks OVERLAP (qrgpu_set_tick_overlap): tick t + 1's solves start in the slots tick t's drain leaves empty, every "
+                                       "robot behind its own tick-t solve; output arrays double-buffered by step parity, inputs resident before the timed region; "
+                                       "`value` is a rate of ticks in flight -- config.tick_latency_ms is one tick on its own, config.ticks_per_s_no_tick_overlap the "
+                                       "rate with every tick behind its predecessor's join" if overlap_on else ""),
+                       "tick_overlap": bool(overlap_on),
                        **side},
             "roofline": roof,
         }

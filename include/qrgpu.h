@@ -182,6 +182,29 @@ int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
  * only: results are those of the serial form bit for bit.  A WBC workgroup that waits longer than 4 ms for its robot (never observed)
  * gives the robot QRGPU_ST_PIPE_TIMEOUT. */
 int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
+/* Overlapped ticks (default OFF; pipelined ticks at h <= 11): a caller that queues qrgpu_tick_batch calls without waiting for them may let
+ * tick t + 1's solves start in the slots tick t's drain leaves empty -- a quarter of a 1024-robot tick's slot-time -- instead of behind tick
+ * t's last workgroup.  With the mode on, a tick's launches go on stream sets of the context's own (two, alternating) and the context's stream
+ * carries only the tick's join: OUTPUTS ARE COMPLETE IN CALL ORDER ON THE CONTEXT'S STREAM exactly as before (whatever is queued there behind
+ * the call sees them), and results are those of the serial tick bit for bit -- what a robot carries from tick to tick (warm-start words,
+ * smoothed cost, the orientation task's memory prev_ori) is handed from its tick-t workgroup to its tick-(t + 1) workgroup behind per-robot
+ * epoch words with bounded waits (20 ms; a robot whose wait gives up starts cold and carries QRGPU_ST_PIPE_TIMEOUT).
+ * What the caller promises in exchange -- the mode is another contract than "stream order" for the INPUTS:
+ *   (1) a tick's input arrays are complete when the call is made, or were produced by work queued on the context's stream BEFORE THE PREVIOUS
+ *       qrgpu_tick_batch call: a chained tick does not wait for work queued on the context's stream since then.  Inputs produced there later
+ *       (an upload, a front-end kernel) need qrgpu_tick_fence() in front of the tick, which makes that one tick wait for the whole stream;
+ *   (2) consecutive ticks write DIFFERENT output arrays (force, tau, qdes, status: double-buffer them) and share prev_ori.  The library
+ *       checks this: a tick that reuses any output array of its predecessor, or changes n or prev_ori, or follows any other launch of this
+ *       context, is simply not chained -- it waits for the context's stream (an event) and runs as the pipelined tick always did.
+ * Throughput, not latency: a chained tick completes LATER after its call than an unchained one (its join waits for a launch that shares the
+ * machine with the next tick); bench.py prints both beside `value` (config.tick_latency_ms, config.ticks_per_s_no_tick_overlap).
+ * Needs the context's streams on hardware queues of their own: qrgpu_set_tick_overlap(1) probes that and returns QRGPU_ERR_NOT_SETUP (mode
+ * stays off, qrgpu_last_error says why) when two of them share one -- set GPU_MAX_HW_QUEUES=8 in the environment before the process's
+ * first HIP call (the HIP runtime's default of 4 is fewer than the streams a context owns). */
+int  qrgpu_set_tick_overlap(qrgpu_ctx *ctx, int on);
+int  qrgpu_tick_fence(qrgpu_ctx *ctx);
+/* How many ticks of this context ran on the overlapped form so far: chained to their predecessor / behind an event of the context's stream. */
+int  qrgpu_tick_overlap_stats(const qrgpu_ctx *ctx, int *chained, int *unchained);
 const char *qrgpu_last_error(const qrgpu_ctx *ctx);
 /* Device facts for reports: returns CU count, writes name (<= len). */
 int  qrgpu_device_info(const qrgpu_ctx *ctx, char *name, int len, int *lds_per_cu_bytes);

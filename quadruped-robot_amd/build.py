@@ -47,6 +47,21 @@ def build(force=False, verbose=False):
             fcntl.flock(lk, fcntl.LOCK_UN)
 
 
+# what each translation unit includes beyond itself: an object is rebuilt only when one of these (or the flags) is newer than it
+KERNEL_DEPS = ["qr_device_types.h", "qr_wave_helpers.h"]
+HOST_DEPS = KERNEL_DEPS + ["qrgpu_ctx.h", os.path.join("..", "..", "include", "qrgpu.h")]
+EXTRA_DEPS = {"qr_mpc_kernel_fl.hip": ["qr_mpc_kernel.hip"], "qr_wbc_kernel_dbg.hip": ["qr_wbc_kernel.hip"]}
+
+
+def _obj_stale(src, obj, flags):
+    stamp = obj + ".flags"
+    if not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src] + (HOST_DEPS if src.startswith("qrgpu_") else KERNEL_DEPS) + EXTRA_DEPS.get(src, [])
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps) or os.path.getmtime(os.path.abspath(__file__)) > t
+
+
 def _build_locked(verbose):
     flags = _flags()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -55,6 +70,8 @@ def _build_locked(verbose):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
+        if not _obj_stale(src, obj, flags):
+            continue
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -63,6 +80,8 @@ def _build_locked(verbose):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+        with open(cmd[-1] + ".flags", "w") as f:
+            f.write(" ".join(flags))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     with open(SO + ".flags", "w") as f:

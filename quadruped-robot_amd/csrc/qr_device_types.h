@@ -127,6 +127,7 @@ struct MpcLaunch {
     unsigned solved_epoch;
     const unsigned *prev_solved;
     unsigned prev_epoch;
+    long long xtick_wait;       // bound of that wait, in ticks of the 100 MHz clock (20 ms; QRGPU_OV_WAIT_US for the give-up tests)
 };
 #define QRGPU_ST_PIPE_TIMEOUT_D 0x02000000   // pipelined tick: the WBC gave up waiting for this robot's MPC forces (never seen; never silent)
 
@@ -218,6 +219,12 @@ struct WbcPipe {
     // (bounded, flagged) before it reads g_prev.  Null / 0: every other launch.
     unsigned *wbc_done;
     unsigned wait_epoch;
+    long long wait_ticks;       // bound of that wait (100 MHz clock)
+    // ... and there is NO second pass: a thousand (empty) workgroups dispatched one freed slot at a time on a machine that is never empty held the
+    // tick's join back by 100 us.  The trailing MPC list launch -- half-CU workgroups in this mode, so a waiting WBC workgroup can never keep it
+    // from starting -- raises the flag of a robot it has re-solved with bit 0 clear, and the robot's workgroup here waits on through the
+    // "on the list pass" value for that (bounded by wait_ticks, flagged).
+    int wait_list;
 };
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)

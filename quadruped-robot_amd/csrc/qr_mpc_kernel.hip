@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (xtick) {
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(P.prev_solved + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.prev_epoch) {
-                if (wall_clock64() - t0 > 2000000) { st |= QRGPU_ST_PIPE_TIMEOUT_D; warm_ok = false; break; }
+                if (wall_clock64() - t0 > P.xtick_wait) { st |= QRGPU_ST_PIPE_TIMEOUT_D; warm_ok = false; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
         }
@@ -2053,6 +2053,7 @@ template __global__ void qr_mpc_kernel<2, false, false, 512>(MpcLaunch, MpcIO); 
 template __global__ void qr_mpc_kernel<4, false, false, 256>(MpcLaunch, MpcIO);     // h <= 11, main pass on four waves (QRGPU_MAIN_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<4, true, true, 256>(MpcLaunch, MpcIO);       // h <= 11, list launches (whole CU's LDS, 96 rows)
 template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);       // h <= 16, list launches (whole CU's LDS, 96 rows)
+template __global__ void qr_mpc_kernel<4, true, true, 256, 2, true>(MpcLaunch, MpcIO);   // h <= 11, list launches of an OVERLAPPED tick: half a CU's LDS, S^-1 (96 rows) in the global scratch
 template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, MpcIO);      // h <= 16, four waves (QRGPU_H16_THREADS=256, A/B)
 template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);   // h <= 16, four waves within 256 registers: two workgroups per CU (QRGPU_H16_TWO)
 template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);      // h <= 16: eight waves build and sweep (256 VGPRs, one workgroup per CU)
@@ -2090,13 +2091,16 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
 // the stream -- which is what the all-gather of its torques polls for (qrgpu_allgather_tau_of_tick).
 // (`lane_done` / `lane_expect`, or null: an overlapped tick's launches on its lane's stream -- trailing list launch, second WBC pass -- are through.)
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
-                               int *lane_done, int lane_expect)
+                               int *lane_done, int lane_expect, long long *dbg)
 {
     if (threadIdx.x != 0) return;
     auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
     long long t0 = wall_clock64();
+    if (dbg) { dbg[0] = t0; dbg[1] = 0; dbg[2] = expected_total; dbg[3] = lane_expect; }
     while (!reached(counter, expected_total) || (lane_done && !reached(lane_done, lane_expect))) {
-        if (wall_clock64() - t0 >= max_ticks) { if (timed_out) { *timed_out = 1; __threadfence_system(); } return; }
+        if (wall_clock64() - t0 >= max_ticks) {
+            if (dbg) { dbg[1] = wall_clock64(); dbg[4] = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dbg[5] = lane_done ? __hip_atomic_load(lane_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1; dbg[6] = 1; }
+            if (timed_out) { *timed_out = 1; __threadfence_system(); } return; }
         __builtin_amdgcn_s_sleep(16);
     }
     // the gathers: another rank may be late with its side of the collective (the first one also sets up RCCL's connections), so this wait is
@@ -2107,6 +2111,7 @@ __global__ void qr_join_kernel(int *counter, int expected_total, long long max_t
         __builtin_amdgcn_s_sleep(16);
     }
     if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dbg) { dbg[1] = wall_clock64(); dbg[6] = 0; }
 }
 
 // The gate in front of an OVERLAPPED tick's launches (qrgpu_set_tick_overlap): tick t + 1 is queued on another stream set and may start in the
@@ -2114,15 +2119,17 @@ __global__ void qr_join_kernel(int *counter, int expected_total, long long max_t
 // gate polls too) and every workgroup of its planned launch (c1 / e1, or null): a workgroup of tick t + 1 waits, per robot, for that robot's
 // tick-t solve, and must never hold a slot that solve still needs to START.  Bounded; giving up is harmless (the per-robot waits are bounded
 // too, and a solve whose wait gives up starts cold and is flagged).
-__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks)
+__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp)
 {
     if (threadIdx.x != 0) return;
     auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
     const long long t0 = wall_clock64();
+    if (stamp) stamp[0] = t0;                   // (diagnostic: when the gate came up / opened)
     while (!reached(c0, e0) || (c1 && !reached(c1, e1))) {
         if (wall_clock64() - t0 >= max_ticks) return;
         __builtin_amdgcn_s_sleep(8);
     }
+    if (stamp) stamp[1] = wall_clock64();
 }
 // ... and the count its join polls: everything queued before this launch on the lane's stream is through.
 __global__ void qr_bump_kernel(int *counter)

@@ -1083,8 +1083,12 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
             if (pipe.wait_epoch) {
                 const long long t0 = wall_clock64();
                 int late = 0;
-                while (__hip_atomic_load(pipe.wbc_done + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pipe.wait_epoch) {
-                    if (wall_clock64() - t0 > 2000000) { late = 1; break; }
+                // (... or for THIS tick's epoch: the robot is on the MPC's list pass and the second WBC pass -- another stream -- has already computed it;
+                //  this workgroup, of the first pass, will find the robot's flag saying so and leave without storing anything)
+                for (;;) {
+                    const unsigned w = __hip_atomic_load(pipe.wbc_done + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w == pipe.wait_epoch || w == pipe.epoch) break;
+                    if (wall_clock64() - t0 > pipe.wait_ticks) { late = 1; break; }
                     __builtin_amdgcn_s_sleep(32);
                 }
                 if (lane == 0) sPipe = late;
@@ -1341,8 +1345,8 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         const long long t0 = wall_clock64();
         for (;;) {
             v = __hip_atomic_load(pipe.flag + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((v >> 1) == pipe.epoch) break;
-            if (wall_clock64() - t0 > 400000) { pipe_st = QRGPU_ST_PIPE_TIMEOUT_D; break; }
+            if ((v >> 1) == pipe.epoch && !(pipe.wait_list && (v & 1u))) break;
+            if (wall_clock64() - t0 > (((v >> 1) == pipe.epoch && pipe.wait_list) ? pipe.wait_ticks : 400000LL)) { pipe_st = QRGPU_ST_PIPE_TIMEOUT_D; break; }
             __builtin_amdgcn_s_sleep(32);
         }
         v = __builtin_amdgcn_readfirstlane(v);

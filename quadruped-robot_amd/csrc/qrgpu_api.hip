@@ -35,6 +35,7 @@ extern template __global__ void qr_mpc_kernel<9, true, false, 256>(MpcLaunch, Mp
 extern template __global__ void qr_mpc_kernel<9, true, false, 256, 2>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel<9, true, true, 256>(MpcLaunch, MpcIO);
+extern template __global__ void qr_mpc_kernel<4, true, true, 256, 2, true>(MpcLaunch, MpcIO);
 template <int MAXB, bool BIG, int NTHR, int MINW = 0> __global__ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io);
 extern template __global__ void qr_mpc_persist_kernel<2, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_persist_kernel<5, true, 512>(MpcLaunch, MpcIO);
@@ -53,8 +54,8 @@ extern template __global__ void qr_mpc_kernel_fl<9, true, false, 256, 2>(MpcLaun
 extern template __global__ void qr_mpc_kernel_fl<5, true, false, 512>(MpcLaunch, MpcIO);
 extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, MpcIO);
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
-                               int *lane_done, int lane_expect);
-__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks);
+                               int *lane_done, int lane_expect, long long *dbg);
+__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp);
 __global__ void qr_bump_kernel(int *counter);
 __global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks);
 __global__ void qr_probe_set_kernel(int *flag);
@@ -98,6 +99,7 @@ static const void *mpc_fn(int var, bool fl)
     case 10: return fl ? (const void *)qr_mpc_kernel_fl<9, true, false, 256, 2> : (const void *)qr_mpc_kernel<9, true, false, 256, 2>;   // 1 within 256 registers (two per CU)
     case 11: return (const void *)qr_mpc_persist_kernel<9, true, 256, 2>;   // persistent form of 10
     case 13: return fl ? (const void *)qr_mpc_kernel_fl<2, false, false, 512, 4, true> : (const void *)qr_mpc_kernel<2, false, false, 512, 4, true>;   // ... 64 working-set positions
+    case 14: return (const void *)qr_mpc_kernel<4, true, true, 256, 2, true>;       // h <= 11 list launches on HALF a CU (overlapped ticks): S^-1 in the global scratch
     case 12: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512, 4, true> : (const void *)qr_mpc_kernel<2, true, false, 512, 4, true>;   // h <= 16 two to a CU on eight waves
     default: return fl ? (const void *)qr_mpc_kernel_fl<2, true, false, 512> : (const void *)qr_mpc_kernel<2, true, false, 512>;
     }
@@ -107,7 +109,7 @@ static const void *mpc_fn(int var, bool fl)
 static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 {
     static std::mutex mu;
-    static int configured[16][2][14];          // [device][counting build][variant], zero-initialised
+    static int configured[16][2][16];          // [device][counting build][variant], zero-initialised
     std::lock_guard<std::mutex> lk(mu);
     int &have = configured[c->device & 15][fl ? 1 : 0][var];
     if (have >= bytes) return QRGPU_OK;
@@ -272,11 +274,14 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream)
     bool ok = hipMalloc(&L.d_order, sizeof(int) * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (nb + 4)) &&
               zalloc(&L.d_skip, nb) && hipHostMalloc((void **)&L.h_pre_count, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer((void **)&L.d_pre_hint, L.h_pre_count, 0) == hipSuccess && zalloc(&L.d_started, sizeof(int)) &&
-              create_side_stream(&L.side_stream) == hipSuccess && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
+              (own_stream || create_side_stream(&L.side_stream) == hipSuccess) && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
               zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) &&
               hipMalloc(&L.d_cmd_tick, sizeof(float) * 12 * nb) == hipSuccess &&
               hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
-    if (ok && own_stream) { ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess; L.own_stream = ok; }
+    if (ok && own_stream) {
+        ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&L.ev_tail, hipEventDisableTiming) == hipSuccess;
+        L.own_stream = ok;
+    }
     if (ok) { L.h_pre_count[0] = L.h_pre_count[1] = L.h_pre_count[2] = L.h_pre_count[3] = 0; }       // ([2] of lane 0: a pipelined tick's join gave up waiting)
     (void)hipDeviceSynchronize();          // (the fills went to the default stream: none of the context's streams waits for that one)
     return ok ? QRGPU_OK : QRGPU_ERR_ALLOC;
@@ -284,7 +289,8 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream)
 static void lane_destroy(Lane &L)
 {
     if (L.stream && L.own_stream) { (void)hipStreamSynchronize(L.stream); }
-    if (L.side_stream) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }
+    if (L.side_stream && !L.own_stream) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }     // (lanes 1, 2 borrow lane 0's)
+    if (L.ev_tail) hipEventDestroy(L.ev_tail);
     if (L.stream && L.own_stream) hipStreamDestroy(L.stream);
     if (L.d_order) hipFree(L.d_order);
     if (L.d_rescue) hipFree(L.d_rescue);
@@ -391,6 +397,9 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_warm) hipFree(c->d_warm);
     if (c->d_flops) hipFree(c->d_flops);
     if (c->wbc_stream) hipStreamDestroy(c->wbc_stream);
+    if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); hipStreamDestroy(c->tail_stream); }
+    if (c->wbc_stream_hi) { (void)hipStreamSynchronize(c->wbc_stream_hi); hipStreamDestroy(c->wbc_stream_hi); }
+    for (int k = 0; k < 2; ++k) if (c->ev_call[k]) hipEventDestroy(c->ev_call[k]);
     if (c->ev_wbc_fork) hipEventDestroy(c->ev_wbc_fork);
     if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
     if (c->ev_ov_fence) hipEventDestroy(c->ev_ov_fence);
@@ -410,12 +419,18 @@ void qrgpu_destroy(qrgpu_ctx *c)
     delete c;
 }
 
+// another population: the dispatch order, the plan and the smoothed costs of every lane mean nothing any more
+static void forget_history(qrgpu_ctx *c)
+{
+    for (auto &L : c->lane) { L.lpt_n = 0; L.plan_n = 0; }
+    c->cost_n[0] = c->cost_n[1] = 0;
+    c->ov_hold = 0;
+}
 int qrgpu_set_lpt_schedule(qrgpu_ctx *c, int on)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->lpt = on != 0;
-    c->lpt_n = 0;
-    c->plan_n = 0;
+    forget_history(c);
     return QRGPU_OK;
 }
 int qrgpu_set_warm_start(qrgpu_ctx *c, int on)
@@ -436,7 +451,7 @@ int qrgpu_set_planned_list(qrgpu_ctx *c, int on, int big_nls)
     if (!c || big_nls < 0) return QRGPU_ERR_BAD_ARG;
     c->planned = on != 0;
     c->big_nls = big_nls;
-    c->plan_n = 0;
+    for (auto &L : c->lane) L.plan_n = 0;
     return QRGPU_OK;
 }
 int qrgpu_set_tick_pipeline(qrgpu_ctx *c, int on)
@@ -449,7 +464,7 @@ int qrgpu_set_rescue_pass(qrgpu_ctx *c, int on)
 {
     if (!c) return QRGPU_ERR_BAD_ARG;
     c->rescue = on != 0;
-    c->plan_n = 0;
+    for (auto &L : c->lane) L.plan_n = 0;
     return QRGPU_OK;
 }
 int qrgpu_set_stream(qrgpu_ctx *c, void *s) { if (!c) return QRGPU_ERR_BAD_ARG; c->stream = (hipStream_t)s; c->lane[0].stream = c->stream; c->ov_chain = false; return QRGPU_OK; }
@@ -505,13 +520,19 @@ static int ready_mask(const bool *r) { int m = 0; for (int t = 0; t < QR_MAX_TYP
 
 // What an overlapped tick adds to its MPC launches (qrgpu_tick_batch): the epoch its solves leave in d_solved, whether they wait -- per robot -- for
 // the previous tick's (chained), and the cost buffers they read and write.
-struct OvLaunch { unsigned epoch; bool chained; unsigned prev_epoch; };
+struct OvLaunch { unsigned epoch; bool chained; unsigned prev_epoch; bool plan_tick; };
+// bound of an overlapped tick's per-robot waits for its predecessor (20 ms; QRGPU_OV_WAIT_US: the give-up tests)
+static long long ov_wait_ticks()
+{
+    static const long long v = [] { const char *e = getenv("QRGPU_OV_WAIT_US"); return e ? 100LL * atoll(e) : 2000000LL; }();
+    return v;
+}
 
 static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_traj, const float *d_gait,
                       const float *d_q, float *d_force, float *d_tau, int *d_status, float *dH, float *dG, float *d_force_wbc, int epilogue = 0,
                       bool piped = false, int lane_id = 0, const OvLaunch *ov = nullptr)
 {
-    Lane &L = c->lane[lane_id];
+    Lane &LN = c->lane[lane_id];
     if (!c || n <= 0 || n > c->max_batch || !d_state || !d_traj || !d_gait || !d_force) return QRGPU_ERR_BAD_ARG;
     if (d_tau && !d_q) return QRGPU_ERR_BAD_ARG;
     // without a type array every robot is type 0; with one, the kernel flags robots whose type was never set up (QRGPU_ST_BAD_TYPE)
@@ -522,8 +543,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.type_ready = ready_mask(c->mpc_ready);
     P.epilogue = epilogue;
     // pipelined tick: the solves raise per-robot flags for the WBC launch that runs beside them (qrgpu_tick_batch)
-    P.done_flag = piped ? L.d_done_flag : nullptr;
+    P.done_flag = piped ? LN.d_done_flag : nullptr;
     P.done_epoch = c->tick_epoch;
+    // overlapped tick (lanes 1, 2): per-robot hand-over of the warm-start and cost words between consecutive ticks (MpcLaunch::solved)
+    const bool ovl = ov != nullptr;
+    if (!ovl) { c->ov_chain = false; c->cost_n[0] = c->cost_n[1] = 0; }      // (any other MPC launch: the next overlapped tick waits for the context's stream)
+    int *const cost_out = c->d_cost[ovl ? (ov->epoch & 1u) : 0];
+    const int *const cost_prev = ovl ? c->d_cost[(ov->epoch & 1u) ^ 1u] : cost_out;
+    P.solved = ovl ? c->d_solved : nullptr; P.solved_epoch = ovl ? ov->epoch : 0u;
+    P.prev_solved = (ovl && ov->chained) ? c->d_solved : nullptr; P.prev_epoch = ovl ? ov->prev_epoch : 0u;
+    P.xtick_wait = ov_wait_ticks();
     P.main_started = piped ? c->d_main_started : nullptr;
     P.tl = piped ? c->d_timeline : nullptr;
     // QRGPU_WBC_ORDER=1 (an experiment, off by default): the solves also leave the moment they ended, from which the launch behind the main pass
@@ -544,21 +573,23 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // warm start from the slot's previous solve: not for inspection launches; a different batch size starts from nothing
     P.warm = (c->warm && !dH) ? c->d_warm : nullptr;
     if (P.warm && c->warm_n != n) {
-        HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, L.stream));
+        HIPCHK(c, hipMemsetAsync(c->d_warm, 0, (size_t)QR_WARM_STRIDE * (size_t)n, LN.stream));
         c->warm_n = n;
     }
     P.lds_bytes = mpc_lds_bytes(c, P.horizon, dH != nullptr);      // (inspection launches have no list pass behind them)
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
-    P.order = (lpt && L.lpt_n == n) ? L.d_order : nullptr;
-    P.cost = lpt ? c->d_cost : nullptr;
-    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && L.lpt_n == n && ema) ? 1 : 0; }
+    P.order = (lpt && LN.lpt_n == n) ? LN.d_order : nullptr;
+    P.cost = lpt ? cost_out : nullptr;
+    P.cost_in = cost_prev;
+    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && ema && (ovl ? c->cost_n[(ov->epoch & 1u) ^ 1u] == n : LN.lpt_n == n)) ? 1 : 0; }
+    if (ovl) c->cost_n[ov->epoch & 1u] = lpt ? n : 0;
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
     P.sinv_spill = nullptr;
-    if (!small) {
+    if (!small || ovl) {            // (overlapped ticks at h <= 11: the list launches run on half a CU with S^-1 in this scratch)
         if (!c->d_sinv_spill) HIPCHK(c, hipMalloc(&c->d_sinv_spill, sizeof(double) * (size_t)c->max_batch * (size_t)(QR_QH * (QR_QH + 1) / 2)));
-        P.sinv_spill = c->d_sinv_spill;
+        if (!small) P.sinv_spill = c->d_sinv_spill;
     }
     // Batches below 64 robots (the single-robot drop-in calls among them) have a CU per robot to themselves: they run the whole-CU eight-wave
     // variant <2, BIG, ., 512> (96 working-set positions, the CU's whole LDS) as their main pass, so that nothing is left for a trailing
@@ -592,16 +623,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // than 45 % of the batch the calls go back to one workgroup per CU for 31 calls; nobody plans meanwhile, so the call after them runs two
         // to a CU whatever the old count says (on the old plan: consistent, if stale) and the one after that decides on the fresh count.
         static const int hold_calls = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
-        if (L.two_hold > 0) { --L.two_hold; two = false; }
-        else if (L.two_probe) L.two_probe = false;
-        else if (hold_calls > 0 && L.plan_n == n && 20 * (long long)L.h_pre_count[L.rescue_parity] > 9 * (long long)n) { L.two_hold = hold_calls; L.two_probe = true; two = false; }
+        if (LN.two_hold > 0) { --LN.two_hold; two = false; }
+        else if (LN.two_probe) LN.two_probe = false;
+        else if (hold_calls > 0 && LN.plan_n == n && 20 * (long long)LN.h_pre_count[LN.rescue_parity] > 9 * (long long)n) { LN.two_hold = hold_calls; LN.two_probe = true; two = false; }
     }
     if (two) P.lds_bytes = (c->lds_per_cu / 2) & ~15;
     const bool rescue = c->rescue && !dH && (small || two) && !tiny;          // (the whole-CU h > 11 variant holds 96 rows itself)
     P.rescue_mode = 0;
-    P.rescue_count = rescue ? L.d_rescue : nullptr;
-    P.rescue_list = rescue ? L.d_rescue + 2 : nullptr;
-    P.rescue_parity = L.rescue_parity;
+    P.rescue_count = rescue ? LN.d_rescue : nullptr;
+    P.rescue_list = rescue ? LN.d_rescue + 2 : nullptr;
+    P.rescue_parity = LN.rescue_parity;
     P.lpt_cost_in = nullptr; P.lpt_order_out = nullptr;
     // rows enter the next tick's guess only when their multiplier exceeds 2 % of the solve's largest (weakly held rows are the ones that do
     // not persist: measured 0.2446 -> 0.2211 ms per launch at h = 10, neutral at h = 5; at h = 16, where a missing row costs 7-13 k cycles
@@ -611,9 +642,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
-    P.pre_count = planned ? L.d_pre : nullptr;
-    P.pre_list = planned ? L.d_pre + 4 : nullptr;
-    P.pre_hint = planned ? L.d_pre_hint : nullptr;
+    P.pre_count = planned ? LN.d_pre : nullptr;
+    P.pre_list = planned ? LN.d_pre + 4 : nullptr;
+    P.pre_hint = planned ? LN.d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
     if (two) {
@@ -635,9 +666,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     }
     P.lds_main = P.lds_bytes;
     P.started = nullptr;
-    if (planned && L.plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
-        HIPCHK(c, hipMemsetAsync(L.d_pre, 0, 4 * sizeof(int), L.stream));
-        HIPCHK(c, hipMemsetAsync(L.d_skip, 0, (size_t)n, L.stream));
+    if (planned && LN.plan_n != n) {                 // no plan for this batch size yet: nothing is skipped, both counters start at zero
+        HIPCHK(c, hipMemsetAsync(LN.d_pre, 0, 4 * sizeof(int), LN.stream));
+        HIPCHK(c, hipMemsetAsync(LN.d_skip, 0, (size_t)n, LN.stream));
     }
     // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 2 = the same on four waves
     // (QRGPU_MAIN_THREADS=256, for A/B runs; six waves were measured too: the second workgroup of a CU then often cannot be placed until
@@ -646,13 +677,21 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
     static const int two_waves = [] { const char *e = getenv("QRGPU_H16_TWO_WAVES"); return e ? atoi(e) : 8; }();
     const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (two ? (two_waves == 8 ? 12 : (two_waves == 9 ? 13 : 10)) : (h16_threads == 256 ? 1 : 0)));
-    const int list_var = small ? 4 : 8;             // striding list kernel (trailing launch, long planned lists)
-    const int one_var = small ? 5 : 0;              // one listed robot per whole-CU eight-wave workgroup
+    // Overlapped ticks (h <= 11): the machine is never empty -- a workgroup that asks for a whole CU's LDS waits until both halves of some CU
+    // happen to be free at once, behind every half-CU workgroup of the next tick's main pass and every WBC workgroup.  So the list launches of
+    // an overlapped tick run on HALF a CU like the main pass, with S^-1 (96 rows) in the global scratch: <4, BIG, LIST, 256, 2, H16> striding
+    // (variant 14) and <2, BIG, ., 512, 4, H16> one robot per workgroup (variant 12: the two-to-a-CU main pass of h > 11).
+    // A tick whose lane has a PLAN is not chained (qrgpu_tick_batch): it starts on an empty machine, and its planned launch is the whole-CU one.
+    const bool half_lists = small && ovl && !ov->plan_tick;
+    const int list_var = small ? (half_lists ? 14 : 4) : 8;             // striding list kernel (trailing launch, long planned lists)
+    const int one_var = small ? (half_lists ? 12 : 5) : 0;              // one listed robot per eight-wave workgroup
+    const int list_lds = half_lists ? P.lds_bytes : c->lds_per_cu;
+    const int one_lds = list_lds;
     // the instrumented kernels (counters, dense H / g, cycle stamps compiled in) only for a launch that asks for one of those
     const bool fl = P.flops != nullptr || dH != nullptr || dG != nullptr || c->d_dbg_cycles != nullptr;
     const void *fn = mpc_fn(var, fl);
     { const int rc_ = mpc_ensure_lds(c, var, fl, P.lds_bytes); if (rc_) return rc_; }
-    if (rescue) { const int rc_ = mpc_ensure_lds(c, list_var, fl, c->lds_per_cu); if (rc_) return rc_; }
+    if (rescue) { const int rc_ = mpc_ensure_lds(c, list_var, fl, list_lds); if (rc_) return rc_; }
     // Persistent main pass (qr_device_types.h): when the batch is more than the machine holds at once, launch one workgroup per resident slot
     // and let them take robots off per-XCD queues.  Default (QRGPU_PERSIST=1): the h > 11 variant only -- 1.31 -> 1.37 M ticks/s on the mixed
     // h = 16 shard.  At h <= 11 (QRGPU_PERSIST=2 to try) it loses what it gains and more: the four waves a solve no longer needs after its sweep
@@ -675,8 +714,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         const int slots = 8 * ((c->main_slots[pvar][0] * c->num_cu + 7) / 8);
         if (main_grid > slots) {
             P.persist = 1;
-            P.qhead = L.d_qhead + 8 * L.qhead_parity; P.qhead_next = L.d_qhead + 8 * (L.qhead_parity ^ 1);
-            L.qhead_parity ^= 1;
+            P.qhead = LN.d_qhead + 8 * LN.qhead_parity; P.qhead_next = LN.d_qhead + 8 * (LN.qhead_parity ^ 1);
+            LN.qhead_parity ^= 1;
             main_grid = slots;
             main_fn = mpc_fn(pvar, false);
         }
@@ -686,8 +725,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
     // the planned launch (and its two stream events) is only worth issuing when the last plan listed somebody: the list's length comes back
     // through pinned memory without a sync.  A stale zero just means the main pass solves everybody (P.skip stays null): consistent either way.
-    if (planned && L.plan_n != n) { L.h_pre_count[0] = L.h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); L.plan_sync_left = ps; }
-    const bool have_plan = planned && L.plan_n == n && L.h_pre_count[L.rescue_parity] > 0;
+    if (planned && LN.plan_n != n) { LN.h_pre_count[0] = LN.h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); LN.plan_sync_left = ps; }
+    const bool have_plan = planned && LN.plan_n == n && LN.h_pre_count[LN.rescue_parity] > 0;
     // QRGPU_PLANNED_MODE: 0 = planned list on the context's side stream (fork / join events), 1 = planned list and main pass on the SAME
     // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
     // workgroups (each needs a whole CU's LDS) are dispatched first, the main pass's fill the rest of the machine
@@ -696,27 +735,27 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.planned_done = nullptr; P.planned_expect = 0;
     if (have_plan) {
         // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
-        P.skip = L.d_skip;
+        P.skip = LN.d_skip;
         MpcLaunch L = P;
         L.persist = 0; L.qhead = nullptr; L.qhead_next = nullptr;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
-        L.lds_bytes = c->lds_per_cu;
+        L.lds_bytes = list_lds;                       // (the one-robot-per-workgroup form below: one_lds)
         L.sinv_spill = c->d_sinv_spill;               // (null at h <= 11; the whole-CU kernels of h > 11 put S^-1 there when an all-stance robot's M leaves no room)
         static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
         const bool gate = gate_on && planned_mode != 1;
-        L.started = gate ? L.d_started : nullptr;
+        L.started = gate ? LN.d_started : nullptr;
         int gate_expect = 0;
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
-        hipStream_t ls = planned_mode == 1 ? L.stream : L.side_stream;
+        hipStream_t ls = planned_mode == 1 ? LN.stream : LN.side_stream;
         // QRGPU_PLANNED_WAVES=4: the four-wave list kernel, a workgroup striding over the list (this round's first form)
         static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
         // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
         // (... unless most of the batch is listed -- a shard of standing robots: then the list is the launch, and it gets every CU)
-        const int g3_cap = (two && 2 * L.h_pre_count[L.rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
-        const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && L.h_pre_count[L.rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
+        const int g3_cap = (two && 2 * LN.h_pre_count[LN.rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
+        const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && LN.h_pre_count[LN.rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
         // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
         // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and
         // the first workgroup of the next main pass on ticks that have a plan, against 2 on ticks that have none (the kernels' stamps).  Instead: a
@@ -733,38 +772,42 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // (h > 11 two to a CU: the cost rule's share of the list comes and goes with the robots' smoothed costs, a dozen entries a tick -- and a
         //  robot handed to the trailing launch is a whole solve BEHIND the main pass: 1.10 M ticks/s with eight spare workgroups, 1.43 M with 24 or 48)
         static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
-        int g3 = L.h_pre_count[L.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
+        int g3 = LN.h_pre_count[LN.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
         L.planned_stride = (two && g3 > g3_cap) ? 1 : 0;
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
         bool main_gate_queued = false;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-            ++L.go_total;
-            if (++L.plan_epoch >= 0x7fffffff) L.plan_epoch = 1;
-            P.plan_abort = L.d_go + 1; P.plan_epoch = L.plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
+            ++LN.go_total;
+            if (++LN.plan_epoch >= 0x7fffffff) LN.plan_epoch = 1;
+            // (the give-up word is a ring indexed by the plan epoch: two planned ticks queued behind a backlog longer than twice the bound must not
+            //  overwrite each other's word before their own kernels have read it)
+            int *const abort_word = LN.d_go + 1 + (LN.plan_epoch & (QR_ABORT_RING - 1));
+            P.plan_abort = abort_word; P.plan_epoch = LN.plan_epoch; L.plan_abort = P.plan_abort; L.plan_epoch = P.plan_epoch;
             // The gate in front of the main pass -- it gives the "go" -- is queued BEFORE the launch that polls for it: should the two streams
             // ever share a hardware queue (more streams in the process than the device has queues), a poller queued in front of what it polls for
             // would sit out its whole bound; this way round the worst case is the 30 us of the main pass's own gate.
-            L.started_total += g3;
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.stream, L.d_started, L.started_total, (long long)3000, (int *)nullptr, 0, L.d_go);
+            LN.started_total += g3;
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.stream, LN.d_started, LN.started_total, (long long)3000, (int *)nullptr, 0, LN.d_go);
             HIPCHK(c, hipGetLastError());
             main_gate_queued = true;
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.side_stream, L.d_go, L.go_total, go_ticks, L.d_go + 1, L.plan_epoch, (int *)nullptr);
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.side_stream, LN.d_go, LN.go_total, go_ticks, abort_word, LN.plan_epoch, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else if (planned_mode != 1) {
-            HIPCHK(c, hipEventRecord(L.ev_fork, L.stream));
-            HIPCHK(c, hipStreamWaitEvent(L.side_stream, L.ev_fork, 0));
+            HIPCHK(c, hipEventRecord(LN.ev_fork, LN.stream));
+            HIPCHK(c, hipStreamWaitEvent(LN.side_stream, LN.ev_fork, 0));
         }
         if (one_per_wg) {
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
             // hands a longer list's tail to the trailing launch)
             L.rescue_mode = 3; L.rescue_count = P.rescue_count; L.rescue_list = P.rescue_list;
-            { const int rc_ = mpc_ensure_lds(c, one_var, fl, c->lds_per_cu); if (rc_) return rc_; }
-            if (poll_join) { L.planned_done_total += g3; L.planned_done = L.d_planned_done; }       // (every workgroup of the launch bumps it once)
+            L.lds_bytes = one_lds;
+            { const int rc_ = mpc_ensure_lds(c, one_var, fl, one_lds); if (rc_) return rc_; }
+            if (poll_join) { LN.planned_done_total += g3; L.planned_done = LN.d_planned_done; }       // (every workgroup of the launch bumps it once)
             void *largs[2] = {(void *)&L, (void *)&io};
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(one_var, fl), dim3(g3), dim3(512), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
             gate_expect = g3;
-            if (!main_gate_queued) L.started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
+            if (!main_gate_queued) LN.started_total += g3;               // every workgroup of this launch bumps the counter once, sooner or later
 
         } else {
             L.started = nullptr;                  // (a long list on the striding kernel competes with the main pass as before: gating it would starve the main pass)
@@ -772,56 +815,58 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
-        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(L.ev_join, L.side_stream));
+        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(LN.ev_join, LN.side_stream));
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
         if (gate && gate_expect > 0 && !main_gate_queued) {
-            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, L.stream, L.d_started, L.started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
+            hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.stream, LN.d_started, LN.started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         }
     }
     {
-        TimerScope ts(c, 0);
+        TimerScope ts(c, 0, LN.stream);
         const dim3 grid(main_grid);
         void *kargs[2] = {(void *)&P, (void *)&io};
         const unsigned flags = (have_plan && planned_mode == 1) ? hipExtAnyOrderLaunch : 0;
         const int threads = (var == 3 || var == 0 || var == 5 || var == 12 || var == 13) ? 512 : 256;
-        HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, L.stream, nullptr, nullptr, flags));
+        HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, LN.stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
-    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(L.stream, L.ev_join, 0));
+    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(LN.stream, LN.ev_join, 0));
     if (rescue) {
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
         MpcLaunch R = P;
         R.persist = 0; R.qhead = nullptr; R.qhead_next = nullptr;
-        R.planned_done = poll_join ? L.d_planned_done : nullptr; R.planned_expect = L.planned_done_total;
+        R.planned_done = poll_join ? LN.d_planned_done : nullptr; R.planned_expect = LN.planned_done_total;
         R.rescue_mode = 1; R.order = nullptr; R.cost = nullptr;
-        R.done_flag = nullptr; R.main_started = nullptr;      // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass)
-        R.skip = planned ? L.d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
-        R.lpt_cost_in = lpt ? c->d_cost : nullptr; R.lpt_order_out = lpt ? L.d_order : nullptr;
-        R.lds_bytes = c->lds_per_cu;
+        // (its robots go to the WBC pass queued behind it, not to the one running beside the main pass -- except in an overlapped tick, which has no
+        //  second pass: there the robot's WBC workgroup waits for the flag this launch raises, WbcPipe::wait_list)
+        R.done_flag = ovl ? LN.d_done_flag : nullptr; R.main_started = nullptr;
+        R.skip = planned ? LN.d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
+        R.lpt_cost_in = lpt ? cost_out : nullptr; R.lpt_order_out = lpt ? LN.d_order : nullptr;
+        R.lds_bytes = list_lds;
         R.sinv_spill = c->d_sinv_spill;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
         // empty pass at 4096 robots)
-        int rgrid = 64 < n ? 64 : n;
+        int rgrid = half_lists ? 16 : (64 < n ? 64 : n);          // (chained ticks: every workgroup of this launch waits for a freed half CU)
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         void *rargs[2] = {(void *)&R, (void *)&io};
-        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, L.stream, nullptr, nullptr, 0));
+        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, LN.stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
         // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
         // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
-        L.plan_n = planned ? n : 0;
-        L.last_rescue_parity = L.rescue_parity;
-        L.rescue_parity ^= 1;
+        LN.plan_n = planned ? n : 0;
+        LN.last_rescue_parity = LN.rescue_parity;
+        LN.rescue_parity ^= 1;
     }
-    L.last_rescue_active = rescue;
+    LN.last_rescue_active = rescue;
     if (piped) c->main_started_total += P.persist ? n : (int)(8 * ((n + 7) / 8));      // (persistent: one count per robot taken off a queue)
-    if (lpt && rescue) L.lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
+    if (lpt && rescue) LN.lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {
-        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, L.stream, n, c->d_cost, L.d_order, (const int *)P.ftime, P.wbc_order_out);
+        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, LN.stream, n, cost_out, LN.d_order, (const int *)P.ftime, P.wbc_order_out);
         HIPCHK(c, hipGetLastError());
-        L.lpt_n = n;
+        LN.lpt_n = n;
     }
     // (the WBC order is sorted by the launch behind the main pass -- the trailing list launch or qr_lpt_order_kernel; any other MPC launch on
     //  this context in between leaves the halves as they are and the next pipelined tick starts from slot order)
@@ -832,18 +877,18 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // the trailing launch, serially behind the main pass (a 20-step run lost a quarter of its rate on populations with an all-stance robot).
     // The first two calls after a history reset (one per parity) therefore end with a stream sync.
     // (Not while the stream is being captured into a graph: a sync is illegal there, and a replayed graph has a fixed launch shape anyway.)
-    if (planned && L.plan_sync_left > 0) {
-        --L.plan_sync_left;
+    if (planned && LN.plan_sync_left > 0) {
+        --LN.plan_sync_left;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(L.stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
-        if (cap == hipStreamCaptureStatusNone) HIPCHK(c, hipStreamSynchronize(L.stream));
+        if (hipStreamIsCapturing(LN.stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+        if (cap == hipStreamCaptureStatusNone) HIPCHK(c, hipStreamSynchronize(LN.stream));
     }
     return QRGPU_OK;
 }
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr})
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0})
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -852,6 +897,7 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     int rc = upload_wbc(c);
     if (rc) return rc;
     const hipStream_t ws = stream_override ? stream_override : c->stream;
+    if (!pipe.wbc_done) c->ov_chain = false;        // (any WBC launch but an overlapped tick's: the next overlapped tick waits for the context's stream)
     {
         TimerScope ts(c, 1, ws, !pipe.second);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
         // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
@@ -1155,9 +1201,6 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     if (!c || !d_fb_state || !d_wbc_cmd || !d_tau || !d_prev_ori) return QRGPU_ERR_BAD_ARG;
     if (n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written.
-    // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
-    float *const force = d_force ? d_force : c->d_cmd_tick;
     static const int pipe_env = [] { const char *e = getenv("QRGPU_TICK_PIPELINE"); return e ? atoi(e) : 1; }();
     c->last_tick_piped = false;
     bool piped = c->pipeline && pipe_env != 0 && n >= 64 && !c->d_dbg_cycles && !c->d_dbg_cycles_wbc;
@@ -1166,6 +1209,32 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
         if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
         if (cap != hipStreamCaptureStatusNone) piped = false;
     }
+    // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
+    // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
+    static const int pipe_join = [] { const char *e = getenv("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
+    // Overlapped tick (qrgpu_set_tick_overlap; h <= 11): the tick's launches go on lane 1 or 2 -- stream sets of the context's own, alternating --
+    // and the context's stream carries only the join.  When the caller's previous call was an overlapped tick of the same batch that wrote OTHER
+    // output arrays, this tick is CHAINED to it: its main pass is released as soon as every workgroup of that tick's MPC launches has started
+    // and fills the slots that tick's drain leaves empty; every robot waits for its own previous solve / WBC pass (MpcLaunch::solved,
+    // WbcPipe::wbc_done).  Otherwise the lane waits for everything queued on the context's stream so far (an event): no overlap, same results.
+    const bool was_chain = c->ov_chain;
+    bool ovl = piped && c->overlap && pipe_join && 4 * c->mpc.horizon <= 44 && !c->flops_on && c->lane[1].d_order && c->lane[2].d_order;
+    if (ovl) {
+        // A population with a PLAN -- robots that want a whole CU on a list launch beside the main pass -- is not for overlapped ticks: on a machine
+        // that is never empty a whole-CU workgroup waits until both halves of some CU happen to be free at once, and the half-CU list kernel that
+        // needs no such luck (S^-1 in the global scratch) takes 300 us and more for such a robot, which the pipeline then waits for: 3.0-3.3 against
+        // 4.2 M ticks/s on the bench's populations with an all-stance robot at a degenerate vertex.  So when the lane that is next finds a plan (its
+        // last trailing launch listed somebody) the context goes back to the plain pipelined tick for 31 calls, then looks again.
+        static const int hold_calls = [] { const char *e = getenv("QRGPU_OV_PLAN_HOLD"); return e ? atoi(e) : 31; }();
+        const Lane &NL = c->lane[1 + c->ov_next];
+        if (c->ov_hold > 0) { --c->ov_hold; ovl = false; }
+        else if (hold_calls > 0 && c->planned && c->rescue && c->lpt && NL.plan_n == n && NL.h_pre_count[NL.rescue_parity] > 0) { c->ov_hold = hold_calls; ovl = false; }
+    }
+    const int lane_id = ovl ? 1 + c->ov_next : 0;
+    Lane &LN = c->lane[lane_id];
+    // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written.
+    // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
+    float *const force = d_force ? d_force : LN.d_cmd_tick;
     if (!piped) {
         int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0);
         if (rc) return rc;
@@ -1177,52 +1246,161 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // going to wait for), then its workgroups settle wherever a solve has left, run the rigid-body dynamics, the task set and the kinematic
     // projection, and wait -- bounded -- at the QP for their robot's flag (qr_wbc_kernel.hip, qr_mpc_kernel.hip).  Robots the main pass hands
     // to its trailing list launch are skipped there and taken by a second, list-driven WBC pass queued behind that launch.
+    const unsigned prev_epoch = c->tick_epoch;
     if (++c->tick_epoch >= 0x7fffffffu) c->tick_epoch = 1;
+    const unsigned epoch = c->tick_epoch;
+    // (the give-up word of this tick's WBC gate: a ring indexed by the epoch -- several ticks may be queued behind a backlog)
+    int *const gate_abort = c->d_gate_abort + (epoch & (QR_ABORT_RING - 1));
+    // (QRGPU_OV_FAULT=1, the give-up tests: chained ticks wait for an epoch nobody ever writes, so that every per-robot wait runs into its bound)
+    static const unsigned ov_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return (e && atoi(e)) ? 0x40000000u : 0u; }();
+    OvLaunch ov{epoch, false, prev_epoch ^ ov_fault, false};
+    if (ovl) {
+        c->ov_next ^= 1;
+        const void *outs[4] = {(const void *)d_force, (const void *)d_tau, (const void *)d_qdes, (const void *)d_status};
+        bool distinct = true;
+        for (int a = 0; a < 4; ++a) if (outs[a]) for (int b = 0; b < 4; ++b) if (outs[a] == c->ov_out[b]) distinct = false;
+        // A tick whose lane has a plan -- robots that want a whole CU, on a list launch beside the main pass -- is not chained, nor is its successor: on
+        // a machine that is never empty a whole-CU workgroup waits until both halves of some CU happen to be free at once (the half-CU list kernel
+        // that needs no such luck takes 300 us and more for such a robot, and the pipeline then waits for it: 3.0 against 4.2 M ticks/s on the
+        // populations that hold an all-stance robot at a degenerate vertex).
+        ov.plan_tick = c->planned && c->rescue && c->lpt && LN.plan_n == n && LN.h_pre_count[LN.rescue_parity] > 0;       // (only with QRGPU_OV_PLAN_HOLD=0)
+        ov.chained = was_chain && c->ov_n == n && c->ov_epoch == prev_epoch && c->ov_prev_ori == (const void *)d_prev_ori && distinct && !ov.plan_tick && !c->ov_prev_plan;
+        c->ov_prev_plan = ov.plan_tick;
+        // What the caller had queued on the context's stream when it made the PREVIOUS tick call -- the join of the tick before that one and whatever
+        // consumed its outputs, which are the arrays this tick overwrites when the caller double-buffers -- must be through before this tick writes
+        // anything: the event recorded at that call.  (It completed about a tick ago: the wait costs the lane nothing.)  An unchained tick waits for
+        // the event recorded now: everything queued on the context's stream so far.
+        const int ev_now = (c->ev_call_last + 1) & 1;
+        const int ev_prev = c->ev_call_last;
+        HIPCHK(c, hipEventRecord(c->ev_call[ev_now], c->stream));
+        if (ov.chained && ev_prev >= 0) {
+            HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_prev], 0));
+            // ... and not before every workgroup of the previous tick's main pass and planned launch has started (bounded: 50 ms; harmless if it gives up)
+            Lane &PL = c->lane[c->ov_lane_last];
+            hipLaunchKernelGGL(qr_gate2_kernel, dim3(1), dim3(64), 0, LN.stream, c->d_main_started, (int)c->ov_main_total, PL.d_started, (int)PL.started_total, (long long)5000000,
+                               c->d_timeline ? c->d_timeline + 512 + (epoch & 63u) * 2 : (long long *)nullptr);      // (diagnostic: qrgpu_debug_gate2)
+            HIPCHK(c, hipGetLastError());
+        } else {
+            ov.chained = false;
+            HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_now], 0));
+        }
+        c->ev_call_last = ev_now;
+        for (int a = 0; a < 4; ++a) c->ov_out[a] = outs[a];
+    }
     // (No fork event from the context stream: the gate below opens only once this tick's main pass -- queued on the context stream behind
     //  everything the caller put there -- is running, and the WBC launch of the previous tick is ahead of this one on the same stream.
     //  QRGPU_PIPE_FORK=1 puts the event back: 10-15 us of cross-stream hand-over per tick.)
     static const int pipe_fork = [] { const char *e = getenv("QRGPU_PIPE_FORK"); return e ? atoi(e) : 0; }();
-    if (pipe_fork) {
+    if (pipe_fork && !ovl) {
         HIPCHK(c, hipEventRecord(c->ev_wbc_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->wbc_stream, c->ev_wbc_fork, 0));
     }
-    // (QRGPU_PIPE_EARLY=K opens the gate K workgroups early: an experiment)
+    // (QRGPU_PIPE_EARLY=K opens the gate K workgroups early: an experiment, see LAB_NOTES.md)
     static const int pipe_early = [] { const char *e = getenv("QRGPU_PIPE_EARLY"); return e ? atoi(e) : 0; }();
     // (the half of d_wbc_order this tick's WBC launch reads: taken before launch_mpc, whose trailing launch writes the other half and flips the parity)
-    const int *const wbc_order_in = c->wbc_order_n == n ? c->d_wbc_order + (size_t)c->wbc_order_parity * (size_t)c->max_batch : nullptr;
-    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true);
+    const int *const wbc_order_in = (c->wbc_order_n == n && !ovl) ? c->d_wbc_order + (size_t)c->wbc_order_parity * (size_t)c->max_batch : nullptr;
+    int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true, lane_id,
+                        ovl ? &ov : nullptr);
     if (rc) return rc;
-    const int expect = c->main_started_total - pipe_early;          // (launch_mpc has added this tick's main-pass units to main_started_total)
+    const int expect = (int)(c->main_started_total - (unsigned)pipe_early);          // (launch_mpc has added this tick's main-pass units to main_started_total)
     // (bounded at 50 ms; QRGPU_PIPE_GATE_MS for the tests.  A gate that gives up -- the caller had that much work of its own queued in front of
     //  this tick -- turns the tick into the serial one: WbcPipe::gate_abort)
     static const long long gate_ticks = [] { const char *e = getenv("QRGPU_PIPE_GATE_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, c->wbc_stream, c->d_main_started, expect, gate_ticks, c->d_gate_abort, (int)c->tick_epoch, (int *)nullptr);
+    const hipStream_t wbc_stream = ovl ? c->wbc_stream_hi : c->wbc_stream;
+    // (an overlapped tick has no second pass to fall back on: its gate is patient -- 2 s -- and one that gives up just lets the launch go: every wait
+    //  of a WBC workgroup for its robot's forces is bounded and flagged.  What the serial fall-back protects against -- inputs that the caller's stream
+    //  has not produced yet -- cannot happen: a chained tick's inputs are ready by contract, an unchained one makes this stream wait for the event too)
+    if (ovl && !ov.chained) HIPCHK(c, hipStreamWaitEvent(wbc_stream, c->ev_call[c->ev_call_last], 0));
+    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, wbc_stream, c->d_main_started, expect, ovl ? 200000000LL : gate_ticks, ovl ? (int *)nullptr : gate_abort, (int)epoch,
+                       (int *)nullptr);
     HIPCHK(c, hipGetLastError());
-    // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
-    // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
-    static const int pipe_join = [] { const char *e = getenv("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
-    WbcPipe wp{c->d_done_flag, c->tick_epoch, nullptr, nullptr, c->d_gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in};
+    unsigned *const wbc_done = ovl ? c->d_wbc_done : nullptr;
+    const unsigned wait_epoch = (ovl && ov.chained) ? (prev_epoch ^ ov_fault) : 0u;
+    WbcPipe wp{LN.d_done_flag, epoch, nullptr, nullptr, ovl ? (int *)nullptr : gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in, wbc_done, wait_epoch, ov_wait_ticks(),
+               ovl ? 1 : 0};
     rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
-                    c->wbc_stream, wp);
+                    wbc_stream, wp);
     if (rc) return rc;
     if (!pipe_join) HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
-    {   // the second pass: the robots of the trailing launch's list (there is one at h <= 11) -- or every robot, should the gate have given up
-        const bool have_list = c->last_rescue_active;
-        WbcPipe lp{nullptr, c->tick_epoch, have_list ? c->d_rescue + 2 : nullptr, have_list ? c->d_rescue + c->last_rescue_parity : nullptr, c->d_gate_abort, 1, nullptr,
-                   nullptr, c->d_timeline, nullptr};
+    if (!ovl) {   // the second pass: the robots of the trailing launch's list (there is one at h <= 11) -- or every robot, should the gate have given up
+        const bool have_list = LN.last_rescue_active;
+        WbcPipe lp{nullptr, epoch, have_list ? LN.d_rescue + 2 : nullptr, have_list ? LN.d_rescue + LN.last_rescue_parity : nullptr, gate_abort, 1, nullptr,
+                   nullptr, c->d_timeline, nullptr, nullptr, 0u, 0, 0};
         rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr, nullptr, lp);
         if (rc) return rc;
     }
     if (pipe_join) {
-        c->wbc_finished_total += 2 * n;
+        c->wbc_finished_total += 2u * (unsigned)n;
         // (... and for the all-gathers queued before this tick, so that the fence in front of the next tick need not queue a launch: qr_join_kernel)
         int *g0 = c->d_gather_done, *g1 = c->d_gather_done ? c->d_gather_done + 1 : nullptr;
-        hipLaunchKernelGGL(qr_join_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, c->wbc_finished_total, (long long)2000000, c->lane[0].d_pre_hint + 2,
-                           g0, c->gather_total[0], g1, c->gather_total[1], c->d_tick_done);
+        hipLaunchKernelGGL(qr_join_kernel, dim3(1), dim3(64), 0, c->stream, c->d_wbc_finished, (int)c->wbc_finished_total, (long long)2000000, c->lane[0].d_pre_hint + 2,
+                           g0, (int)c->gather_total[0], g1, (int)c->gather_total[1], c->d_tick_done, (int *)nullptr, 0,
+                           c->d_join_dbg ? c->d_join_dbg + 8 * (c->tick_done_total & 15u) : (long long *)nullptr);
         HIPCHK(c, hipGetLastError());
         c->gather_joined[0] = c->gather_total[0]; c->gather_joined[1] = c->gather_total[1];
         ++c->tick_done_total; c->last_tick_piped = true;
     } else HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wbc_join, 0));
+    if (ovl) {
+        ++c->ov_stats[ov.chained ? 0 : 1];
+        c->ov_chain = true; c->ov_n = n; c->ov_epoch = epoch; c->ov_main_total = c->main_started_total; c->ov_prev_ori = (const void *)d_prev_ori; c->ov_lane_last = lane_id;
+    }
+    return QRGPU_OK;
+}
+
+// Overlapped ticks: see include/qrgpu.h.  Switching them on creates lanes 1 and 2 and PROBES that two of the context's streams really run side
+// by side in this process (a launch on one lane that waits for a launch queued afterwards on the other): with fewer hardware queues than streams
+// (GPU_MAX_HW_QUEUES, default 4, against the context's seven) two streams may share one, a chained tick would sit out its gates' bounds behind its
+// predecessor, and the mode is refused -- QRGPU_ERR_NOT_SETUP, qrgpu_last_error says why, ticks stay as they were.
+int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    c->ov_chain = false;
+    if (!on) { c->overlap = 0; return QRGPU_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ev_call[0]) for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->ev_call[k], hipEventDisableTiming));
+    if (!c->wbc_stream_hi) {
+        static const int hi = [] { const char *e = getenv("QRGPU_OV_WBC_PRIORITY"); return e ? atoi(e) : 1; }();
+        if (hi) HIPCHK(c, create_side_stream(&c->wbc_stream_hi));
+        else HIPCHK(c, hipStreamCreateWithFlags(&c->wbc_stream_hi, hipStreamNonBlocking));
+    }
+    for (int l = 1; l < QR_LANES; ++l) {
+        if (lane_create(c, c->lane[l], true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a lane failed"; return QRGPU_ERR_ALLOC; }
+        c->lane[l].side_stream = c->lane[0].side_stream;         // (planned launches of consecutive ticks: one stream, in tick order)
+    }
+    // probe, both ways round, and each lane's stream against the WBC stream and the context's
+    int *d_probe = nullptr;
+    HIPCHK(c, hipMalloc(&d_probe, 16 * sizeof(int)));
+    HIPCHK(c, hipMemset(d_probe, 0, 16 * sizeof(int)));
+    HIPCHK(c, hipDeviceSynchronize());
+    hipStream_t st[4] = {c->lane[1].stream, c->lane[2].stream, c->wbc_stream_hi, c->stream};
+    int k = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            if (a == b || (a >= 2 && b >= 2)) continue;
+            hipLaunchKernelGGL(qr_probe_wait_kernel, dim3(1), dim3(64), 0, st[a], d_probe + k, d_probe + 8, (long long)200000);      // 2 ms
+            hipLaunchKernelGGL(qr_probe_set_kernel, dim3(1), dim3(64), 0, st[b], d_probe + k);
+            HIPCHK(c, hipStreamSynchronize(st[a]));
+            HIPCHK(c, hipStreamSynchronize(st[b]));
+            int res = 0;
+            HIPCHK(c, hipMemcpy(&res, d_probe + 8, sizeof(int), hipMemcpyDeviceToHost));
+            if (res != 1) {
+                hipFree(d_probe);
+                c->err = "qrgpu_set_tick_overlap: two of the context's streams share a hardware queue in this process (set GPU_MAX_HW_QUEUES=8 before the first HIP call); overlapped ticks stay off";
+                c->overlap = 0;
+                return QRGPU_ERR_NOT_SETUP;
+            }
+            k = (k + 1) & 7;
+        }
+    hipFree(d_probe);
+    c->overlap = 1;
+    return QRGPU_OK;
+}
+int qrgpu_tick_fence(qrgpu_ctx *c) { if (!c) return QRGPU_ERR_BAD_ARG; c->ov_chain = false; return QRGPU_OK; }
+int qrgpu_tick_overlap_stats(const qrgpu_ctx *c, int *chained, int *unchained)
+{
+    if (!c) return QRGPU_ERR_BAD_ARG;
+    if (chained) *chained = c->ov_stats[0];
+    if (unchained) *unchained = c->ov_stats[1];
     return QRGPU_OK;
 }
 
@@ -1383,11 +1561,55 @@ int qrgpu_debug_lists(qrgpu_ctx *c, int *host_out /* [8]: rescue list lengths (b
 {   // undocumented diagnostic: how many robots the last MPC launches handed to the trailing list launch / planned for the next call; which gates gave up
     if (!c || !host_out) return QRGPU_ERR_BAD_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(host_out, c->d_rescue, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(host_out + 2, c->d_pre, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(host_out + 4, c->d_go, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(host_out + 6, c->d_gate_abort, sizeof(int), hipMemcpyDeviceToHost));
-    host_out[7] = c->plan_epoch;
+    // (the lane the context's last launch ran on; the give-up words are rings indexed by epoch: the latest epoch in each is reported)
+    const Lane &L = c->lane[c->ov_chain ? c->ov_lane_last : 0];
+    HIPCHK(c, hipMemcpy(host_out, L.d_rescue, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out + 2, L.d_pre, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    int ring[1 + QR_ABORT_RING];
+    HIPCHK(c, hipMemcpy(ring, L.d_go, sizeof(ring), hipMemcpyDeviceToHost));
+    host_out[4] = ring[0]; host_out[5] = 0;
+    for (int i = 1; i <= QR_ABORT_RING; ++i) if (ring[i] > host_out[5]) host_out[5] = ring[i];
+    HIPCHK(c, hipMemcpy(ring, c->d_gate_abort, QR_ABORT_RING * sizeof(int), hipMemcpyDeviceToHost));
+    host_out[6] = 0;
+    for (int i = 0; i < QR_ABORT_RING; ++i) if (ring[i] > host_out[6]) host_out[6] = ring[i];
+    host_out[7] = L.plan_epoch;
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_counters(qrgpu_ctx *c, int *host_out /* [12]: device count / host total of main_started, wbc_finished, tick_done, lane_done of lanes 1 and 2, epoch */)
+{   // undocumented diagnostic: the cumulative counters the gates and joins poll, as the device and the host see them
+    if (!c || !host_out) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    memset(host_out, 0, 12 * sizeof(int));
+    HIPCHK(c, hipMemcpy(host_out + 0, c->d_main_started, sizeof(int), hipMemcpyDeviceToHost)); host_out[1] = (int)c->main_started_total;
+    HIPCHK(c, hipMemcpy(host_out + 2, c->d_wbc_finished, sizeof(int), hipMemcpyDeviceToHost)); host_out[3] = (int)c->wbc_finished_total;
+    HIPCHK(c, hipMemcpy(host_out + 4, c->d_tick_done, sizeof(int), hipMemcpyDeviceToHost)); host_out[5] = (int)c->tick_done_total;
+    for (int l = 1; l < QR_LANES; ++l)
+        if (c->lane[l].d_lane_done) { HIPCHK(c, hipMemcpy(host_out + 4 + 2 * l, c->lane[l].d_lane_done, sizeof(int), hipMemcpyDeviceToHost)); host_out[5 + 2 * l] = (int)c->lane[l].lane_done_total; }
+    host_out[10] = (int)c->tick_epoch;
+    if (!c->d_join_dbg) { HIPCHK(c, hipMalloc(&c->d_join_dbg, 16 * 8 * sizeof(long long))); HIPCHK(c, hipMemset(c->d_join_dbg, 0, 16 * 8 * sizeof(long long))); }
+    else {
+        long long h[16 * 8];
+        HIPCHK(c, hipMemcpy(h, c->d_join_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) if (h[8 * i]) fprintf(stderr, "  join[%d]: start %lld dur %.1f us expect %lld lane_expect %lld seen %lld lane_seen %lld gave_up %lld\n", i, h[8 * i], (h[8 * i + 1] - h[8 * i]) / 100.0, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6]);
+    }
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_gate2(qrgpu_ctx *c, long long *host_out /* [64][2]: when the gate in front of a chained tick's launches came up / opened, by epoch & 63 */)
+{
+    if (!c || !c->d_timeline || !host_out) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 512, sizeof(long long) * 128, hipMemcpyDeviceToHost));
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_words(qrgpu_ctx *c, unsigned *solved, unsigned *wbc_done, int n)
+{   // undocumented diagnostic: the per-robot epoch words of the overlapped tick
+    if (!c || n <= 0 || n > c->max_batch) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    if (solved) HIPCHK(c, hipMemcpy(solved, c->d_solved, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost));
+    if (wbc_done) HIPCHK(c, hipMemcpy(wbc_done, c->d_wbc_done, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost));
     return QRGPU_OK;
 }
 
@@ -1402,7 +1624,7 @@ int qrgpu_debug_timeline(qrgpu_ctx *c, long long *host_out /* [65][8] (row 64, e
 #endif
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->wbc_stream));
-    if (!c->d_timeline) HIPCHK(c, hipMalloc(&c->d_timeline, sizeof(long long) * 512));
+    if (!c->d_timeline) { HIPCHK(c, hipMalloc(&c->d_timeline, sizeof(long long) * 640)); HIPCHK(c, hipMemset(c->d_timeline, 0, sizeof(long long) * 640)); }
     if (!c->d_tlr) HIPCHK(c, hipMalloc(&c->d_tlr, sizeof(int) * 4 * (size_t)c->max_batch));
     if (host_out) HIPCHK(c, hipMemcpy(host_out, c->d_timeline, sizeof(long long) * 512, hipMemcpyDeviceToHost));
     long long init[512];
@@ -1504,6 +1726,9 @@ int qrgpu_get_timing(qrgpu_ctx *c, int kernel, double *mean_ms, int *count)
     double tot = 0.0;
     for (size_t i = 0; i < c->ev_used[kernel]; ++i) {
         float ms = 0.f;
+        // (a pipelined tick records the WBC launch's events on the WBC stream, an overlapped one the main pass's on a lane's stream: the tick's join on
+        //  the context's stream polls counts the kernels bump BEFORE they retire, so the second event may still be pending)
+        HIPCHK(c, hipEventSynchronize(c->ev[kernel][i].second));
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[kernel][i].first, c->ev[kernel][i].second));
         tot += ms;
     }

@@ -49,7 +49,8 @@ struct Lane {
     bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
     unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by this lane's solves for the WBC launch
     float *d_cmd_tick = nullptr;              // [12][max_batch] force scratch of a tick whose caller passes no force array
-    int *d_lane_done = nullptr;               // overlapped ticks of this lane whose launches on the lane's stream are through, ever (the tick's join polls it)
+    hipEvent_t ev_tail = nullptr;             // the lane's MPC launches of a tick are through (the tail stream waits for it)
+    int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
     unsigned lane_done_total = 0;
 };
 
@@ -114,7 +115,23 @@ struct qrgpu_ctx {
     const void *ov_out[4] = {nullptr, nullptr, nullptr, nullptr};   // ... writing these output arrays (force, tau, qdes, status)
     const void *ov_prev_ori = nullptr;        // ... and this orientation-task memory
     int ov_lane_last = 0;                     // ... on this lane
+    int ov_hold = 0;                          // calls left on the plain pipelined tick after a lane found a plan (a population with whole-CU robots)
+    bool ov_prev_plan = false;                // ... with a planned launch (its successor is not chained either)
     hipEvent_t ev_ov_fence = nullptr;
+    // the tail of an overlapped tick -- its second WBC pass and the count its join polls -- runs on a stream of its own behind an event of the lane's
+    // stream: on the lane's stream those thousand (empty) workgroups, dispatched one freed slot at a time on a machine that is never empty, stood
+    // between the lane's next tick and its gate (60 us per tick)
+    hipStream_t tail_stream = nullptr;
+    // the WBC launches of overlapped ticks: a stream of the highest priority.  Tick k's WBC workgroups and tick k + 1's solves want the same freed
+    // slots; at equal priority the solves get most of them, tick k's WBC launch lasts until tick k + 1's main pass is dispatched (tick duration: two
+    // periods) and tick k + 2, which waits for tick k's join, starts late every other tick
+    hipStream_t wbc_stream_hi = nullptr;
+    // a chained tick waits for what the caller had queued on the context's stream when it made the PREVIOUS tick call (its predecessor's predecessor's
+    // join and whatever consumed that tick's outputs: the arrays this tick overwrites), recorded at that call: ring of two
+    hipEvent_t ev_call[2] = {nullptr, nullptr};
+    int ev_call_last = -1;                    // index of the event recorded at the last overlapped tick call (-1: none)
+    long long *d_join_dbg = nullptr;          // diagnostic (qrgpu_debug_counters): what the last joins saw
+    int ov_stats[2] = {0, 0};                 // overlapped ticks issued so far: chained to their predecessor / behind an event of the context's stream
     unsigned *d_solved = nullptr;             // [max_batch] epoch of the overlapped tick whose solve of the robot has left its warm-start and cost words in memory
     unsigned *d_wbc_done = nullptr;           // [max_batch] ... whose WBC pass has left the orientation task's memory (prev_ori) in memory
     int *d_tlr = nullptr;                     // diagnostic: [4][max_batch] per-robot WBC moments of the last pipelined tick

@@ -113,7 +113,8 @@ EXPORTS = ["qrgpu_model_desc_default", "qrgpu_create", "qrgpu_destroy", "qrgpu_s
            "qrgpu_set_torque_epilogue", "qrgpu_comm_unique_id", "qrgpu_comm_init_rank", "qrgpu_comm_info", "qrgpu_comm_destroy",
            "qrgpu_allgather_tau", "qrgpu_allgather_tau_of_tick", "qrgpu_allgather_fence", "qrgpu_allgather_wait", "qrgpu_comm_sync", "qrgpu_set_warm_start", "qrgpu_set_planned_list",
            "qrgpu_enable_flop_count", "qrgpu_mpc_flop_counts", "qrgpu_mpc_set_hessian_mode", "qrgpu_wbc_inspect_batch", "qrgpu_host_alloc", "qrgpu_host_free",
-           "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms", "qrgpu_set_tick_pipeline"]
+           "qrgpu_memcpy_async", "qrgpu_memset_async", "qrgpu_mark", "qrgpu_mark_elapsed_ms", "qrgpu_set_tick_pipeline", "qrgpu_set_tick_overlap",
+           "qrgpu_tick_fence", "qrgpu_tick_overlap_stats"]
 
 
 def load_library():
@@ -121,6 +122,9 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # a context owns more streams than the HIP runtime's default of four hardware queues; streams that share a queue serialise each other and
+    # the overlapped tick is refused (qrgpu_set_tick_overlap).  Read by the runtime at its first call in the process: a caller's own value stands.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     p = lib_path()
     if not os.path.exists(p):
         raise MissingExtension("%s not found: the HIP extension must be built first (no CPU fallback exists)" % p)
@@ -147,6 +151,9 @@ def load_library():
     lib.qrgpu_wbc_run_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_wbc_inspect_batch.argtypes = [vp, ip] + [vp] * 7
     lib.qrgpu_tick_batch.argtypes = [vp, ip] + [vp] * 11
+    lib.qrgpu_set_tick_overlap.argtypes = [vp, ip]
+    lib.qrgpu_tick_fence.argtypes = [vp]
+    lib.qrgpu_tick_overlap_stats.argtypes = [vp, C.POINTER(ip), C.POINTER(ip)]
     lib.qrgpu_set_torque_epilogue.argtypes = [vp, ip]
     lib.qrgpu_comm_unique_id.argtypes = [C.c_char_p]
     lib.qrgpu_comm_init_rank.argtypes = [vp, C.c_char_p, ip, ip]
@@ -306,6 +313,9 @@ class Context:
         if rc != 0:
             raise QrgpuError("%s: %s" % (ERRORS.get(rc, rc), self._lib.qrgpu_last_error(self._h).decode()))
 
+    def last_error(self):
+        return self._lib.qrgpu_last_error(self._h).decode()
+
     # -- setup ---------------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
         self._chk(self._lib.qrgpu_set_stream(self._h, C.c_void_p(int(stream_ptr) if stream_ptr else 0)))
@@ -382,6 +392,26 @@ class Context:
     def set_tick_pipeline(self, on=True):
         """WBC launch of a tick beside its MPC launches (default) or behind them."""
         self._chk(self._lib.qrgpu_set_tick_pipeline(self._h, 1 if on else 0))
+
+    def set_tick_overlap(self, on=True, strict=True):
+        """Consecutive pipelined ticks (h <= 11) that write different output arrays overlap: tick t + 1's solves start in tick t's drain
+        (include/qrgpu.h: the caller's promise about inputs).  -> True when the mode is on.  The library refuses it when two of the context's
+        streams share a hardware queue (GPU_MAX_HW_QUEUES): strict raises, otherwise False is returned and ticks stay as they were."""
+        rc = self._lib.qrgpu_set_tick_overlap(self._h, 1 if on else 0)
+        if rc == 3 and not strict:             # QRGPU_ERR_NOT_SETUP
+            return False
+        self._chk(rc)
+        return bool(on)
+
+    def tick_overlap_stats(self):
+        """-> (ticks chained to their predecessor, overlapped-form ticks that waited for the context's stream instead)"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.qrgpu_tick_overlap_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def tick_fence(self):
+        """The next overlapped tick waits for everything queued on the context's stream so far (inputs produced there since the last tick)."""
+        self._chk(self._lib.qrgpu_tick_fence(self._h))
 
     def set_torque_epilogue(self, hip_comp=False, clip=False):
         """K14 tail on the batched torques: +-0.9 N m abad compensation (qr_fsm_state_locomotion.cpp:141-151), +-23 N m clip (qr_safety_checker.cpp:48-66)."""
