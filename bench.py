@@ -19,9 +19,10 @@ and its share of the K timed steps, bracketed by barrier + synchronize; `value` 
 over ranks of its time), min / max / per-draw rates beside it.
 
 No GPU array library is involved: device buffers, pinned host buffers, the stream, event timing and the collective are all behind the C
-ABI of include/qrgpu.h (qrgpu_malloc, qrgpu_host_alloc, qrgpu_enable_timing, qrgpu_mark, qrgpu_allgather_tau).  With N = 1 torch is
-not imported at all; with N > 1 torch.distributed's CPU backend (gloo) is the launcher's plumbing -- barrier, max-reduce of the draw
-times, handing rank 0's 128-byte communicator id to the other ranks.  Rank 0 prints ONE JSON line.
+ABI of include/qrgpu.h (qrgpu_malloc, qrgpu_host_alloc, qrgpu_enable_timing, qrgpu_mark, qrgpu_allgather_tau).  torch is not imported
+at any N: with N > 1 the launcher's plumbing -- rendezvous, barrier, max-reduce of the draw times, handing rank 0's 128-byte communicator
+id to the other ranks -- is a localhost socket (quadruped-robot_amd/rendezvous.py; the ranks find each other through RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT as torch.distributed.run or this program's own launcher set them).  Rank 0 prints ONE JSON line.
 
   python bench.py --mode single     the drop-in boundary's single-robot latency (qrgpu_mpc_solve1 / qrgpu_wbc_run1, and both through the C++
                                     adapters): p50 / p99 over 1000 calls at h = 5, 10, 16 beside the reference's solver on the same QPs
@@ -61,6 +62,16 @@ def _load_pkg():
     return mod
 
 
+def _load_rendezvous():
+    """quadruped-robot_amd/rendezvous.py on its own (standard library only): the dry run of the launcher test has no built extension to load."""
+    if "quadruped_robot_amd" in sys.modules:
+        return sys.modules["quadruped_robot_amd"].rendezvous
+    spec = importlib.util.spec_from_file_location("qrgpu_rendezvous", os.path.join(ROOT, "quadruped-robot_amd", "rendezvous.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def cpu_baseline(pkg, b, horizon, mode=1, epilogue=3, budget_s=6.0):
     """The CPU restatement (oracle/, kind "port") timed on this box's host cores over a bounded sample: the same tick the GPU runs
     (K12 always runs on the CPU side, as in the reference; K14 tail on)."""
@@ -94,6 +105,11 @@ def cpu_baseline(pkg, b, horizon, mode=1, epilogue=3, budget_s=6.0):
                       "K12 and the K14 tail included" % (passes, n, cores),
                single_thread_value=m1 / t1)
     out.update(reference_solver(pkg, O, b, horizon))
+    if out.get("reference_solver_ratio"):
+        # DERIVED, not measured: what this box's cores would do with the reference's own solver in the port's place (>= 95 % of the reference's tick is
+        # its QP solve) -- the port's rate divided by how much slower the reference's solver is on the same QPs
+        out["reference_equivalent_ticks_per_s"] = out["value"] / out["reference_solver_ratio"]
+        out["reference_equivalent_is"] = "derived: value / reference_solver_ratio (the reference's Eigen glue cannot be built here; its solver can, and is >= 95 % of its tick)"
     return out
 
 
@@ -341,7 +357,15 @@ def self_launch(args, argv):
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     deadline = None
+    # an overall deadline as well: ranks that all hang (a collective that never completes) are killed -- fresh children only, this parent never
+    # touched a GPU -- and the run fails instead of sitting there (QRGPU_BENCH_DEADLINE_S, default 1500 s)
+    overall = time.time() + float(os.environ.get("QRGPU_BENCH_DEADLINE_S", "1500"))
     while procs:
+        if time.time() > overall and rc == 0:
+            print("bench.py: the ranks did not finish within the deadline: killing them", file=sys.stderr)
+            rc = 124
+            for p in procs:
+                p.kill()
         for p in list(procs):
             code = p.poll()
             if code is None:
@@ -437,24 +461,27 @@ def main():
     rehearsal = os.environ.get("QRGPU_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    dist = None
+    grp = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # launcher plumbing on the CPU: barrier, max-reduce of times, the communicator id
-        dist.init_process_group(backend="gloo")
+        # launcher plumbing on the CPU, over a localhost socket (quadruped-robot_amd/rendezvous.py): barrier, max-reduce of times, the communicator
+        # id -- no GPU array library is imported at any N
+        grp = _load_rendezvous().Group(rank, world)
     dry = os.environ.get("QRGPU_BENCH_DRY", "")
     if dry:
         # launcher self-test (tests/test_bench_launch.py, no GPU): rendezvous, one max-reduce, one JSON line; "fail<r>" makes rank r exit 3 first
         if dry == "fail%d" % rank:
             sys.exit(3)
+        if dry == "hang":
+            time.sleep(3600)
         v = float(rank + 1)
+        if os.environ.get("QRGPU_BENCH_DRY_ASSERT_NO_TORCH") and "torch" in sys.modules:
+            sys.exit(5)
         if os.environ.get("QRGPU_BENCH_DRY_NOISE"):
             os.write(1, b"a library's banner on file descriptor 1\n")      # what RCCL does when its first communicator comes up (the launcher test)
         if world > 1:
-            t = torch.tensor([v], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); v = float(t.item())
-            dist.barrier(); dist.destroy_process_group()
+            v = grp.allreduce_max(v)
+            grp.barrier(); grp.close()
         if rank == 0:
             emit({"metric": "launcher self-test", "value": v, "n_gpus": world, "dry": True})
         return
@@ -463,7 +490,7 @@ def main():
     if rank == 0 or (local_rank == 0 and not rehearsal):
         pkg._build.build()          # one build per node; the other ranks wait (the build is also file-locked)
     if world > 1:
-        dist.barrier()
+        grp.barrier()
     if args.mode == "single":
         emit(single_mode(args, pkg))
         return
@@ -482,7 +509,7 @@ def main():
     # check of the gathered block -- with world = 1: what that path costs a rank's ticks, measured where there is only one GPU
     comm_on = (world > 1 and not rehearsal) or (world == 1 and os.environ.get("QRGPU_BENCH_FORCE_COMM") == "1")
     if world > 1 and not rehearsal:
-        ctx.comm_init_rank(pkg.shard.exchange_comm_id(rank, pkg.qrgpu.comm_unique_id), world, rank)     # RCCL communicator owned by the context
+        ctx.comm_init_rank(pkg.rendezvous.exchange_comm_id(grp, pkg.qrgpu.comm_unique_id), world, rank)     # RCCL communicator owned by the context
     elif comm_on:
         ctx.comm_init_rank(pkg.qrgpu.comm_unique_id(), 1, 0)
     ctx.set_torque_epilogue(hip_comp=True, clip=True)          # K14 tail is part of the tick SURVEY 8(d) defines
@@ -536,7 +563,9 @@ def main():
     # t + 1's solves in the slots tick t's drain leaves empty (qrgpu_set_tick_overlap, include/qrgpu.h; QRGPU_BENCH_OVERLAP=0: one set of
     # arrays, the mode off -- rounds 1-3's form).  The mode is a promise about INPUTS too: every batch of every sequence is resident in HBM
     # before the first timed step (above), and nothing is queued on the context's stream between ticks.
-    want_overlap = args.mode == "tick" and os.environ.get("QRGPU_BENCH_OVERLAP", "1") != "0"
+    # (one rank only: with the exchange of N > 1 in the loop -- a fence in front of and a gather behind every tick -- it gains nothing, measured with
+    #  a one-rank communicator: 4.45 M ticks/s either way -- and the first run on several GPUs is to be a boring one)
+    want_overlap = args.mode == "tick" and world == 1 and not comm_on and os.environ.get("QRGPU_BENCH_OVERLAP", "1") != "0"
     overlap_on = want_overlap and ctx.set_tick_overlap(True, strict=False)
     nbuf = 2 if (overlap_on or world > 1 or comm_on) else 1
     d_force2 = [dv.zeros((12, n)) for _ in range(nbuf)]
@@ -566,9 +595,8 @@ def main():
         if world > 1 or comm_on:
             if rehearsal:
                 ctx.sync()
-                parts = [torch.empty((12, n)) for _ in range(world)]
-                dist.all_gather(parts, torch.from_numpy(tau.download()))
-                d_tau_all.upload(torch.stack(parts).numpy())
+                parts = grp.allgather_bytes(np.ascontiguousarray(tau.download(), np.float32).tobytes())
+                d_tau_all.upload(np.stack([np.frombuffer(p_, np.float32).reshape(12, n) for p_ in parts]))
             else:
                 ctx.allgather_tau(tau, n, d_tau_all, slot, of_tick=(args.mode == "tick"))     # RCCL over xGMI on the context's own stream: the only exchange of the path
 
@@ -580,7 +608,7 @@ def main():
             ctx.comm_sync()
         if world > 1:
             ctx.sync()
-            dist.barrier()
+            grp.barrier()
         ctx.sync()
 
     def reset(draw, k12=True, fixed=None, lpt=True):
@@ -603,9 +631,7 @@ def main():
         el = time.perf_counter() - t0
         if cur.get("ktime"): ctx.enable_timing(-1)
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = grp.allreduce_max(el)
         return el
 
     # ---- the timed region: K steps split over the draws -------------------------------------------------------------------
@@ -618,6 +644,16 @@ def main():
     ctx.enable_timing(0)
     if ktime:
         ctx.enable_timing(ktime); ctx.enable_timing(-1)        # the event pool is made here, paused: nothing of it inside a draw's barrier-to-barrier region
+    if world > 1 or comm_on:
+        # The first 8 steps of the run, untimed, every one of them checked: this rank's block of the gathered torques IS its local torque array of
+        # that step, on every rank (a gather that reads a buffer too early, too late or from the wrong slot shows here, not in the rate).
+        reset(0)
+        for k_ in range(8):
+            step()
+            fence()
+            own = d_tau_all.download()[rank]
+            if not np.array_equal(own, d_tau2[last_slot()].download()):
+                raise RuntimeError("rank %d, step %d: all-gathered torques differ from the local ones" % (rank, k_))
     draw_s, draw_flags, draw_itmax, draw_itmean = [], [], [], []
     cur["ktime"] = ktime
     for d in range(D):
@@ -697,6 +733,35 @@ def main():
         ctx.enable_flop_count(False)
         fence()
         flop = acc
+        # roofline.imbalance: what bounds the main pass is not a phase's mean but the packing of a thousand solves of very different length into 512
+        # slots -- 1 - (sum of solve times / slots) / span, from the instrumented kernel's own stamps on the shared 100 MHz clock (four more untimed,
+        # MPC-only launches on draw 0; h <= 11: two workgroups per CU)
+        imbalance = None
+        if args.mode == "tick" and h <= 11:
+            import ctypes as C_
+            lib_ = ctx._lib
+            lib_.qrgpu_debug_cycles.argtypes = [C_.c_void_p, C_.c_void_p, C_.c_int]
+            lib_.qrgpu_debug_cycles(ctx._h, None, 0)
+            vals = []
+            for k_ in range(6):
+                ds, dt_, dg, dfb, dcmd = dev_seq[0][walk[k_ % len(walk)]]
+                ctx.mpc_solve_batch(n, ds, dt_, dg, dfb.row(13), d_force2[0], d_tau2[0], d_status2[0])
+                ctx.sync()
+                if k_ < 2:
+                    continue
+                buf = np.zeros((n, 16), np.int64)
+                lib_.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, n)
+                t0_, t6_ = buf[:, 12].astype(np.float64), buf[:, 13].astype(np.float64)
+                good = t6_ > t0_
+                span = t6_[good].max() - t0_[good].min()
+                slots = 2 * ctx.device_info()["cus"]
+                vals.append(dict(imb=1.0 - ((t6_[good] - t0_[good]).sum() / slots) / span, span_us=span / 100.0, mean_us=float((t6_[good] - t0_[good]).mean() / 100.0),
+                                 max_us=float((t6_[good] - t0_[good]).max() / 100.0)))
+            lib_.qrgpu_debug_cycles(ctx._h, None, -1)
+            imbalance = {"value": float(np.mean([v["imb"] for v in vals])), "span_us": float(np.mean([v["span_us"] for v in vals])),
+                         "mean_solve_us": float(np.mean([v["mean_us"] for v in vals])), "longest_solve_us": float(np.mean([v["max_us"] for v in vals])),
+                         "what": "1 - (sum of the robots' solve times / resident slots) / span of the main pass, mean over 4 instrumented MPC launches of draw 0: the share of "
+                                 "the dominant launch's slot-time that is empty (coarse bin packing: ~2 rounds of solves of 40-140 us)"}
 
     side = {}
     if world == 1 and not args.no_side and args.mode == "tick":
@@ -807,19 +872,25 @@ def main():
                                             "measured) over the same kernel time: a yardstick against that accounting, not work the kernel does (swing variables are "
                                             "eliminated, zero terms skipped)"},
                 "traffic": traffic, "traffic_source": traffic_src,
+                "imbalance": imbalance,
                 "kernel_ms": dom_ms, "kernel_launches": mpc_cnt, "other_kernel_ms": wbc_ms,
                 "other_kernel_ms_is": "span of the WBC launch on its own stream; in the pipelined tick it runs BESIDE the MPC launches and includes the wait for "
                                       "each robot's forces (config.serial_tick_kernel_ms.wbc is the kernel on its own)",
                 "kernel_ms_is": "mean over the launches bracketed by HIP events on the launching stream: every %d-th timed step" % ktime,
-                "outside_kernels_ms": ms_pooled - mpc_ms if args.mode == "tick" else None,
+                "outside_kernels_ms": (ms_pooled - mpc_ms) if (args.mode == "tick" and not overlap_on) else None,
+                "kernel_alone": ({"kernel_ms": side["serial_tick_kernel_ms"]["mpc"], "frac": f64 * sec / (side["serial_tick_kernel_ms"]["mpc"] * 1e-3) / PEAK_F64_VECTOR_TFLOPS,
+                                  "what": "the same launch with the machine to itself (serial tick, config.serial_tick_kernel_ms): with overlapped ticks `kernel_ms` is the "
+                                          "span of a launch that shares the machine with its predecessor's drain and its successor's first workgroups"}
+                                 if (overlap_on and side.get("serial_tick_kernel_ms")) else None),
                 "outside_kernels_is": "all timed steps pooled: ms per step minus the MPC main pass's mean time = what of a tick is not hidden behind the main pass "
-                                      "(the tail of the WBC launch that runs beside it, the trailing list launch, the list-driven WBC pass, stream hand-overs)",
+                                      "(the tail of the WBC launch that runs beside it, the trailing list launch, the list-driven WBC pass, stream hand-overs); "
+                                      "null with overlapped ticks, where a launch's span is longer than a step",
                 "hbm_algorithmic_GBs": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9, "hbm_frac": BYTES_PER_TICK * n / (dom_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         what = "full MPC+WBC tick (K1-K14: kinematic projection on, motor tail on)"
         out = {
             "metric": "MPC+WBC control ticks/s (batched robots)" if args.mode == "tick" else "%s-only control ticks/s (batched robots)" % args.mode.upper(),
             "value": value, "unit": "ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_pooled": ms_pooled, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16x3 Hessian (fp32 accumulate) / f32 assembly / f64 QP+WBC" if args.hessian == "bf16x3" else "f32 assembly / f64 QP+WBC"), "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[4] per GPU: %d A1 + %d Lite3 robots interleaved, horizon %d, %s (%s, fp64 QP)" % (n // 2, n // 2, h, what, "bf16x3 Hessian MFMA" if args.hessian == "bf16x3" else "fp32 assembly")) if args.mixed
                        else "BASELINE.json configs[2]: %d A1 robots per GPU, horizon %d, %s" % (n, h, what)
@@ -832,7 +903,7 @@ def main():
                        "rank_batches": "every rank draws the same populations (control)" if args.same_seed_ranks else "every rank draws its own populations",
                        "parallelism": ("robots sharded over %d GPU(s); qrgpu_allgather_tau_of_tick (RCCL, context-owned stream) overlapped with the next tick" % world) + (" [QRGPU_BENCH_FORCE_COMM: one-rank communicator, the exchange of the N > 1 path on one GPU]" if (comm_on and world == 1) else ""),
                        "host_plumbing": "no GPU array library: device / pinned buffers, stream, events and the collective behind the C ABI" +
-                                        ("; torch.distributed (gloo, CPU) for the launcher's barrier / max-reduce / id hand-over" if world > 1 else "; torch not imported"),
+                                        ("; the launcher's barrier / max-reduce / id hand-over over a localhost socket (rendezvous.py)" if world > 1 else "") + "; torch not imported at any N",
                        "mean_active_set_iterations": it_mean, "status_flags_nonzero": int((flags != 0).sum()),
                        "status_flags_nonzero_per_draw": draw_flags, "max_active_set_changes_per_draw": draw_itmax,
                        "dispatch": "longest-first from each robot's solve time of the previous steps, smoothed (running mean, weight 1/2: a prediction -- consecutive steps see different batches)"
@@ -921,8 +992,8 @@ def main():
                             "tests/golden/parity_as_called.json, tests/test_gpu_golden.py)"}
         emit(out)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        grp.barrier()
+        grp.close()
     ctx.close()
 
 

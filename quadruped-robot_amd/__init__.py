@@ -8,6 +8,7 @@ The directory name is not a Python identifier; load it with
 from . import build as _build          # noqa: F401
 from . import workload                  # noqa: F401
 from . import shard                     # noqa: F401
+from . import rendezvous                # noqa: F401
 from . import ticklog                   # noqa: F401
 from . import replay                    # noqa: F401
 from .qrgpu import (Context, QrgpuError, MissingExtension, lib_path, load_library,   # noqa: F401

@@ -1285,6 +1285,10 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
             HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_now], 0));
         }
         c->ev_call_last = ev_now;
+        // (the all-gathers the caller fenced since the last tick -- qrgpu_allgather_fence -- still read output arrays this tick overwrites)
+        for (int sl = 0; sl < 2; ++sl)
+            if (((c->ov_fence_slots >> sl) & 1) && c->ev_gather[sl]) HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_gather[sl], 0));
+        c->ov_fence_slots = 0;
         for (int a = 0; a < 4; ++a) c->ov_out[a] = outs[a];
     }
     // (No fork event from the context stream: the gate below opens only once this tick's main pass -- queued on the context stream behind
@@ -1540,8 +1544,15 @@ int qrgpu_vmc_force_world1(qrgpu_ctx *c, int type_id, const float vmc_in[37], co
 }
 
 int qrgpu_debug_cycles(qrgpu_ctx *c, long long *host_out /* [n][8] or NULL to disable */, int n)
-{   // undocumented diagnostic: phase cycle stamps of the last MPC launch (enable by calling once with NULL first)
+{   // undocumented diagnostic: phase cycle stamps of the last MPC launch (enable by calling once with NULL first; NULL with n < 0 switches them off again)
     if (!c) return QRGPU_ERR_BAD_ARG;
+    if (!host_out && n < 0) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_dbg_cycles) hipFree(c->d_dbg_cycles);
+        if (c->d_dbg_cycles_wbc) hipFree(c->d_dbg_cycles_wbc);
+        c->d_dbg_cycles = nullptr; c->d_dbg_cycles_wbc = nullptr;
+        return QRGPU_OK;
+    }
     if (!c->d_dbg_cycles) {
         HIPCHK(c, hipMalloc(&c->d_dbg_cycles, sizeof(long long) * 16 * (size_t)c->max_batch));
         HIPCHK(c, hipMalloc(&c->d_dbg_cycles_wbc, sizeof(long long) * 16 * (size_t)(c->max_batch + 8)));

@@ -22,14 +22,19 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
 
 namespace {
 
-// The compute stream's wait for a gather (qrgpu_allgather_fence) is a one-thread launch that polls a count bumped by a one-thread launch behind
-// the gather on the communication stream, not a stream event: a wait for an event of another stream costs the waiting stream 5-8 us on this
-// pool even when the event has long happened (the same finding as for the tick's own streams), and the fence sits in
-// front of every tick of a multi-rank run.  QRGPU_COMM_EVENTS=1: the event form.
-bool comm_polls()
+// How the streams of a context learn of a gather.  Two forms:
+//   events (stream-ordered RCCL, nothing else): the gather waits for an event of the compute stream, the fence makes the compute stream wait for an
+//          event of the communication stream.  The DEFAULT whenever the communicator has more than one rank: no run on several GPUs has ever been
+//          available to the builder, and the first one must not depend on anything cleverer than stream order.
+//   polls: one-thread launches poll counts (the tick's join bumps one for the gather, a launch behind the gather bumps one for the fence) -- a wait
+//          for an event of another stream costs the waiting stream 5-8 us on this pool even when the event has long happened, 4 % of a tick
+//          (4.47 against 4.25 M ticks/s with a one-rank communicator on one GPU).  The default for a ONE-rank communicator (where it is tested:
+//          tests/test_gpu_comm.py, bench.py QRGPU_BENCH_FORCE_COMM=1) and opt-in for more: QRGPU_COMM_EVENTS=0.  (QRGPU_COMM_EVENTS=1: events always.)
+bool comm_polls(const qrgpu_ctx *c)
 {
-    static const int ev = [] { const char *e = getenv("QRGPU_COMM_EVENTS"); return e ? atoi(e) : 0; }();
-    return ev == 0;
+    static const int ev = [] { const char *e = getenv("QRGPU_COMM_EVENTS"); return e ? atoi(e) : -1; }();
+    if (ev >= 0) return ev == 0;
+    return !(c && c->comm_nranks > 1);
 }
 
 struct Rccl {
@@ -172,7 +177,7 @@ static int allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int 
     NCCLCHK(c, R, R->AllGather(d_tau, d_tau_all, (size_t)12 * (size_t)n_local, ncclFloat, comm, c->comm_stream));
     // ... and whoever overwrites d_tau (buffer `slot`) later fences on this event
     HIPCHK(c, hipEventRecord(c->ev_gather[slot], c->comm_stream));
-    if (comm_polls()) {
+    if (comm_polls(c)) {
         // (one thread behind the gather on its stream: bumps the slot's count -- and, the count being what it then expects, leaves at once)
         ++c->gather_total[slot];
         hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->comm_stream, c->d_gather_done + slot, c->gather_total[slot], (long long)0, (int *)nullptr, 0,
@@ -191,24 +196,26 @@ int qrgpu_allgather_tau(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n
 int qrgpu_allgather_tau_of_tick(qrgpu_ctx *c, void *nccl_comm, const float *d_tau, int n_local, float *d_tau_all, int slot)
 {
     // the gather of the torques of the context's LAST qrgpu_tick_batch: when that was a pipelined tick the gather waits for that tick, not for the stream
-    return allgather_tau(c, nccl_comm, d_tau, n_local, d_tau_all, slot, c && c->last_tick_piped && comm_polls() && c->d_tick_done != nullptr);
+    return allgather_tau(c, nccl_comm, d_tau, n_local, d_tau_all, slot, c && c->last_tick_piped && comm_polls(c) && c->d_tick_done != nullptr);
 }
 
 int qrgpu_allgather_fence(qrgpu_ctx *c, int slot)
 {
     if (!c || slot < 0 || slot > 1) return QRGPU_ERR_BAD_ARG;
     if (!c->comm_stream || !c->ev_gather_pending[slot]) return QRGPU_OK;
+    // (overlapped ticks run on streams of their own: the next one must wait for this gather too before it overwrites the buffer -- qrgpu_tick_batch)
+    if (c->overlap) c->ov_fence_slots |= 1 << slot;
     // (A wait for an event of another stream costs the waiting stream several microseconds even when the event has long happened -- 8 us between
     //  two launches on this pool, against 2 without.  The gather of two steps ago normally HAS happened by the time the host queues this step:
     //  ask first, and put the wait on the stream only when it is still running.  hipErrorNotReady is not an error here.)
-    if (comm_polls() && c->gather_joined[slot] == c->gather_total[slot]) {     // a pipelined tick's join has waited for this gather already
+    if (comm_polls(c) && c->gather_joined[slot] == c->gather_total[slot]) {     // a pipelined tick's join has waited for this gather already
         c->ev_gather_pending[slot] = false;
         return QRGPU_OK;
     }
     const hipError_t q = hipEventQuery(c->ev_gather[slot]);
     if (q != hipSuccess) {
         (void)hipGetLastError();
-        if (comm_polls()) {
+        if (comm_polls(c)) {
             // bounded (30 s: another rank may be late with its side of the collective, and the first gather also sets up RCCL's connections; beyond
             // that it is a hung collective, the stream goes on and qrgpu_sync reports it)
             hipLaunchKernelGGL(qrgpu::qr_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gather_done + slot, c->gather_total[slot], (long long)3000000000LL,

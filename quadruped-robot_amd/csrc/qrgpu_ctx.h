@@ -115,6 +115,7 @@ struct qrgpu_ctx {
     const void *ov_out[4] = {nullptr, nullptr, nullptr, nullptr};   // ... writing these output arrays (force, tau, qdes, status)
     const void *ov_prev_ori = nullptr;        // ... and this orientation-task memory
     int ov_lane_last = 0;                     // ... on this lane
+    int ov_fence_slots = 0;                   // bit s: qrgpu_allgather_fence(s) was called since the last overlapped tick (that tick's lane waits for the gather too)
     int ov_hold = 0;                          // calls left on the plain pipelined tick after a lane found a plan (a population with whole-CU robots)
     bool ov_prev_plan = false;                // ... with a planned launch (its successor is not chained either)
     hipEvent_t ev_ov_fence = nullptr;
