@@ -647,6 +647,69 @@ def test_planned_launch_whose_go_never_comes_is_called_off(pkg):
     assert int(res[3]) == 1, res          # (the plan was called off in that tick; the WBC launch's gate gives up too unless the streams share a hardware queue)
 
 
+_BACKLOG3_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+h, n = 10, 512
+ctx = pkg.Context(0, 1024, 16)
+G.setup_a1(ctx, pkg, h)
+trot = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=0.0, frac_three_leg=0.0)
+stance = pkg.make_batch(n, h, "a1", seed=0x51A7, frac_all_stance=1.0, frac_three_leg=0.0, excite=2.0)
+b = {key: (v.copy() if isinstance(v, np.ndarray) else v) for key, v in trot.items()}
+idx = np.arange(24) * (n // 24) + 3
+for key in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+    b[key][idx] = stance[key][idx]
+S = pkg.to_soa
+d = dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+         fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])), prev=ctx.alloc((3, n)).upload(S(b["prev_ori_vel"])))
+outs = [dict(force=ctx.alloc((12, n)), tau=ctx.alloc((12, n)), status=ctx.alloc((n,), np.int32)) for _ in range(4)]
+def tick(o):
+    ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], d["prev"], o["force"], o["tau"], o["status"])
+for _ in range(6):                                # a plan exists and the host has seen its length
+    tick(outs[0]); ctx.sync()
+ref_tau, ref_st = outs[0]["tau"].download().T.copy(), outs[0]["status"].download()
+big = ctx.alloc((1 << 28,))
+pin = ctx.alloc_pinned((28, n)); pin.array[...] = S(b["mpc_state"])
+pin_fb = ctx.alloc_pinned((37, n)); pin_fb.array[...] = S(b["fb_state"])
+d["state"].zero(); d["fb"].zero()                 # what a launch that ran too early would read
+for o in outs[1:]:
+    o["tau"].upload(np.full((12, n), np.nan, np.float32)); o["status"].upload(np.full((n,), 0x7f0000ff, np.int32))
+ctx.sync()
+for _ in range(400):
+    big.zero()                                    # ~100 ms of the caller's own work on the context's stream: far beyond twice the 1 ms bounds
+d["state"].copy_from_pinned(pin); d["fb"].copy_from_pinned(pin_fb)
+for o in outs[1:]:                                # THREE ticks queued behind it without a sync: every one of their gates gives up before the first tick runs
+    tick(o)
+ctx.sync()
+bad = 0
+worst = 0.0
+for o in outs[1:]:
+    st, tau = o["status"].download(), o["tau"].download().T
+    bad += int((G.flags(st) != G.flags(ref_st)).sum()) + int(not np.isfinite(tau).all())
+    worst = max(worst, float(np.nanmax(np.abs(tau - ref_tau))))
+print("result", bad, worst)
+"""
+
+
+def test_several_ticks_queued_behind_a_backlog_longer_than_their_gates_bounds(pkg):
+    """the give-up words of the WBC gate and of the planned launch's gate were single words shared by every tick in flight.  Two or more
+    ticks queued behind a backlog longer than twice the bound then overwrote each other's word before their own kernels had read it: a tick's
+    second WBC pass skipped the whole batch, its main pass skipped listed robots that nobody solved -- stale or raw torques, no flag.  The words
+    are rings indexed by the epoch now.  A process of its own with both bounds at 1 ms, ~100 ms of fills in front of THREE ticks queued without a
+    sync, the inputs produced behind the fills: every robot of every tick against the tick run alone."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, QRGPU_PLAN_GO_MS="1", QRGPU_PIPE_GATE_MS="1")
+    r = subprocess.run([sys.executable, "-c", _BACKLOG3_SCRIPT, here], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [l.split()[1:] for l in r.stdout.strip().splitlines() if l.startswith("result")][0]
+    assert int(res[0]) == 0, res
+    assert float(res[1]) < 2e-4, res
+
+
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
     K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
