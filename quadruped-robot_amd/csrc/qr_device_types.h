@@ -225,6 +225,7 @@ struct WbcPipe {
     // from starting -- raises the flag of a robot it has re-solved with bit 0 clear, and the robot's workgroup here waits on through the
     // "on the list pass" value for that (bounded by wait_ticks, flagged).
     int wait_list;
+    long long flag_ticks;       // bound of the wait for the robot's forces (100 MHz clock; 4 ms, QRGPU_PIPE_WAIT_US for the tests)
 };
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)

@@ -1817,7 +1817,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // wave): wait for them, then raise the robot's flag for the WBC workgroup that is waiting for it (or, for a robot on its way to the
             // list pass, tell that workgroup to leave it to the WBC pass behind the list launch)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | (to_rescue ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                // (an exchange, not a store: a WBC workgroup that gave up waiting for this robot leaves 0x80000000 | epoch << 1 here -- its own status
+                //  word, written before ours, is gone, so the time-out is recorded again behind ours: never silent)
+                const unsigned old = __hip_atomic_exchange(P.done_flag + rid, (P.done_epoch << 1) | (to_rescue ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (0x80000000u | (P.done_epoch << 1)) && io.g_status)
+                    __hip_atomic_fetch_or(io.g_status + rid, QRGPU_ST_PIPE_TIMEOUT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane == 0 && QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
             if (lane == 0 && QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 2, wall_clock64());
         }

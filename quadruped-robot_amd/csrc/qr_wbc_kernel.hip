@@ -1346,7 +1346,14 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
         for (;;) {
             v = __hip_atomic_load(pipe.flag + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((v >> 1) == pipe.epoch && !(pipe.wait_list && (v & 1u))) break;
-            if (wall_clock64() - t0 > (((v >> 1) == pipe.epoch && pipe.wait_list) ? pipe.wait_ticks : 400000LL)) { pipe_st = QRGPU_ST_PIPE_TIMEOUT_D; break; }
+            if (wall_clock64() - t0 > (((v >> 1) == pipe.epoch && pipe.wait_list) ? pipe.wait_ticks : pipe.flag_ticks)) {
+                // Never silent, also when the solve is still running and will store its status word OVER the one this workgroup writes: leave
+                // "gave up in this epoch" in the flag word itself (bit 31; epochs stay below 2^30) -- the solve raises the flag with an exchange
+                // and, finding that value, adds QRGPU_ST_PIPE_TIMEOUT to the status word it has just stored (qr_mpc_kernel.hip).
+                pipe_st = QRGPU_ST_PIPE_TIMEOUT_D;
+                if (lane == 0) __hip_atomic_store(const_cast<unsigned *>(pipe.flag) + rid, 0x80000000u | (pipe.epoch << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
             __builtin_amdgcn_s_sleep(32);
         }
         v = __builtin_amdgcn_readfirstlane(v);

@@ -888,7 +888,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0})
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0})
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -1247,7 +1247,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // projection, and wait -- bounded -- at the QP for their robot's flag (qr_wbc_kernel.hip, qr_mpc_kernel.hip).  Robots the main pass hands
     // to its trailing list launch are skipped there and taken by a second, list-driven WBC pass queued behind that launch.
     const unsigned prev_epoch = c->tick_epoch;
-    if (++c->tick_epoch >= 0x7fffffffu) c->tick_epoch = 1;
+    if (++c->tick_epoch >= 0x3fffffffu) c->tick_epoch = 1;        // (below 2^30: bit 31 of a robot's flag word says "its WBC workgroup gave up in this epoch")
     const unsigned epoch = c->tick_epoch;
     // (the give-up word of this tick's WBC gate: a ring indexed by the epoch -- several ticks may be queued behind a backlog)
     int *const gate_abort = c->d_gate_abort + (epoch & (QR_ABORT_RING - 1));
@@ -1318,10 +1318,11 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, wbc_stream, c->d_main_started, expect, ovl ? 200000000LL : gate_ticks, ovl ? (int *)nullptr : gate_abort, (int)epoch,
                        (int *)nullptr);
     HIPCHK(c, hipGetLastError());
+    static const long long flag_ticks = [] { const char *e = getenv("QRGPU_PIPE_WAIT_US"); return e ? 100LL * atoll(e) : 400000LL; }();
     unsigned *const wbc_done = ovl ? c->d_wbc_done : nullptr;
     const unsigned wait_epoch = (ovl && ov.chained) ? (prev_epoch ^ ov_fault) : 0u;
     WbcPipe wp{LN.d_done_flag, epoch, nullptr, nullptr, ovl ? (int *)nullptr : gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in, wbc_done, wait_epoch, ov_wait_ticks(),
-               ovl ? 1 : 0};
+               ovl ? 1 : 0, flag_ticks};
     rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
                     wbc_stream, wp);
     if (rc) return rc;
@@ -1329,7 +1330,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     if (!ovl) {   // the second pass: the robots of the trailing launch's list (there is one at h <= 11) -- or every robot, should the gate have given up
         const bool have_list = LN.last_rescue_active;
         WbcPipe lp{nullptr, epoch, have_list ? LN.d_rescue + 2 : nullptr, have_list ? LN.d_rescue + LN.last_rescue_parity : nullptr, gate_abort, 1, nullptr,
-                   nullptr, c->d_timeline, nullptr, nullptr, 0u, 0, 0};
+                   nullptr, c->d_timeline, nullptr, nullptr, 0u, 0, 0, flag_ticks};
         rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr, nullptr, lp);
         if (rc) return rc;
     }

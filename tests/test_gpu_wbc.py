@@ -710,6 +710,46 @@ def test_several_ticks_queued_behind_a_backlog_longer_than_their_gates_bounds(pk
     assert float(res[1]) < 2e-4, res
 
 
+_FLAG_WAIT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import load_pkg
+import gpu_helpers as G
+pkg = load_pkg()
+h, n = 10, 1024
+b = pkg.make_batch(n, h, "a1", seed=0x7A17)
+outs = {}
+for piped in (False, True):
+    ctx = pkg.Context(0, 1024, 16)
+    G.setup_a1(ctx, pkg, h)
+    ctx.set_tick_pipeline(piped)
+    with G.cold_start(ctx):
+        for _ in range(3):
+            outs[piped] = G.run_tick(ctx, pkg, b)
+    ctx.close()
+ser, pip = outs[False], outs[True]
+to = (G.flags(pip["status"]) & 0x02000000) != 0
+same = np.all(ser["tau"] == pip["tau"], 1)
+print("result", int(to.sum()), int((~to & ~same).sum()), int((G.flags(ser["status"]) != 0).sum()))
+"""
+
+
+def test_a_wbc_workgroup_that_gives_up_is_never_silent(pkg):
+    """a WBC workgroup of a pipelined tick that gives up waiting for its robot's forces stores torques computed from stale forces and a
+    status word with QRGPU_ST_PIPE_TIMEOUT -- and the robot's solve, still running, then stored ITS status word over it: raw MPC torque, no
+    WBC, no flag.  Now the workgroup leaves "gave up in this epoch" in the robot's flag word and the solve, raising the flag with an exchange,
+    finds it and adds the bit behind its own status word.  A process of its own with the bound at 1 us (QRGPU_PIPE_WAIT_US): every robot whose
+    workgroup looked before its solve had ended gives up; every robot either carries the flag or has the serial tick's torques bit for bit."""
+    import subprocess, sys, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, QRGPU_PIPE_WAIT_US="1")
+    r = subprocess.run([sys.executable, "-c", _FLAG_WAIT_SCRIPT, here], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [int(x) for x in [l.split()[1:] for l in r.stdout.strip().splitlines() if l.startswith("result")][0]]
+    assert res[0] > 0, res                 # some workgroups did give up ...
+    assert res[1] == 0 and res[2] == 0, res   # ... and nobody is wrong without saying so
+
+
 def test_configs4_per_gpu_shard_1024_mixed_h16(gpu_ctx, pkg, oracle):
     """BASELINE.json configs[4] as one GPU sees it: 512 A1 + 512 Lite3 robots interleaved (type_id per robot), horizon 16, the full tick with
     K12 and the K14 tail on, fp32 Hessian assembly -- the workload `bench.py --mixed --horizon 16` times.  Every robot: no flag, forces inside
