@@ -68,6 +68,31 @@
  *                       normalizedPhase[4], desiredLegState[4], legState[4] (LegState enum values as floats),
  *                       firstSwingBaseState x, y
  *   fe_state  [8][n]  : in/out controller memory: xVelDes, yVelDes, yawTurnRate, yawDesTrue, posDesiredinWorld[3], iterationCounter
+ *
+ * ENVIRONMENT SWITCHES.  These are the supported ones (read once per process).  qrgpu_create warns once about any other QRGPU_* variable it
+ * finds: the alternative launch shapes and thresholds rounds 1-3 measured with are laboratory switches, ignored unless QRGPU_LAB=1 is set
+ * (LAB_NOTES.md lists them with what each measured).
+ *   name                    default  effect
+ *   QRGPU_TICK_PIPELINE     1        0: qrgpu_tick_batch queues the WBC launch behind the MPC launches (the serial tick) whatever qrgpu_set_tick_pipeline says
+ *   QRGPU_PIPE_GATE_MS      50       bound of the gate in front of a pipelined tick's WBC launch; one that gives up turns the tick into the serial one
+ *   QRGPU_PLAN_GO_MS        50       bound of the planned launch's wait for its "go"; one that gives up calls the plan off for the call
+ *   QRGPU_PIPE_WAIT_US      4000     bound of a WBC workgroup's wait for its robot's forces (then QRGPU_ST_PIPE_TIMEOUT)
+ *   QRGPU_OV_WAIT_US        20000    overlapped ticks: bound of a robot's waits for its previous solve / WBC pass (then QRGPU_ST_PIPE_TIMEOUT)
+ *   QRGPU_OV_PLAN_HOLD      31       overlapped ticks: calls on the plain pipelined tick after a lane found a planned list (0: never go back)
+ *   QRGPU_OV_FAULT          0        test hook: 1 makes every chained tick wait for an epoch nobody writes (the give-up paths, tests/test_gpu_overlap.py)
+ *   QRGPU_COMM_EVENTS       unset    the all-gather's hand-overs: unset = stream events when the communicator has more than one rank, polled counts
+ *                                    with one; 1 = events always; 0 = polled counts always
+ *   QRGPU_SINGLE_COPIES     0        1: the single-robot calls stage through device buffers and three copies instead of one mapped pinned block
+ *   QRGPU_PERSIST           1        h > 11: persistent main pass (one workgroup per resident slot taking robots off per-XCD queues); 0 off, 2 also at h <= 11
+ *   QRGPU_H16_TWO           1        h > 11: two workgroups per CU from 3.5 robots per CU on; 0 never, 2 from 64 robots on
+ *   QRGPU_H16_TWO_HOLD      31       ... calls on one workgroup per CU after the planned list outgrew 45 % of the batch
+ *   QRGPU_H16_BIG_US        450      ... smoothed solve time from which a robot is planned onto a whole CU
+ *   QRGPU_H16_BIG_STAY_US   300      ... and below which it leaves it again
+ *   QRGPU_LIB               unset    (Python mirror, bench.py) path of another build of libqrgpu.so to load: A/B runs
+ *   QRGPU_EXTRA_FLAGS       unset    (build.py) extra hipcc flags; -DQR_TIMELINE builds the per-tick stamps of qrgpu_debug_timeline in
+ *   QRGPU_LAB               0        1: the laboratory switches are read
+ *   GPU_MAX_HW_QUEUES       (HIP)    the HIP runtime's: hardware queues per process (its default 4; the Python mirror sets 8 when unset).  Streams that
+ *                                    share a queue serialise each other: qrgpu_set_tick_overlap probes for it and refuses the mode
  * ========================================================================== */
 #ifndef QRGPU_H
 #define QRGPU_H

@@ -13,7 +13,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast-honor
 
 
 def _flags():
-    return FLAGS + (["-DQR_GI_STAMPS"] if os.environ.get("QRGPU_GI_STAMPS") == "1" else []) + os.environ.get("QRGPU_EXTRA_FLAGS", "").split()
+    # QRGPU_EXTRA_FLAGS=-DQR_TIMELINE: the one diagnostic build (per-tick stamps of the pipelined / overlapped tick on the shared clock: scratch/diag_overlap.py)
+    return FLAGS + os.environ.get("QRGPU_EXTRA_FLAGS", "").split()
 
 
 def _stale():

@@ -52,15 +52,9 @@ namespace qrgpu {
 // Pivot reciprocals of both sweeps: v_rcp_f64 + one Newton step (2.2e-15 relative, scratch/ubench/rcp.hip) -- 0.7 % of the main pass.  (Before
 // the periodic refresh of S^-1 existed, one robot of the stress set at twice the 8d ranges wandered into the iteration cap with it; with the
 // refresh the stress run is the same with either form: 21 overflow flags at twice the ranges, none inside them, largest count 202 / 204.)
-#ifndef QR_RCP_PIVOT
 #define QR_RCP_PIVOT fast_rcp1
-#endif
-#ifndef QR_REFRESH_EVERY
-#define QR_REFRESH_EVERY 100
-#endif
-#ifndef QR_MAIN_WAVES_PER_SIMD
+#define QR_REFRESH_EVERY 100         // a solve still going after this many working-set changes gets S^-1 rebuilt from its working set, and again every so many
 #define QR_MAIN_WAVES_PER_SIMD 3     // register budget of the h <= 11 main pass: 3 workgroups per CU (168 VGPRs); the LDS allotment decides how many run
-#endif
 // The executed-arithmetic counters (qrgpu_enable_flop_count) cost the main pass four live fp64 accumulators and 2.4 % of its time even when the
 // pointer is null (0.2242 -> 0.2189 ms with them compiled out), so the kernels exist twice: this file compiles them without the counters,
 // qr_mpc_kernel_fl.hip includes it with QR_FLOPS_BUILD and gets the same kernels under the name qr_mpc_kernel_fl with the counters in;
@@ -289,11 +283,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // active set's four alive -- they must come back for the next robot -- and a live wave counts at every s_barrier of its workgroup, so
     // those waves cross barriers in step with the working ones until the count wave 0 leaves in sMisc[15] at the solve's last one (QR_IDLE).
     int nbar = 0;
-#ifdef QR_NO_BARRIER_COUNT      // (A/B: what the count costs the kernels that never park a wave)
-#define QR_SYNC() do { __syncthreads(); } while (0)
-#else
 #define QR_SYNC() do { __syncthreads(); if (PERSIST) ++nbar; } while (0)
-#endif
 #define QR_IDLE() do { for (;;) { QR_SYNC(); if (((volatile int *)sMisc)[15] == nbar) break; } } while (0)
     // a type id outside the table, or one that was never set up, would read garbage (mass 0 => 1/mass = inf): the robot is solved with the
     // first valid type's constants and carries QRGPU_ST_BAD_TYPE
@@ -323,19 +313,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // (pointer arithmetic only: an integer round trip would drop the LDS address space and turn every access into flat_*)
     double *Mb = smem + (int)(mpc_lds_fixed_bytes(h, true) / 8);   // block-packed M; the sweep panels live here first
 
-#if defined(QR_TRACE) || defined(QR_DIAG_REFAC)
-#define QR_TS(i) do { } while (0)
-#else
-#ifdef QR_K4_STAMPS      // (slots 4-6 carry the unit loop's accumulated times in this diagnostic build)
-#define QR_TS(i) do { if (QR_DBGT && tid == 0 && (i) < 4) QR_DBGT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
-#else
 #define QR_TS(i) do { if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + (i)] = clock64(); } while (0)
-#endif
-#endif
     QR_TS(0);
-#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
     if (QR_DBGT && tid == 0) QR_DBGT[(size_t)rid * 16 + 12] = wall_clock64();       // (the 100 MHz clock every CU shares: launch-wide concurrency, scratch/diag_util.py)
-#endif
     // ---------------- phase 0: inputs ----------------
     if (tid == 0) sMisc[15] = -1;
     if (tid < 28) sSt[tid] = io.g_state[(size_t)tid * n + rid];
@@ -359,19 +339,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     float R[3][3];
     quat_to_R(sSt[6], sSt[7], sSt[8], sSt[9], R);
     if (tid < 4) ((float *)sMisc)[4 + tid] = sSt[6 + tid];
-#if 0
-    {
-#pragma clang fp contract(off)
-        const float w = sSt[6], x = sSt[7], y = sSt[8], z = sSt[9];
-        const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
-        const float twx = tx * w, twy = ty * w, twz = tz * w;
-        const float txx = tx * x, txy = ty * x, txz = tz * x;
-        const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
-        R[0][0] = 1.f - (tyy + tzz); R[0][1] = txy - twz;         R[0][2] = txz + twy;
-        R[1][0] = txy + twz;         R[1][1] = 1.f - (txx + tzz); R[1][2] = tyz - twx;
-        R[2][0] = txz - twy;         R[2][1] = tyz + twx;         R[2][2] = 1.f - (txx + tyy);
-    }
-#endif
     const float dt = C.dt, dt2 = C.dt * C.dt, minv = 1.0f / C.mass;
     if (tid < 4) {
 #pragma clang fp contract(off)
@@ -548,14 +515,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // v_mfma_f32_16x16x4_f32), [2] fp64 flops of the sweep and x0, [3] fp64 flops of the active set (rebuilds included).  mul and add count 1
     // each, fma 2.  Wave 0 keeps the sums (uniform) and stores them at the end.
     double fl_v32 = 0.0, fl_m32 = 0.0, fl_sw = 0.0, fl_as = 0.0;
-#ifdef QR_K4_STAMPS
-#define K4_TS(i) do { } while (0)
-#define K4_WAVE_END() do { if (QR_DBGT && lane == 0 && (tid >> 6) < 8) QR_DBGT[(size_t)rid * 16 + 8 + (tid >> 6)] = clock64(); } while (0)
-#else
-#define K4_WAVE_END() do { } while (0)
-#define K4_TS(i) do { } while (0)
-#endif
-    K4_TS(8);
     // ---------------- phase 2: Hessian (matrix cores -> fp32 tiles in LDS -> blocks in registers) + gradient (LDS) ----------------
     // (the torque map's Jacobian columns first, on twelve lanes of the last wave)
     // The torque map's Jacobian columns (AnalyticalLegJacobian, QS/robots/qr_robot.cpp:148-172) on twelve lanes of the second-to-last wave (the
@@ -622,9 +581,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // load their blocks -- no fp64 conversion, division by three or scattered 8-byte store behind the matrix instructions any more.
     // The lane constants of a tile side come from a per-variable table (sOp, in the xz exchange area, idle until phase 4) built once per
     // robot, instead of a chain of dependent LDS reads (leg-step id -> leg -> T / U entries) per tile and side.
-#ifdef QR_K4_PRIO
-    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) __builtin_amdgcn_s_setprio(QR_K4_PRIO);
-#endif
     const int NT = (ns + 15) >> 4;
     const int NOD = (NT * (NT - 1)) >> 1;                  // off-diagonal tiles below the diagonal
     float *Hs = (float *)Mb;                               // [2 NOD + NT][16][16]: buffers 2 t, 2 t + 1 of off-diagonal tile t = tri(R - 1) + C, then one per diagonal tile
@@ -641,7 +597,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
         return;
     }
-    K4_TS(10);
     {
 #pragma clang fp contract(off)
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -665,9 +620,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             k2 = (g == 0) ? o2 : ((i == g - 1) ? dtm : 0.f);       // s = 8 | 9, 10, 11
         };
         const int NU = (NT * (NT + 1)) >> 1;            // one unit per tile on or below the tile diagonal
-#ifdef QR_K4_STAMPS
-        long long k4_loop = 0, k4_setup = 0, k4_dump = 0;
-#endif
         // Deal.  Units come tile row by tile row, i.e. in order of descending cost (a row's chains run over h - first step of the row).  The
         // last two waves carry the gradient (below) and the Jacobian columns, so the first NW - 2 units go to waves 0 .. NW - 3, and the rest
         // go back and forth over waves NW - 1 .. 1 (snake) -- wave 0 keeps tile (0, 0) alone, the one chain that runs over every horizon step.
@@ -678,9 +630,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             if (it == 0) { if (half || wvb >= NF) continue; u = wvb; }
             else u = NF + (it - 1) * per + (half == 0 ? NW - 1 - wvb : NW - 2 + wvb);
             if (u >= NU) continue;
-#ifdef QR_K4_STAMPS
-            const long long k4_t0 = clock64();
-#endif
             int R = (int)((__builtin_sqrtf(8.f * (float)u + 1.f) - 1.f) * 0.5f);
             while (tri(R + 1) <= u) ++R;
             while (tri(R) > u) --R;
@@ -694,10 +643,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             const float t1R = k1R * w2q1, t2R = k2R * w2q2, t1C = k1C * w2q1, t2C = k2C * w2q2;
             const int r0 = __builtin_amdgcn_readfirstlane(((const int *)(sOp + 8 * 16 * R))[6]) & 255;      // first step at which any entry of the tile switches on
             f4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#ifdef QR_K4_STAMPS
-            asm volatile("" :: "v"(t1R), "v"(t2R), "v"(t1C), "v"(t2C), "v"(a0R), "v"(a0C), "s"(r0));
-            const long long k4_t1 = clock64();
-#endif
             const float bR = 0.5f - (float)iaR, bC = 0.5f - (float)iaC;      // (r - i_a) + 1/2 is exact in fp32 either way
             if (P.hess_mode == 1) {
                 // BASELINE.json configs[4]'s arithmetic: the same contraction on the bf16 matrix cores.  Every fp32 operand is cut into three
@@ -785,10 +730,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gR, tC, acc2, 0, 0, 0);
                 }
             }
-#ifdef QR_K4_STAMPS
-            asm volatile("" :: "v"(acc1), "v"(acc2));
-            const long long k4_t2 = clock64();
-#endif
             // D[row = 4 g + reg][col = lc] -> the tile's buffer(s), 4-byte stores, lanes lc contiguous.  Row r sits at physical row
             // hs_row(r, Cc) = (4 (r & 3) + (r >> 2)) ^ (Cc & 1): the lane groups g = 0, 1 of a store land in different halves of the 32
             // banks (rows 4 apart would share them), and the block owners' reads, which run across column tiles, alternate halves with the tile
@@ -812,16 +753,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                 }
             }
-#ifdef QR_K4_STAMPS
-            { const long long k4_t3 = clock64(); k4_setup += k4_t1 - k4_t0; k4_loop += k4_t2 - k4_t1; k4_dump += k4_t3 - k4_t2; }
-#endif
           }
         }
-#ifdef QR_K4_STAMPS
-        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 4] = k4_setup; QR_DBGT[(size_t)rid * 16 + 5] = k4_loop; QR_DBGT[(size_t)rid * 16 + 6] = k4_dump; }
-#endif
     }
-    K4_TS(11);
     // gradient: qg[a] = sum_k temp[a][k] v[k], one free variable per thread -- on the last two waves (variable e and, beyond 128 of them, e + 128 per thread), which the deal above leaves out of its first pass
     for (int e = tid - (NTHR - 128); e >= 0 && e < ns; e += 128) {
 #pragma clang fp contract(off)
@@ -850,10 +784,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         if (QR_DBGG) QR_DBGG[(size_t)rid * NV + 3 * ls + j] = acc;
     }
     for (int c = tid; c < 6 * nls; c += NTHR) sPos[c] = -1;
-#ifdef QR_K4_PRIO
-    if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) __builtin_amdgcn_s_setprio(0);
-#endif
-    K4_WAVE_END();
     QR_TS(2);
 
     // ---------------- phase 3: symmetric block sweep in registers,  A <- -H^-1 ----------------
@@ -862,7 +792,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // The pivot column is exchanged through a double-buffered LDS panel: one barrier per pivot.
     Blk A[MAXB];
     QR_SYNC();               // every unit's tile is in LDS
-    K4_TS(12);
     // block (a, b), a >= b, of (H + H') / 2: entry (i, j) from H[x][y] and H[y][x], x = 3 a + i >= y = 3 b + j (the block's lower half when
     // a = b), both fp32, averaged exactly in fp64.  Off-diagonal tile (R, C): buffers at 512 (tri(R - 1) + C), H[x][y] at [x & 15][y & 15] of
     // the first, H[y][x] at the same place of the second; diagonal tile: one buffer, H[y][x] at the transposed place.
@@ -898,19 +827,13 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 }
         }
     }
-    K4_TS(14);
     QR_SYNC();               // every block is in registers: the M region can now carry the pivot panels
     // A wave beyond the active set's four that owns no block (a trotting robot's 300 blocks fill 4.7 of the 8 waves) is done: it would only
     // load panels and wait at barriers (a wave that has ended no longer counts there), competing for the LDS pipe with the ones that work.
     if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS && (tid & ~63) >= npairs) { if (PERSIST) QR_IDLE(); return; }
     {
         double *panel0 = Mb, *panel1 = Mb + NL * 9;
-#ifdef QR_SWEEP_STAMPS
-        long long vs_t[4] = {0, 0, 0, 0}, vs_0 = clock64();
-#define VS_STAMP(i) do { const long long t_ = clock64(); vs_t[i] += t_ - vs_0; vs_0 = t_; } while (0)
-#else
 #define VS_STAMP(i) do { } while (0)
-#endif
         // the pivot column of step kk out of block sl: block (a, kk), a > kk, is C_a; block (kk, b), b < kk, is C_b'; the owner of the
         // pivot block (kk, kk) publishes P^-1 (3x3 symmetric, adjugate / determinant) in its place: once per pivot, not once per thread
         auto write_panel = [&](int sl, int kk, double *pn) {
@@ -959,9 +882,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 Pi[0] = Pk[0]; Pi[1] = Pk[1]; Pi[2] = Pk[2]; Pi[4] = Pk[4]; Pi[5] = Pk[5]; Pi[8] = Pk[8];
                 Pi[3] = Pi[1]; Pi[6] = Pi[2]; Pi[7] = Pi[5];
             }
-#ifdef QR_SWEEP_STAMPS
-            asm volatile("" :: "v"(Pi[0]), "v"(Pi[4]), "v"(Pi[8]), "v"(Pi[5]));
-#endif
             VS_STAMP(2);
 #pragma unroll
             for (int sl = 0; sl < MAXB; ++sl) {
@@ -1008,10 +928,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#ifdef QR_SWEEP_STAMPS
-        VS_STAMP(3);
-        if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 8] = vs_t[0]; QR_DBGT[(size_t)rid * 16 + 9] = vs_t[1]; QR_DBGT[(size_t)rid * 16 + 10] = vs_t[2]; QR_DBGT[(size_t)rid * 16 + 11] = vs_t[3]; QR_DBGT[(size_t)rid * 16 + 12] = 0; }
-#endif
         QR_SYNC();           // everybody is done with the panels before M overwrites them
 #pragma unroll
         for (int sl = 0; sl < MAXB; ++sl) {
@@ -1026,9 +942,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     // phases 0-3 may run on more than four waves (NTHR / 64: one block of a trotting robot's Hessian per thread); the active set is a
     // four-wave protocol, so the others are done here (a wave that has ended no longer counts at the workgroup's barriers)
     if (NTHR > QR_AS_THREADS && tid >= QR_AS_THREADS) { if (PERSIST) QR_IDLE(); return; }
-#ifdef QR_AS_PRIO        // (A/B: issue priority for the four waves of the latency-bound active set over a co-resident workgroup's build and sweep)
-    __builtin_amdgcn_s_setprio(QR_AS_PRIO);
-#endif
     if (sMisc[1]) st |= QRGPU_ST_MPC_NOTSPD_D;
     QR_TS(3);
     if (QR_PFLOPS) {
@@ -1095,11 +1008,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             QR_SYNC();
         }
         QR_TS(4);
-#ifdef QR_CTRL_NOFASTZ
-        bool fastz = false;
-#else
         bool fastz = qW > 0;
-#endif
         // r partial over columns j = wv (mod 4); (i, j) at tri(i) + j for j <= i, else tri(j) + i
         auto r_partial = [&](int q, double dq, double dq2) {
             if (BIG && q > 64) {
@@ -1139,9 +1048,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             const int ne = tri(q);
             double *colp = xr;                            // [2][QMAX] pivot columns (the r exchange is idle during a rebuild)
             double *diag0 = xz + NV;                      // [q] the diagonal of S (q <= 3 nls <= NV)
-#if defined(QR_DIAG_REFAC)
-            const long long tb0 = clock64();
-#endif
             // (the 128-register h > 11 variant keeps the elements a 67-row set needs in registers, as the 64-row variants do; what a larger set
             //  adds is swept in place in S^-1's own storage -- slower per pivot, for the one robot in a hundred that gets there unannounced)
             constexpr int NER = (BIG && H16 && MAXB <= 4) ? 9 : NE;
@@ -1195,9 +1101,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 }
             }
             QR_SYNC();
-#if defined(QR_DIAG_REFAC)
-            const long long tb1 = clock64();
-#endif
             bool ok = true;
             for (int p = 0; p < q; ++p) {
                 const double *cur = colp + (p & 1) * QMAX;
@@ -1235,10 +1138,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 }
                 QR_SYNC();
             }
-#if defined(QR_DIAG_REFAC)
-            const long long tb2 = clock64();
-            if (QR_DBGT && tid == 0) { QR_DBGT[(size_t)rid * 16 + 2] = tb1 - tb0; QR_DBGT[(size_t)rid * 16 + 3] = tb2 - tb1; }
-#endif
             if (ok) {
 #pragma unroll
                 for (int m = 0; m < NER; ++m) { const int e = tid + QR_AS_THREADS * m; if (e < ne) Sinv[e] = -el[m]; }
@@ -1382,20 +1281,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         }
         // ================================ wave 0: control ================================
         int q = 0, iter = 0;
-#ifdef QR_GI_STAMPS      // sub-phase cycle accounting of wave 0 (build.py: QRGPU_GI_STAMPS=1)
-        long long cs_t[6] = {0, 0, 0, 0, 0, 0}, cs_0 = clock64();
-#ifdef QR_GI_STAMPS_FINE  // (the stretch from B3 to the next row's pick in four parts, slots 0-3; the pick in 4, the rest of the change in 5;
-                          //  scratch/diag_change_fine.py.  A stamp waits for the wave's outstanding LDS traffic: ~150 cycles each)
-#define CS_STAMP(i) do { const long long t_ = clock64(); cs_t[(i) == 0 ? 4 : 5] += t_ - cs_0; cs_0 = t_; } while (0)
-#define CS_FINE(i) do { const long long t_ = clock64(); cs_t[i] += t_ - cs_0; cs_0 = t_; } while (0)
-#else
-#define CS_STAMP(i) do { const long long t_ = clock64(); cs_t[i] += t_ - cs_0; cs_0 = t_; } while (0)
-#define CS_FINE(i) do { } while (0)
-#endif
-#else
 #define CS_STAMP(i) do { } while (0)
 #define CS_FINE(i) do { } while (0)
-#endif
         unsigned amask = 0, xmask = 0;
         unsigned long long posk = 0;                      // byte t: working-set position of row t of my leg-step
         int ck = 0, ct = 0;                               // constraint (leg-step, row) at working-set position `lane`
@@ -1480,15 +1367,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (BIG && lane + 64 < q) sAct[lane + 64] = 6 * ck2 + ct2;
                 if (lane == 0) { sCtl[0] = CMD_REBUILD; sCtl[1] = q; }
                 QR_SYNC();                          // X1
-#if defined(QR_DIAG_REFAC)
-                const long long tr0 = clock64();
-#endif
                 const bool ok = rebuild(q);
                 if (QR_PFLOPS) fl_as += 17.5 * (double)q * (double)q + 1.5 * (double)q * (double)q * (double)q + 15.0 * (double)q * (double)nls;   // S, sweep of S, W_A
-#if defined(QR_DIAG_REFAC)
-                if (QR_DBGT && lane == 0) { QR_DBGT[(size_t)rid * 16 + 8] += ok ? 1 : 100; QR_DBGT[(size_t)rid * 16 + 10] = clock64() - tr0; QR_DBGT[(size_t)rid * 16 + 11] = q; }
-                const long long tr1 = clock64();
-#endif
                 if (!ok) {
                     // dependent rows in the guess: cold start
                     if (own) {
@@ -1555,9 +1435,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
 #pragma unroll
                             for (int t = 0; t < 6; ++t) { const int ps = sPos[6 * kme + t]; if (ps >= 0) { amask |= 1u << t; posk |= (unsigned long long)(ps & 0xff) << (8 * t); } }
                         }
-#if defined(QR_DIAG_REFAC)
-                        if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 13] += nneg;
-#endif
                         need_rebuild = true;
                         break;
                     }
@@ -1569,9 +1446,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                         if (hi) uq2 = (lane + 64 < q && rq2 < 0.0) ? -rq2 : 0.0;
                         break;
                     }
-#if defined(QR_DIAG_REFAC)
-                    if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 13] += 1;
-#endif
                     // position lpos leaves: the same bookkeeping as a drop of the loop below (the workers downdate S^-1 between D1 and D3)
                     {
                         const int l = lpos, last = q - 1;
@@ -1594,9 +1468,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                     if (q == 0) { x0 = gl[3 * kme]; x1 = gl[3 * kme + 1]; x2 = gl[3 * kme + 2]; uq = 0.0; uq2 = 0.0; break; }
                 }
-#if defined(QR_DIAG_REFAC)
-                if (QR_DBGT && lane == 0) QR_DBGT[(size_t)rid * 16 + 9] += clock64() - tr1;
-#endif
                 if (done) break;
                 if (need_rebuild) continue;               // (a block drop: solve on what is left)
             }
@@ -1622,9 +1493,6 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                     }
                 }
                 const double bemin = wave_min_d(be);
-#if defined(QR_DIAG_REFAC)
-                if (QR_DBGT && lane == 0) { QR_DBGT[(size_t)rid * 16 + 12] = __double_as_longlong(bemin); }
-#endif
                 if (bemin < -1e-4) {
                     // S^-1 has drifted (hundreds of bordered updates / downdates) or a row was set aside wrongly: rebuild it from the working
                     // set as it stands, re-solve on that set, restore dual feasibility and carry on; only a solve that fails the check
@@ -1703,14 +1571,8 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 const double t = t1 < t2 ? t1 : t2;
                 const bool degenerate = !(t < INF);
                 const bool full = !degenerate && indep && t == t2;
-#if defined(QR_DIAG_REFAC)
-                if (QR_DBGT && lane == 0 && full) { const double ratio = zc / delta; double *mr = (double *)&QR_DBGT[(size_t)rid * 16 + 15]; if (iter <= 2 || ratio < *mr) *mr = ratio; }
-#endif
                 const bool over = full && q >= qcap;
                 const int flags = (degenerate || over) ? 0 : (full ? F_FULL : F_DROP);
-#ifdef QR_TRACE
-                if (QR_DBGT && lane == 0 && iter <= 7) { QR_DBGT[(size_t)rid * 16 + 2 * (iter - 1)] = ((long long)kp << 32) | (tp << 24) | (q << 16) | (full ? 1 : 0) | (have_z ? 2 : 0); QR_DBGT[(size_t)rid * 16 + 2 * (iter - 1) + 1] = __double_as_longlong(t); }
-#endif
                 if (lane == 0) { sCtl[2] = flags; sCtl[3] = lpos; sCtl[4] = __double2hiint(izc); sCtl[5] = __double2loint(izc); }
                 CS_STAMP(4);
                 QR_SYNC();                          // B3
@@ -1861,22 +1723,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             if (lane == 0) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         QR_TS(6);
-#if !defined(QR_TRACE) && !defined(QR_DIAG_REFAC) && !defined(QR_GI_STAMPS) && !defined(QR_K4_STAMPS)
         if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 13] = wall_clock64();
-#endif
-#ifndef QR_TRACE
-#ifdef QR_K4_STAMPS
-        if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; }
-#else
         if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; QR_DBGT[(size_t)rid * 16 + 14] = q; }
-#endif
-#ifdef QR_GI_STAMPS
-        if (lane == 0 && QR_DBGT) for (int i = 0; i < 6; ++i) QR_DBGT[(size_t)rid * 16 + 8 + i] = cs_t[i];
-#endif
-#ifdef QR_SLOT_STAMPS      // which CU ran this robot (HW_ID, XCC_ID): per-CU timelines of a launch, scratch/diag_slots.py
         if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-#endif
-#endif
     }
 }
 #undef QR_SYNC

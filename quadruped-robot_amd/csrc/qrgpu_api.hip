@@ -120,7 +120,7 @@ static int mpc_ensure_lds(qrgpu_ctx *c, int var, bool fl, int bytes)
 
 static int mpc_main_wgs()
 {   // workgroups of the h <= 11 main pass per CU: 2 (80 KB each: every robot fits) or 3 (53 KB: robots above ~32 stance leg-steps go to the list launches)
-    static const int v = [] { const char *e = getenv("QRGPU_MAIN_WGS"); const int k = e ? atoi(e) : 2; return (k == 3) ? 3 : 2; }();
+    static const int v = [] { const char *e = lab_env("QRGPU_MAIN_WGS"); const int k = e ? atoi(e) : 2; return (k == 3) ? 3 : 2; }();
     return v;
 }
 
@@ -258,7 +258,7 @@ void qrgpu_model_desc_default(qrgpu_model_desc *d)
 // robot starts 80-160 us late, which is then the end of the launch (QRGPU_SIDE_PRIORITY=0 for the default priority).
 static hipError_t create_side_stream(hipStream_t *s)
 {
-    static const int want = [] { const char *e = getenv("QRGPU_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
+    static const int want = [] { const char *e = lab_env("QRGPU_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
     int least = 0, greatest = 0;
     if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
@@ -309,9 +309,34 @@ static void lane_destroy(Lane &L)
     L = Lane{};
 }
 
+// Once per process: any QRGPU_* variable of the environment that is neither a supported switch (include/qrgpu.h) nor bench.py's own (QRGPU_BENCH_*)
+// is reported on the standard error -- a laboratory switch without QRGPU_LAB=1 is ignored, a misspelt one never did anything.
+extern char **environ;
+static void warn_unknown_env()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        static const char *supported[] = {QRGPU_SUPPORTED_ENV};
+        static const char *labs[] = {QRGPU_LAB_ENV};
+        const bool lab_on = lab_env("QRGPU_LAB") != nullptr;
+        for (char **e = environ; e && *e; ++e) {
+            if (strncmp(*e, "QRGPU_", 6) != 0 || strncmp(*e, "QRGPU_BENCH_", 12) == 0) continue;
+            const char *eq = strchr(*e, '=');
+            const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+            bool ok = false, is_lab = false;
+            for (const char *s_ : supported) if (name == s_) ok = true;
+            for (const char *s_ : labs) if (name == s_) is_lab = true;
+            if (ok || (is_lab && lab_on)) continue;
+            if (is_lab) fprintf(stderr, "libqrgpu: %s is a laboratory switch: ignored unless QRGPU_LAB=1 is set (include/qrgpu.h lists the supported ones)\n", name.c_str());
+            else fprintf(stderr, "libqrgpu: %s is not an environment switch of this library (include/qrgpu.h lists the supported ones): ignored\n", name.c_str());
+        }
+    });
+}
+
 int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
 {
     if (!out || max_batch <= 0 || horizon_max <= 0 || horizon_max > QRGPU_MAX_HORIZON) return QRGPU_ERR_BAD_ARG;
+    warn_unknown_env();
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return QRGPU_ERR_NO_DEVICE;
@@ -364,7 +389,7 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
     {   // The compute stream is the context's own (non-blocking) unless the caller names one (qrgpu_set_stream; NULL there = the default stream).  On the
         // default stream two contexts of one process serialise each other's launches: 16.9 against 34.7 M WBC calls/s for two contexts of 512 robots.
         // QRGPU_OWN_STREAM=0: rounds 1-3's default.
-        static const int own = [] { const char *e = getenv("QRGPU_OWN_STREAM"); return e ? atoi(e) : 1; }();
+        static const int own = [] { const char *e = lab_env("QRGPU_OWN_STREAM"); return e ? atoi(e) : 1; }();
         if (own && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess) c->stream = c->own_stream;
     }
     c->lane[0].stream = c->stream;
@@ -561,7 +586,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // has ended, they are short of slots, not waiting for flags) and -6 % at 8192 (two rank sorts of 1024-robot chunks behind the main pass).
     // (The moments come from the timeline hooks: a library built with -DQR_TIMELINE only.)
 #ifdef QR_TIMELINE
-    static const int wbc_order_on = [] { const char *e = getenv("QRGPU_WBC_ORDER"); return e ? atoi(e) : 0; }();
+    static const int wbc_order_on = [] { const char *e = lab_env("QRGPU_WBC_ORDER"); return e ? atoi(e) : 0; }();
 #else
     static const int wbc_order_on = 0;
 #endif
@@ -582,7 +607,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.order = (lpt && LN.lpt_n == n) ? LN.d_order : nullptr;
     P.cost = lpt ? cost_out : nullptr;
     P.cost_in = cost_prev;
-    { static const int ema = [] { const char *e = getenv("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && ema && (ovl ? c->cost_n[(ov->epoch & 1u) ^ 1u] == n : LN.lpt_n == n)) ? 1 : 0; }
+    { static const int ema = [] { const char *e = lab_env("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && ema && (ovl ? c->cost_n[(ov->epoch & 1u) ^ 1u] == n : LN.lpt_n == n)) ? 1 : 0; }
     if (ovl) c->cost_n[ov->epoch & 1u] = lpt ? n : 0;
     // up to 4 register-resident 3x3 blocks per thread cover tri(44) leg-step pairs (h <= 11); 9 cover h = 16
     const bool small = 4 * P.horizon <= 44;
@@ -596,7 +621,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // list launch -- one launch instead of two on the single-robot path, and the ping-pong parity of the rescue / planned lists, which
     // belongs to the batched calls' plan, is not touched by calls in between (a solve1 between two planned calls used to flip it
     // and the next planned call read the counters of the plan before last).  QRGPU_TINY_WHOLE_CU=0: the old two-launch form.
-    static const int tiny_whole_cu = [] { const char *e = getenv("QRGPU_TINY_WHOLE_CU"); return e ? atoi(e) : 1; }();
+    static const int tiny_whole_cu = [] { const char *e = lab_env("QRGPU_TINY_WHOLE_CU"); return e ? atoi(e) : 1; }();
     const bool tiny = small && n < 64 && !dH && tiny_whole_cu != 0;
     if (tiny) P.lds_bytes = c->lds_per_cu;
     // rescue pass for the h <= 11 main pass (not for inspection launches or tiny batches)
@@ -637,9 +662,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // rows enter the next tick's guess only when their multiplier exceeds 2 % of the solve's largest (weakly held rows are the ones that do
     // not persist: measured 0.2446 -> 0.2211 ms per launch at h = 10, neutral at h = 5; at h = 16, where a missing row costs 7-13 k cycles
     // to add, every threshold measured worse, so none is applied there).  QRGPU_WARM_UTHR overrides.
-    { static const double wu = [] { const char *e = getenv("QRGPU_WARM_UTHR"); return e ? atof(e) : -1.0; }(); P.warm_uthr = wu >= 0.0 ? wu : (4 * P.horizon <= 44 ? 0.02 : 0.0); }
-    { static const int nb = [] { const char *e = getenv("QRGPU_NO_BLOCK_DROP"); return e ? atoi(e) : 0; }(); P.no_block_drop = nb; }
-    { static const int nw = [] { const char *e = getenv("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
+    { static const double wu = [] { const char *e = lab_env("QRGPU_WARM_UTHR"); return e ? atof(e) : -1.0; }(); P.warm_uthr = wu >= 0.0 ? wu : (4 * P.horizon <= 44 ? 0.02 : 0.0); }
+    { static const int nb = [] { const char *e = lab_env("QRGPU_NO_BLOCK_DROP"); return e ? atoi(e) : 0; }(); P.no_block_drop = nb; }
+    { static const int nw = [] { const char *e = lab_env("QRGPU_NO_WCACHE"); return e ? atoi(e) : 0; }(); P.no_wcache = nw; }
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
     P.pre_count = planned ? LN.d_pre : nullptr;
@@ -655,7 +680,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         if (k > 45) k = 45;                 // (and the eight-wave kernel holds two blocks per thread: 1024 >= tri(44))
         if (P.big_nls <= 0 || P.big_nls > k) P.big_nls = k;        // (a caller's own, stricter class rule stands: qrgpu_set_planned_list)
     }
-    { static const int bm = [] { const char *e = getenv("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = two ? -1000 : bm; }
+    { static const int bm = [] { const char *e = lab_env("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = two ? -1000 : bm; }
     P.big_cost = P.big_cost_stay = 0; P.planned_stride = 0;
     if (two) {
         // the long poles: a robot whose solve takes most of the tick's span two to a CU (a large working set over the spilled S^-1: 600-800 us
@@ -673,9 +698,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // kernel variant: 3 = h <= 11, eight waves build and sweep (two blocks per thread, 128 VGPRs; the default), 2 = the same on four waves
     // (QRGPU_MAIN_THREADS=256, for A/B runs; six waves were measured too: the second workgroup of a CU then often cannot be placed until
     // the first has shed its extra waves), 1 = <9, positions 64..95 in a second register set> (h <= 16)
-    static const int main_threads = [] { const char *e = getenv("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
-    static const int h16_threads = [] { const char *e = getenv("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
-    static const int two_waves = [] { const char *e = getenv("QRGPU_H16_TWO_WAVES"); return e ? atoi(e) : 8; }();
+    static const int main_threads = [] { const char *e = lab_env("QRGPU_MAIN_THREADS"); return e ? atoi(e) : 512; }();
+    static const int h16_threads = [] { const char *e = lab_env("QRGPU_H16_THREADS"); return e ? atoi(e) : 512; }();
+    static const int two_waves = [] { const char *e = lab_env("QRGPU_H16_TWO_WAVES"); return e ? atoi(e) : 8; }();
     const int var = tiny ? 5 : (small ? (main_threads == 256 ? 2 : 3) : (two ? (two_waves == 8 ? 12 : (two_waves == 9 ? 13 : 10)) : (h16_threads == 256 ? 1 : 0)));
     // Overlapped ticks (h <= 11): the machine is never empty -- a workgroup that asks for a whole CU's LDS waits until both halves of some CU
     // happen to be free at once, behind every half-CU workgroup of the next tick's main pass and every WBC workgroup.  So the list launches of
@@ -725,12 +750,12 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     io.g_status = d_status; io.dbgH = dH; io.dbgG = dG; io.g_force_wbc = d_force_wbc; io.force_stride = 51; io.dbgT = (long long *)c->d_dbg_cycles;
     // the planned launch (and its two stream events) is only worth issuing when the last plan listed somebody: the list's length comes back
     // through pinned memory without a sync.  A stale zero just means the main pass solves everybody (P.skip stays null): consistent either way.
-    if (planned && LN.plan_n != n) { LN.h_pre_count[0] = LN.h_pre_count[1] = 0; static const int ps = [] { const char *e = getenv("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); LN.plan_sync_left = ps; }
+    if (planned && LN.plan_n != n) { LN.h_pre_count[0] = LN.h_pre_count[1] = 0; static const int ps = [] { const char *e = lab_env("QRGPU_PLAN_SYNC"); return e ? atoi(e) : 2; }(); LN.plan_sync_left = ps; }
     const bool have_plan = planned && LN.plan_n == n && LN.h_pre_count[LN.rescue_parity] > 0;
     // QRGPU_PLANNED_MODE: 0 = planned list on the context's side stream (fork / join events), 1 = planned list and main pass on the SAME
     // stream, the main pass launched with hipExtAnyOrderLaunch so that it may start before the list launch has finished: the list's
     // workgroups (each needs a whole CU's LDS) are dispatched first, the main pass's fill the rest of the machine
-    static const int planned_mode = [] { const char *e = getenv("QRGPU_PLANNED_MODE"); return e ? atoi(e) : 0; }();
+    static const int planned_mode = [] { const char *e = lab_env("QRGPU_PLANNED_MODE"); return e ? atoi(e) : 0; }();
     bool poll_join = false;
     P.planned_done = nullptr; P.planned_expect = 0;
     if (have_plan) {
@@ -741,7 +766,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = list_lds;                       // (the one-robot-per-workgroup form below: one_lds)
         L.sinv_spill = c->d_sinv_spill;               // (null at h <= 11; the whole-CU kernels of h > 11 put S^-1 there when an all-stance robot's M leaves no room)
-        static const int gate_on = [] { const char *e = getenv("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
+        static const int gate_on = [] { const char *e = lab_env("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
         const bool gate = gate_on && planned_mode != 1;
         L.started = gate ? LN.d_started : nullptr;
         int gate_expect = 0;
@@ -749,7 +774,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
         hipStream_t ls = planned_mode == 1 ? LN.stream : LN.side_stream;
         // QRGPU_PLANNED_WAVES=4: the four-wave list kernel, a workgroup striding over the list (this round's first form)
-        static const int planned_waves = [] { const char *e = getenv("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
+        static const int planned_waves = [] { const char *e = lab_env("QRGPU_PLANNED_WAVES"); return e ? atoi(e) : 8; }();
         // (big batches -- hundreds of listed robots at 8192 per launch -- stay on the striding kernel: one workgroup per robot would take every CU
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
         // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
@@ -762,16 +787,16 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // one-thread launch on the side stream polls a "go" count that the gate in front of the main pass -- a launch on the context's stream --
         // bumps before it waits for the listed workgroups.  Bounded (50 ms, QRGPU_PLAN_GO_MS); a gate that gives up calls the plan off for
         // this call (MpcLaunch::plan_abort): nobody runs on inputs the caller's stream has not produced yet.
-        static const int planned_fork = [] { const char *e = getenv("QRGPU_PLANNED_FORK"); return e ? atoi(e) : 0; }();
+        static const int planned_fork = [] { const char *e = lab_env("QRGPU_PLANNED_FORK"); return e ? atoi(e) : 0; }();
         const bool poll_fork = !planned_fork && planned_mode != 1 && gate && one_per_wg;
         P.plan_abort = nullptr; P.plan_epoch = 0; L.plan_abort = nullptr; L.plan_epoch = 0;
         // ... and, in a pipelined tick, how the trailing launch learns that the planned launch is through (MpcLaunch::planned_done); QRGPU_PLANNED_JOIN=1: an event
-        static const int planned_join = [] { const char *e = getenv("QRGPU_PLANNED_JOIN"); return e ? atoi(e) : 0; }();
+        static const int planned_join = [] { const char *e = lab_env("QRGPU_PLANNED_JOIN"); return e ? atoi(e) : 0; }();
         poll_join = poll_fork && piped && !planned_join;
         // grid of the one-robot-per-workgroup launch: the list's length as the host last saw it, plus two (below)
         // (h > 11 two to a CU: the cost rule's share of the list comes and goes with the robots' smoothed costs, a dozen entries a tick -- and a
         //  robot handed to the trailing launch is a whole solve BEHIND the main pass: 1.10 M ticks/s with eight spare workgroups, 1.43 M with 24 or 48)
-        static const int g3_extra = [] { const char *e = getenv("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
+        static const int g3_extra = [] { const char *e = lab_env("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
         int g3 = LN.h_pre_count[LN.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
         L.planned_stride = (two && g3 > g3_cap) ? 1 : 0;
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
@@ -1211,7 +1236,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     }
     // the join: QRGPU_PIPE_JOIN=1 (default) a one-thread launch on the context's stream that polls the count of WBC waves whose written-through
     // outputs are in memory; 0: an event of the WBC stream (10-13 us between the last WBC workgroup and the next launch on the context's stream)
-    static const int pipe_join = [] { const char *e = getenv("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
+    static const int pipe_join = [] { const char *e = lab_env("QRGPU_PIPE_JOIN"); return e ? atoi(e) : 1; }();
     // Overlapped tick (qrgpu_set_tick_overlap; h <= 11): the tick's launches go on lane 1 or 2 -- stream sets of the context's own, alternating --
     // and the context's stream carries only the join.  When the caller's previous call was an overlapped tick of the same batch that wrote OTHER
     // output arrays, this tick is CHAINED to it: its main pass is released as soon as every workgroup of that tick's MPC launches has started
@@ -1294,13 +1319,13 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (No fork event from the context stream: the gate below opens only once this tick's main pass -- queued on the context stream behind
     //  everything the caller put there -- is running, and the WBC launch of the previous tick is ahead of this one on the same stream.
     //  QRGPU_PIPE_FORK=1 puts the event back: 10-15 us of cross-stream hand-over per tick.)
-    static const int pipe_fork = [] { const char *e = getenv("QRGPU_PIPE_FORK"); return e ? atoi(e) : 0; }();
+    static const int pipe_fork = [] { const char *e = lab_env("QRGPU_PIPE_FORK"); return e ? atoi(e) : 0; }();
     if (pipe_fork && !ovl) {
         HIPCHK(c, hipEventRecord(c->ev_wbc_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->wbc_stream, c->ev_wbc_fork, 0));
     }
     // (QRGPU_PIPE_EARLY=K opens the gate K workgroups early: an experiment, see LAB_NOTES.md)
-    static const int pipe_early = [] { const char *e = getenv("QRGPU_PIPE_EARLY"); return e ? atoi(e) : 0; }();
+    static const int pipe_early = [] { const char *e = lab_env("QRGPU_PIPE_EARLY"); return e ? atoi(e) : 0; }();
     // (the half of d_wbc_order this tick's WBC launch reads: taken before launch_mpc, whose trailing launch writes the other half and flips the parity)
     const int *const wbc_order_in = (c->wbc_order_n == n && !ovl) ? c->d_wbc_order + (size_t)c->wbc_order_parity * (size_t)c->max_batch : nullptr;
     int rc = launch_mpc(c, n, d_type_id, d_mpc_state, d_traj, d_gait, d_fb_state + (size_t)13 * n, force, d_tau, d_status, nullptr, nullptr, nullptr, 0, true, lane_id,
@@ -1364,7 +1389,7 @@ int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->ev_call[0]) for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->ev_call[k], hipEventDisableTiming));
     if (!c->wbc_stream_hi) {
-        static const int hi = [] { const char *e = getenv("QRGPU_OV_WBC_PRIORITY"); return e ? atoi(e) : 1; }();
+        static const int hi = [] { const char *e = lab_env("QRGPU_OV_WBC_PRIORITY"); return e ? atoi(e) : 1; }();
         if (hi) HIPCHK(c, create_side_stream(&c->wbc_stream_hi));
         else HIPCHK(c, hipStreamCreateWithFlags(&c->wbc_stream_hi, hipStreamNonBlocking));
     }

@@ -1,6 +1,7 @@
 // Internal: the context behind the opaque qrgpu_ctx of include/qrgpu.h (shared by qrgpu_api.hip and qrgpu_comm.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -172,6 +173,20 @@ struct qrgpu_ctx {
     size_t ev_used[2] = {0, 0};
     std::vector<hipEvent_t> marks;   // qrgpu_mark: caller-indexed events on the context stream
 };
+
+// Environment switches.  The SUPPORTED ones are listed in include/qrgpu.h (name, default, effect) and read with getenv.  Everything else that
+// rounds 1-3 measured with -- alternative launch shapes, event / polling forms of each hand-over, thresholds -- is a LABORATORY switch: read
+// through lab_env, which answers only when QRGPU_LAB=1 is set, so that a product run cannot be steered by a leftover of an experiment.
+// qrgpu_create warns once per process about any other QRGPU_* variable it finds in the environment.
+inline const char *lab_env(const char *name)
+{
+    static const bool lab = [] { const char *e = getenv("QRGPU_LAB"); return e && atoi(e) != 0; }();
+    return lab ? getenv(name) : nullptr;
+}
+#define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", \
+                            "QRGPU_COMM_EVENTS", "QRGPU_SINGLE_COPIES", "QRGPU_PERSIST", "QRGPU_H16_TWO", "QRGPU_H16_TWO_HOLD", "QRGPU_H16_BIG_US", "QRGPU_H16_BIG_STAY_US", \
+                            "QRGPU_LIB", "QRGPU_EXTRA_FLAGS", "QRGPU_LAB"
+#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN"
 
 #define HIPCHK(ctx, call)                                                                    \
     do {                                                                                     \

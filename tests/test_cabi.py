@@ -111,3 +111,23 @@ def test_error_returns(gpu_ctx, pkg):
             v.free()
     finally:
         ctx.close()
+
+
+def test_supported_environment_switches_are_listed_in_the_header():
+    """include/qrgpu.h carries the table of supported environment switches; csrc/qrgpu_ctx.h the list the library checks the environment against
+    (anything else named QRGPU_* is reported once by qrgpu_create).  Every getenv of the host code names a supported switch -- laboratory
+    switches go through lab_env and answer only under QRGPU_LAB=1 -- and every supported switch is in the header's table."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ctxh = open(os.path.join(root, "quadruped-robot_amd", "csrc", "qrgpu_ctx.h")).read()
+    header = open(os.path.join(root, "include", "qrgpu.h")).read()
+    sup = re.search(r"#define QRGPU_SUPPORTED_ENV (.*?)\n#define QRGPU_LAB_ENV (.*?)\n", ctxh, re.S)
+    supported = set(re.findall(r'"(QRGPU_\w+)"', sup.group(1)))
+    lab = set(re.findall(r'"(QRGPU_\w+)"', sup.group(2)))
+    assert supported and lab and not (supported & lab)
+    for name in supported:
+        assert re.search(r"^ \*   %s\b" % name, header, re.M), name
+    for f in ("qrgpu_api.hip", "qrgpu_comm.hip"):
+        src = open(os.path.join(root, "quadruped-robot_amd", "csrc", f)).read()
+        assert set(re.findall(r'[^_]getenv\("(QRGPU_\w+)"\)', src)) <= supported, f
+        assert set(re.findall(r'lab_env\("(QRGPU_\w+)"\)', src)) <= lab | {"QRGPU_LAB"}, f
