@@ -999,15 +999,17 @@ def main():
 
 def committed_traffic(kernel, n, h):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
-    the gfx950 correction of MI355X_MICROARCH.md), which are separate profiler runs of this same command: profiles/r03_pmc_summary.json names
+    the gfx950 correction of MI355X_MICROARCH.md), which are separate profiler runs of this same command: profiles/r04_pmc_summary.json names
     the commit they were taken at.  Only quoted for the configuration they were collected on (1024 robots, h = 10)."""
-    p = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    p = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+    if not os.path.exists(p):
+        p = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
     if not os.path.exists(p) or n != 1024 or h != 10:
         return None, None
     try:
         d = json.load(open(p))
         k = d["kernels"][kernel]
-        return float(k["hbm_bytes_per_launch"]), "profiles/r03_pmc_summary.json (commit %s; %s)" % (d.get("commit", "?"), d.get("recipe", "rocprofv3 --pmc passes of bench.py"))
+        return float(k["hbm_bytes_per_launch"]), os.path.relpath(p, ROOT) + " (commit %s; %s)" % (d.get("commit", "?"), d.get("recipe", "rocprofv3 --pmc passes of bench.py"))
     except Exception:
         return None, None
 
