@@ -9,7 +9,9 @@ ROOT=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
+PART=${2:-12}
 run() { name=$1; shift; timeout -k 10 500 "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "$name failed"; echo "$name done"; }
+if [[ $PART == *1* ]]; then
 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -1 $OUT/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 run bench python bench.py
@@ -30,6 +32,8 @@ if [ -f scratch/ab/tl.so ]; then
   echo "timeline done"
 fi
 for u in cumask cumask2 pipes; do [ -x scratch/ubench/$u ] && timeout -k 5 60 scratch/ubench/$u > $OUT/ubench_$u.txt 2>&1; done; echo "ubench done"
+fi
+[[ $PART == *2* ]] || exit 0
 B="python3 $ROOT/bench.py --steps 96 --warmup 4 --no-cpu-baseline --no-side"
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- $B > $OUT/prof_bench.json 2> $OUT/prof.err
