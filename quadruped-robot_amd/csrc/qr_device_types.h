@@ -65,6 +65,8 @@ struct MpcLaunch {
     int *pre_count;             // [0], [1] list lengths by call parity, [2] planning workgroups done (last one publishes the hint)
     int *pre_hint;              // the same two lengths in pinned host memory (the host decides from them whether to issue the planned launch), or null
     int *pre_list;
+    int pre_list_next;          // where the planning writes the NEXT list, as an offset from pre_list (entries): 0 = over this one (the planned launch that reads it is through
+                                // before the trailing launch starts), the lane's other half in an overlapped tick at h > 11 (there it is not: the trailing launch follows the main pass only)
     unsigned char *skip;
     int big_nls;                // 0 = no class rule
     int big_margin;             // a solve that ends within this many rows of what the main pass's LDS holds puts its robot on the planned list
@@ -128,6 +130,24 @@ struct MpcLaunch {
     const unsigned *prev_solved;
     unsigned prev_epoch;
     long long xtick_wait;       // bound of that wait, in ticks of the 100 MHz clock (20 ms; QRGPU_OV_WAIT_US for the give-up tests)
+    // Overlapped ticks at h > 11: the trailing launch normally only sorts and plans (eight small workgroups on the lane's stream: a whole-CU
+    // workgroup would queue behind the NEXT tick's planned launch on the reserved CUs for a third of a tick).  plan_only = 1: it does that and,
+    // should the rescue list not be empty after all -- a robot that changed class this very tick, with no rescue launch queued for it -- gives
+    // each listed robot QRGPU_ST_MPC_OVERFLOW and raises its flag (never silent, never a hang); rescue_hint (pinned) tells the host, whose next
+    // ticks on this lane then carry the whole-CU rescue launch again.
+    int plan_only;
+    int *rescue_hint;
+    // ... and who solves a robot that turns up on the rescue list of such a tick -- one that changed class since the lane's plan was made, or whose
+    // working set outgrew the main pass: the tick's PLANNED launch.  Its workgroups hold the reserved CUs anyway; when their share of the list is
+    // done they stay and take rescue-list entries as the main pass appends them (rescue_taken: the list's second head, a compare-and-swap per
+    // entry; an entry reads -1 until its writer's store has landed, and is set back to -1 by whoever takes it), until every workgroup of the main
+    // pass has left (main_done, cumulative like `started`, against main_done_expect) and the list is empty.  Not the trailing launch on the
+    // reserved CUs: the NEXT tick's planned workgroups hold those by then, each waiting for its robot's previous solve -- one of which would be
+    // the robot the trailing launch cannot start to solve (measured: every listed robot 20 ms late, tick after tick).  plan_only = 2 tells
+    // the trailing launch that the rescue list is not its business.
+    int *main_done;
+    int main_done_expect;
+    int *rescue_taken;
 };
 #define QRGPU_ST_PIPE_TIMEOUT_D 0x02000000   // pipelined tick: the WBC gave up waiting for this robot's MPC forces (never seen; never silent)
 
@@ -194,6 +214,18 @@ __host__ __device__ static inline size_t mpc_lds_fixed_bytes(int h, bool multi)
     b += 2 * (6 * NL + ((6 * NL) & 1));                                // sPos
     b += 4 * 16;                                                       // sMisc (+ the control block of the control/worker loop)
     return (b + 7) & ~(size_t)7;
+}
+
+// Per-robot epoch words of the overlapped tick (MpcLaunch::solved, WbcPipe::wbc_done).  Epochs run 1 .. 2^30 - 1 and wrap; a word only ever moves
+// FORWARD (modulo 2^30): should a robot's wait for its predecessor give up and its solve finish before the late predecessor's, that predecessor's
+// older epoch must not overwrite the newer one -- the robot's next solve would wait for a value that never comes back, and so would every one after it.
+__device__ static inline bool qr_epoch_reached(unsigned word, unsigned want) { return ((word - want) & 0x3fffffffu) < 0x20000000u; }
+__device__ static inline void qr_epoch_raise(unsigned *p, unsigned e)
+{
+    unsigned old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (!qr_epoch_reached(old, e)) {
+        if (__hip_atomic_compare_exchange_strong(p, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
 }
 
 // Pipelined tick, WBC side (qr_wbc_kernel): flag / epoch: the per-robot flags the MPC solves raise (MpcLaunch::done_flag); list / list_count: a

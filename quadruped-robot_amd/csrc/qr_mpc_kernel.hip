@@ -41,9 +41,11 @@ namespace qrgpu {
 // launch, QRGPU_WBC_ORDER=1, needs them too): compiled in only with -DQR_TIMELINE (QRGPU_EXTRA_FLAGS).  With the pointers merely null at run
 // time the main pass was 1.5-2 % slower (1.373 against 1.346 ms at 8192 robots, A/B on one box).
 #ifdef QR_TIMELINE
+#define QR_TRACE(rid_, bits_) do { if (P.tl && P.solved) atomicOr((unsigned long long *)(P.tl + 768 + 32768 + 4096 + 64 + (P.solved_epoch & 15u) * 1024 + ((rid_) & 1023)), (unsigned long long)(bits_) | ((unsigned long long)(P.solved_epoch & 15u) << 32) | (1ull << 40)); } while (0)
 #define QR_P_TL P.tl
 #define QR_P_FTIME P.ftime
 #else
+#define QR_TRACE(rid_, bits_) do { } while (0)
 #define QR_P_TL ((long long *)nullptr)
 #define QR_P_FTIME ((int *)nullptr)
 #endif
@@ -194,6 +196,17 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
 // dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
 // the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
 // leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
+// Overlapped ticks: words one tick's launches leave for the lane's next tick (plan, lists, counters) are read while OTHER ticks' kernels run on the
+// same XCDs and keep lines of the same arrays in that XCD's L2 -- a plain load may hit a line fetched before the writer's kernel ended (measured:
+// a planned launch that read the list length of two ticks ago and left the list's tail to nobody).  xt: read it from memory (agent scope).
+template <typename T> __device__ __forceinline__ T ld_xt(const T *p, bool xt)
+{
+    return xt ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <typename T> __device__ __forceinline__ void st_xt(T *p, T v, bool xt)
+{
+    if (xt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 __device__ __forceinline__ void lpt_order_chunk(int x, int n, const int *__restrict__ cost, int *__restrict__ order, int *hist /* >= 2048 ints of LDS */)
 {
     const int chunk = (n + 7) >> 3;
@@ -497,10 +510,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         // per CU and an all-stance robot): nothing is computed here, the robot goes to the list pass at once -- and, through the `big`
         // bit, onto the planned list of the next call
         if (tid == 0) {
-            if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
-            if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            else if (P.solved) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody solves it again this tick)
-            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
+            if (io.g_status) st_xt(io.g_status + rid, st | QRGPU_ST_MPC_OVERFLOW_D, P.main_done != nullptr);      // (its rescuer may already be running: not behind that one's word)
+            if (P.main_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QR_TRACE(rid, 4 | (P.rescue_mode << 8));
+            if (P.rescue_list && !P.rescue_mode) st_xt(P.rescue_list + atomicAdd(P.rescue_count + P.rescue_parity, 1), rid, P.solved != nullptr);
+            else if (P.solved) qr_epoch_raise(P.solved + rid, P.solved_epoch);      // (nobody solves it again this tick)
+            if (P.cost) st_xt(P.cost + rid, 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16), P.solved != nullptr);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
         }
@@ -588,10 +603,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
     if ((long long)NT * NT * 1024 > (long long)P.lds_bytes - (long long)((Mb - smem) * 8)) {
         // (h = 11 all stance in the main pass's half-CU allotment: to the list pass, like a robot whose S^-1 does not fit)
         if (tid == 0) {
-            if (io.g_status) io.g_status[rid] = st | QRGPU_ST_MPC_OVERFLOW_D;
-            if (P.rescue_list && !P.rescue_mode) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
-            else if (P.solved) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nobody solves it again this tick)
-            if (P.cost) P.cost[rid] = 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16);
+            if (io.g_status) st_xt(io.g_status + rid, st | QRGPU_ST_MPC_OVERFLOW_D, P.main_done != nullptr);      // (its rescuer may already be running: not behind that one's word)
+            if (P.main_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QR_TRACE(rid, 4 | (P.rescue_mode << 8));
+            if (P.rescue_list && !P.rescue_mode) st_xt(P.rescue_list + atomicAdd(P.rescue_count + P.rescue_parity, 1), rid, P.solved != nullptr);
+            else if (P.solved) qr_epoch_raise(P.solved + rid, P.solved_epoch);      // (nobody solves it again this tick)
+            if (P.cost) st_xt(P.cost + rid, 255 | (P.pre_list ? 256 : 0) | (0xff0 << 16), P.solved != nullptr);
             if (P.done_flag) __hip_atomic_store(P.done_flag + rid, (P.done_epoch << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
         }
@@ -1307,10 +1324,12 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         bool warm_ok = true;
         if (xtick) {
             const long long t0 = wall_clock64();
-            while (__hip_atomic_load(P.prev_solved + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.prev_epoch) {
+            while (!qr_epoch_reached(__hip_atomic_load(P.prev_solved + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.prev_epoch)) {
                 if (wall_clock64() - t0 > P.xtick_wait) { st |= QRGPU_ST_PIPE_TIMEOUT_D; warm_ok = false; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
+            if (lane == 0) QR_TRACE(rid, 32);
+            if (lane == 0 && QR_P_TL) QR_P_TL[768 + 1024 * 16 + (P.solved_epoch & 15u) * 1024 + (rid & 1023)] = ((wall_clock64() - t0) << 8) | (long long)(P.rescue_mode & 7) | (warm_ok ? 0 : 8);
         }
         auto warm_ld = [&](const unsigned char *p_) -> unsigned { return xtick ? (unsigned)__hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)*p_; };
         if (warm && warm_ok && warm_ld(warm + QR_WARM_STRIDE - 1) == (unsigned)(unsigned char)h) {
@@ -1673,7 +1692,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             if (P.done_flag) __hip_atomic_store(io.g_status + rid, st | ((iter & 0xffff) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else io.g_status[rid] = st | ((iter & 0xffff) << 8);
         }
-        if (lane == 0 && to_rescue) P.rescue_list[atomicAdd(P.rescue_count + P.rescue_parity, 1)] = rid;
+        if (to_rescue && P.main_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (its rescuer may start at once: everything this solve stored is out first)
+        if (lane == 0 && to_rescue) QR_TRACE(rid, 64);
+        if (lane == 0 && to_rescue) st_xt(P.rescue_list + atomicAdd(P.rescue_count + P.rescue_parity, 1), rid, P.solved != nullptr);
         if (P.done_flag) {
             // pipelined tick: the forces, torques and status word of this robot are on their way to memory (write-through stores of this very
             // wave): wait for them, then raise the robot's flag for the WBC workgroup that is waiting for it (or, for a robot on its way to the
@@ -1720,8 +1741,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // overlapped ticks: the warm-start words and the cost word of this robot are on their way to memory (write-through stores of this
             // very wave): wait for them, then tell the robot's next solve (a robot on its way to the list pass is told by that pass's solve)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(P.solved + rid, P.solved_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) qr_epoch_raise(P.solved + rid, P.solved_epoch);
         }
+        if (lane == 0 && QR_P_TL && P.solved) QR_P_TL[768 + (P.solved_epoch & 15u) * 1024 + (rid & 1023)] = (wall_clock64() << 8) | (long long)(P.rescue_mode & 7) | (to_rescue ? 8 : 0) | ((long long)(P.solved_epoch & 15u) << 4);
         QR_TS(6);
         if (lane == 0 && QR_DBGT) QR_DBGT[(size_t)rid * 16 + 13] = wall_clock64();
         if (lane == 0 && QR_DBGT) { QR_DBGT[(size_t)rid * 16 + 7] = ns; QR_DBGT[(size_t)rid * 16 + 14] = q; }
@@ -1774,9 +1796,9 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                 // plan the next call: robots whose solve left the `big` bit go on the planned list and are skipped by the main pass
                 const int chunk = (P.n + 7) >> 3, lo = blockIdx.x * chunk, hi = (lo + chunk < P.n) ? lo + chunk : P.n;
                 for (int i = lo + threadIdx.x; i < hi; i += NTHR) {
-                    const int big = (P.lpt_cost_in[i] >> 8) & 1;
-                    P.skip[i] = (unsigned char)big;
-                    if (big) P.pre_list[atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 1)] = i;
+                    const int big = (ld_xt(P.lpt_cost_in + i, P.solved != nullptr) >> 8) & 1;
+                    st_xt(P.skip + i, (unsigned char)big, P.solved != nullptr);
+                    if (big) st_xt(P.pre_list + P.pre_list_next + atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 1), i, P.solved != nullptr);
                 }
                 __syncthreads();
                 // the last of the eight planning workgroups tells the host how long the list is (a write to pinned host memory: no copy
@@ -1785,16 +1807,30 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                     __threadfence();
                     if (atomicAdd(P.pre_count + 2, 1) == 7) {
                         P.pre_hint[P.rescue_parity ^ 1] = atomicAdd(P.pre_count + (P.rescue_parity ^ 1), 0);
+                        if (QR_P_TL) QR_P_TL[768 + 32768 + 4096 + (P.done_epoch & 63u)] = (long long)P.pre_hint[P.rescue_parity ^ 1] | ((long long)(P.rescue_parity ^ 1) << 16) | (1ll << 40);
                         __threadfence_system();
                     }
                 }
             }
         }
         const int *list = planned ? P.pre_list : P.rescue_list;
-        int cnt = planned ? P.pre_count[P.rescue_parity] : P.rescue_count[P.rescue_parity];
+        int cnt = ld_xt((planned ? P.pre_count : P.rescue_count) + P.rescue_parity, P.solved != nullptr);
         cnt = cnt < P.n ? cnt : P.n;
+        if (P.rescue_mode == 1 && P.rescue_hint && blockIdx.x == 0 && threadIdx.x == 0) { P.rescue_hint[0] = cnt; __threadfence_system(); }
+        if (P.plan_only == 2) return;            // (the tick's planned launch empties the rescue list: MpcLaunch::main_done)
+        if (P.plan_only) {
+            // (no solves here: this launch has neither the LDS nor the CUs for them.  A robot on the list after all is flagged, and its WBC workgroup told)
+            for (int e = blockIdx.x * NTHR + threadIdx.x; e < cnt; e += gridDim.x * NTHR) {
+                const int r = ld_xt(list + e, true);
+                if (io.g_status) __hip_atomic_store(io.g_status + r, QRGPU_ST_MPC_OVERFLOW_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (P.solved) qr_epoch_raise(P.solved + r, P.solved_epoch);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (P.done_flag) __hip_atomic_store(P.done_flag + r, P.done_epoch << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
         for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, list[e], smem);
+            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, ld_xt(list + e, P.solved != nullptr), smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
         }
         if (QR_P_TL && threadIdx.x == 0 && P.rescue_mode == 1) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 6, wall_clock64());
@@ -1805,22 +1841,72 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             // unsynchronised copy of the list's length; should the list be longer, the last workgroup hands the remainder to the trailing list
             // launch, and workgroups past the end of a shorter list leave at once.
             // (every workgroup of this launch tells the trailing launch when it is done -- planned_done -- whichever way it leaves)
+            // (timeline build: first start / last end of the planned launch's workgroups, behind the gate's two slots of the epoch's extra row)
+            if (QR_P_TL && threadIdx.x == 0) atomicMin(QR_P_TL + 640 + (P.done_epoch & 63u) * 2, wall_clock64());
             auto tell_done = [&]() {
+                if (QR_P_TL && threadIdx.x == 0) atomicMax(QR_P_TL + 640 + (P.done_epoch & 63u) * 2 + 1, wall_clock64());
                 if (P.planned_done && threadIdx.x < 64) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (threadIdx.x == 0) __hip_atomic_fetch_add(P.planned_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             };
             if (P.plan_abort && *P.plan_abort == P.plan_epoch) { tell_done(); return; }       // its gate gave up: the main pass solves everybody (below)
-            int cnt = P.pre_count[P.rescue_parity];
+            int cnt = ld_xt(P.pre_count + P.rescue_parity, P.solved != nullptr);
+            if (QR_P_TL && threadIdx.x == 0) QR_P_TL[768 + 32768 + (P.done_epoch & 63u) * 64 + (blockIdx.x & 63)] = (long long)cnt | ((long long)P.rescue_parity << 16) | ((long long)gridDim.x << 20) | ((long long)P.planned_stride << 32) | (1ll << 40);
             cnt = cnt < P.n ? cnt : P.n;
             if constexpr (MAXB == 5) {
                 // (QRGPU_H16_TWO: a tenth of a mixed h = 16 batch is listed -- more robots than the launch may take CUs.  The workgroup keeps its CU
                 //  and goes down the list; the waves its sweep no longer needs are parked as in the persistent main pass.)
                 if (P.planned_stride) {
+                    if (P.planned_stride == 2) cnt = 0;            // (no plan on the host's side: the main pass skips nobody, this launch only rescues)
                     for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
-                        mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, P.pre_list[e], smem);
+                        if (threadIdx.x == 0) QR_TRACE(ld_xt(P.pre_list + e, P.solved != nullptr), 8);
+                        mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, ld_xt(P.pre_list + e, P.solved != nullptr), smem);
                         __syncthreads();
+                    }
+                    if (P.main_done && P.rescue_taken && P.rescue_list) {
+                        // stay for the main pass's hand-overs (MpcLaunch::main_done)
+                        volatile int *sNext = (volatile int *)smem;        // (the head of the dynamic LDS, dead between two solves)
+                        int *const head = P.rescue_taken + P.rescue_parity;
+                        const int *const tail = P.rescue_count + P.rescue_parity;
+                        const long long t0 = wall_clock64();
+                        for (;;) {
+                            if (threadIdx.x == 0) {
+                                int got = -2;
+                                for (;;) {
+                                    int taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    int avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (taken < avail && taken < P.n) {
+                                        if (!__hip_atomic_compare_exchange_strong(head, &taken, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                                        // (the entry's store follows its writer's bump of the tail: a few hundred nanoseconds at most)
+                                        int r = -1;
+                                        const long long t1 = wall_clock64();
+                                        while ((r = __hip_atomic_load(P.rescue_list + taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t1 < 100000)
+                                            __builtin_amdgcn_s_sleep(4);
+                                        if (r < 0 || r >= P.n) continue;           // (cannot happen: the robot's WBC workgroup then reports it, QRGPU_ST_PIPE_TIMEOUT)
+                                        __hip_atomic_store(P.rescue_list + taken, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        got = r;
+                                        QR_TRACE(r, 16);
+                                        break;
+                                    }
+                                    if ((int)((unsigned)__hip_atomic_load(P.main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)P.main_done_expect) >= 0) {
+                                        avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (taken < avail && taken < P.n) continue;
+                                        break;                                     // the main pass is through and the list is empty
+                                    }
+                                    if (wall_clock64() - t0 > 5 * P.xtick_wait) break;          // (100 ms: a main pass that never ends)
+                                    __builtin_amdgcn_s_sleep(32);
+                                }
+                                *sNext = got;
+                            }
+                            __syncthreads();
+                            const int rid = *sNext;
+                            __syncthreads();
+                            if (rid < 0) break;
+                            mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, rid, smem);
+                            __syncthreads();
+                        }
                     }
                     tell_done();
                     return;
@@ -1828,7 +1914,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             }
             if (blockIdx.x == gridDim.x - 1 && cnt > (int)gridDim.x && P.rescue_list) {
                 for (int e2 = (int)gridDim.x + (int)threadIdx.x; e2 < cnt; e2 += NTHR) {
-                    const int r2 = P.pre_list[e2];
+                    const int r2 = ld_xt(P.pre_list + e2, P.solved != nullptr);
                     __hip_atomic_store(P.rescue_list + atomicAdd(P.rescue_count + P.rescue_parity, 1), r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // (pipelined tick: the WBC workgroup of a robot handed on like this must not wait for a flag nobody raises -- the main pass
                     //  skips the robot, the trailing launch raises none -- but leave it to the WBC pass behind the trailing launch)
@@ -1837,20 +1923,30 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                 __syncthreads();                       // (every wave's hand-over stores are out before wave 0 can tell anybody)
             }
             if ((int)blockIdx.x >= cnt) { tell_done(); return; }
-            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, P.pre_list[blockIdx.x], smem);
+            mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, ld_xt(P.pre_list + blockIdx.x, P.solved != nullptr), smem);
             tell_done();                               // (wave 0 is the last to return from the solve and the one that stored its results)
             return;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
-            if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
-            if (P.pre_count) { P.pre_count[P.rescue_parity ^ 1] = 0; P.pre_count[2] = 0; }
+            if (P.rescue_count) st_xt(P.rescue_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr);
+            if (P.rescue_taken) st_xt(P.rescue_taken + (P.rescue_parity ^ 1), 0, true);
+            if (P.pre_count) { st_xt(P.pre_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr); st_xt(P.pre_count + 2, 0, P.solved != nullptr); }
         }
         const int slot = xcd_robot_index(blockIdx.x, P.n);
-        if (slot < 0) return;
-        const int rid = P.order ? P.order[slot] : slot;       // same XCD chunk either way (the order permutes inside a chunk)
-        // solved by the planned list launch, beside this one -- unless that launch's gate gave up waiting for this one's stream (plan_abort)
-        if (P.skip && P.skip[rid] && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) return;
-        mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, rid, smem);
+        if (slot >= 0) {
+            const int rid = P.order ? ld_xt(P.order + slot, P.solved != nullptr) : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+            // solved by the planned list launch, beside this one -- unless that launch's gate gave up waiting for this one's stream (plan_abort)
+            if (threadIdx.x == 0) QR_TRACE(rid, 1);
+            if (!(P.skip && ld_xt(P.skip + rid, P.solved != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)))
+                mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, rid, smem);
+            else if (threadIdx.x == 0) QR_TRACE(rid, 2);
+        }
+        // (overlapped ticks at h > 11: the planned launch's workgroups take what this pass leaves on the rescue list -- thread 0 is the one that
+        //  appends -- and go home when every workgroup of this launch has left: MpcLaunch::main_done)
+        if (P.main_done && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(P.main_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1865,8 +1961,8 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
     volatile int *sNext = (volatile int *)smem;        // (the head of the dynamic LDS, dead between two solves: a static word would push the second workgroup off the CU)
     if (QR_P_TL && threadIdx.x == 0) atomicMin(QR_P_TL + (P.done_epoch & 63u) * 8, wall_clock64());
     if (blockIdx.x == 0 && threadIdx.x == 0) {         // the next call's counters
-        if (P.rescue_count) P.rescue_count[P.rescue_parity ^ 1] = 0;
-        if (P.pre_count) { P.pre_count[P.rescue_parity ^ 1] = 0; P.pre_count[2] = 0; }
+        if (P.rescue_count) st_xt(P.rescue_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr);
+        if (P.pre_count) { st_xt(P.pre_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr); st_xt(P.pre_count + 2, 0, P.solved != nullptr); }
     }
     if (blockIdx.x == 0 && threadIdx.x < 8) P.qhead_next[threadIdx.x] = 0;
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);      // HW_REG_XCC_ID[3:0]
@@ -1881,8 +1977,8 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
                     const int k = atomicAdd(P.qhead + y, 1);
                     if (k >= len) break;
                     if (P.main_started) atomicAdd(P.main_started, 1);
-                    const int r = P.order ? P.order[lo + k] : lo + k;
-                    if (P.skip && P.skip[r] && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) continue;         // solved by the planned list launch, beside this one
+                    const int r = P.order ? ld_xt(P.order + lo + k, P.solved != nullptr) : lo + k;
+                    if (P.skip && ld_xt(P.skip + r, P.solved != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) continue;         // solved by the planned list launch, beside this one
                     got = r;
                     if (QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 1, wall_clock64());
                     break;

@@ -1087,7 +1087,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
                 //  this workgroup, of the first pass, will find the robot's flag saying so and leave without storing anything)
                 for (;;) {
                     const unsigned w = __hip_atomic_load(pipe.wbc_done + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w == pipe.wait_epoch || w == pipe.epoch) break;
+                    if (qr_epoch_reached(w, pipe.wait_epoch)) break;
                     if (wall_clock64() - t0 > pipe.wait_ticks) { late = 1; break; }
                     __builtin_amdgcn_s_sleep(32);
                 }
@@ -1368,7 +1368,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
     if (pipe.wbc_done) {
         // overlapped ticks: g_prev of this robot is on its way to memory (written through by this wave): wait, then tell the robot's next WBC pass
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(pipe.wbc_done + rid, pipe.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) qr_epoch_raise(pipe.wbc_done + rid, pipe.epoch);
     }
     wbc_signal_done(pipe.finished, lane);
     if (QW_P_TL && lane == 0) atomicMax(QW_P_TL + (pipe.epoch & 63u) * 8 + (pipe.second ? 7 : 4), wall_clock64());

@@ -266,22 +266,26 @@ static hipError_t create_side_stream(hipStream_t *s)
 }
 
 // A lane's buffers, counters and (lanes 1, 2) streams.  Counters start at zero and are never cleared.
-static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream)
+static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream, bool masked = false)
 {
     if (L.d_order) return QRGPU_OK;
     const size_t nb = (size_t)c->max_batch;
     auto zalloc = [](auto **p, size_t bytes) { return hipMalloc((void **)p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
-    bool ok = hipMalloc(&L.d_order, sizeof(int) * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (nb + 4)) &&
+    bool ok = hipMalloc(&L.d_order, sizeof(int) * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (2 * nb + 4)) &&
               zalloc(&L.d_skip, nb) && hipHostMalloc((void **)&L.h_pre_count, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer((void **)&L.d_pre_hint, L.h_pre_count, 0) == hipSuccess && zalloc(&L.d_started, sizeof(int)) &&
-              (own_stream || create_side_stream(&L.side_stream) == hipSuccess) && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
-              zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) &&
+              ((own_stream && !masked) || masked || create_side_stream(&L.side_stream) == hipSuccess) && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
+              zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) && zalloc(&L.d_main_done, sizeof(int)) && zalloc(&L.d_rescue_taken, 2 * sizeof(int)) &&
               hipMalloc(&L.d_cmd_tick, sizeof(float) * 12 * nb) == hipSuccess &&
               hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok && own_stream) {
-        ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&L.ev_tail, hipEventDisableTiming) == hipSuccess;
-        L.own_stream = ok;
+        const uint32_t words = (uint32_t)((c->num_cu + 31) / 32);
+        ok = (masked ? (hipExtStreamCreateWithCUMask(&L.stream, words, c->mask16_main) == hipSuccess && hipExtStreamCreateWithCUMask(&L.side_stream, words, c->mask16_side) == hipSuccess)
+                     : hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess) &&
+             hipEventCreateWithFlags(&L.ev_tail, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_trail, hipEventDisableTiming) == hipSuccess;
+        L.own_stream = ok; L.masked = ok && masked;
     }
+    if (ok && masked) ok = hipMemset(L.d_rescue + 2, 0xff, sizeof(int) * nb) == hipSuccess;      // (an entry reads -1 until it is written: MpcLaunch::rescue_taken)
     if (ok) { L.h_pre_count[0] = L.h_pre_count[1] = L.h_pre_count[2] = L.h_pre_count[3] = 0; }       // ([2] of lane 0: a pipelined tick's join gave up waiting)
     (void)hipDeviceSynchronize();          // (the fills went to the default stream: none of the context's streams waits for that one)
     return ok ? QRGPU_OK : QRGPU_ERR_ALLOC;
@@ -289,8 +293,9 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream)
 static void lane_destroy(Lane &L)
 {
     if (L.stream && L.own_stream) { (void)hipStreamSynchronize(L.stream); }
-    if (L.side_stream && !L.own_stream) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }     // (lanes 1, 2 borrow lane 0's)
+    if (L.side_stream && (!L.own_stream || L.masked)) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }     // (lanes 1, 2 borrow lane 0's)
     if (L.ev_tail) hipEventDestroy(L.ev_tail);
+    if (L.ev_trail) hipEventDestroy(L.ev_trail);
     if (L.stream && L.own_stream) hipStreamDestroy(L.stream);
     if (L.d_order) hipFree(L.d_order);
     if (L.d_rescue) hipFree(L.d_rescue);
@@ -303,6 +308,8 @@ static void lane_destroy(Lane &L)
     if (L.d_planned_done) hipFree(L.d_planned_done);
     if (L.d_go) hipFree(L.d_go);
     if (L.d_lane_done) hipFree(L.d_lane_done);
+    if (L.d_main_done) hipFree(L.d_main_done);
+    if (L.d_rescue_taken) hipFree(L.d_rescue_taken);
     if (L.d_cmd_tick) hipFree(L.d_cmd_tick);
     if (L.ev_fork) hipEventDestroy(L.ev_fork);
     if (L.ev_join) hipEventDestroy(L.ev_join);
@@ -424,6 +431,7 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->wbc_stream) hipStreamDestroy(c->wbc_stream);
     if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); hipStreamDestroy(c->tail_stream); }
     if (c->wbc_stream_hi) { (void)hipStreamSynchronize(c->wbc_stream_hi); hipStreamDestroy(c->wbc_stream_hi); }
+    if (c->wbc_stream_16) { (void)hipStreamSynchronize(c->wbc_stream_16); hipStreamDestroy(c->wbc_stream_16); }
     for (int k = 0; k < 2; ++k) if (c->ev_call[k]) hipEventDestroy(c->ev_call[k]);
     if (c->ev_wbc_fork) hipEventDestroy(c->ev_wbc_fork);
     if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
@@ -545,7 +553,7 @@ static int ready_mask(const bool *r) { int m = 0; for (int t = 0; t < QR_MAX_TYP
 
 // What an overlapped tick adds to its MPC launches (qrgpu_tick_batch): the epoch its solves leave in d_solved, whether they wait -- per robot -- for
 // the previous tick's (chained), and the cost buffers they read and write.
-struct OvLaunch { unsigned epoch; bool chained; unsigned prev_epoch; bool plan_tick; };
+struct OvLaunch { unsigned epoch; bool chained; unsigned prev_epoch; bool plan_tick; int *prev_started; unsigned prev_started_total; };
 // bound of an overlapped tick's per-robot waits for its predecessor (20 ms; QRGPU_OV_WAIT_US: the give-up tests)
 static long long ov_wait_ticks()
 {
@@ -572,6 +580,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.done_epoch = c->tick_epoch;
     // overlapped tick (lanes 1, 2): per-robot hand-over of the warm-start and cost words between consecutive ticks (MpcLaunch::solved)
     const bool ovl = ov != nullptr;
+    const bool ov16 = ovl && LN.masked;            // h > 11 overlapped: main pass on the lane's (masked) stream, planned AND trailing launch on its side stream (reserved CUs)
     if (!ovl) { c->ov_chain = false; c->cost_n[0] = c->cost_n[1] = 0; }      // (any other MPC launch: the next overlapped tick waits for the context's stream)
     int *const cost_out = c->d_cost[ovl ? (ov->epoch & 1u) : 0];
     const int *const cost_prev = ovl ? c->d_cost[(ov->epoch & 1u) ^ 1u] : cost_out;
@@ -648,7 +657,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // than 45 % of the batch the calls go back to one workgroup per CU for 31 calls; nobody plans meanwhile, so the call after them runs two
         // to a CU whatever the old count says (on the old plan: consistent, if stale) and the one after that decides on the fresh count.
         static const int hold_calls = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
-        if (LN.two_hold > 0) { --LN.two_hold; two = false; }
+        if (ov16) { }                              // (qrgpu_tick_batch has decided: an overlapped tick IS the two-to-a-CU form)
+        else if (LN.two_hold > 0) { --LN.two_hold; two = false; }
         else if (LN.two_probe) LN.two_probe = false;
         else if (hold_calls > 0 && LN.plan_n == n && 20 * (long long)LN.h_pre_count[LN.rescue_parity] > 9 * (long long)n) { LN.two_hold = hold_calls; LN.two_probe = true; two = false; }
     }
@@ -668,7 +678,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     // planned list: needs the trailing list launch (it plans) and the per-robot cost words (they carry the `big` bit)
     const bool planned = c->planned && rescue && lpt;
     P.pre_count = planned ? LN.d_pre : nullptr;
-    P.pre_list = planned ? LN.d_pre + 4 : nullptr;
+    // (h > 11 overlapped: the list is two lists, by the parity the counters ping-pong on -- MpcLaunch::pre_list_next)
+    P.pre_list = planned ? LN.d_pre + 4 + ((ov16 && LN.rescue_parity) ? c->max_batch : 0) : nullptr;
+    P.pre_list_next = ov16 ? (LN.rescue_parity ? -c->max_batch : c->max_batch) : 0;
     P.pre_hint = planned ? LN.d_pre_hint : nullptr;
     P.skip = nullptr;
     P.big_nls = c->big_nls;
@@ -682,7 +694,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     }
     { static const int bm = [] { const char *e = lab_env("QRGPU_BIG_MARGIN"); return e ? atoi(e) : 6; }(); P.big_margin = two ? -1000 : bm; }
     P.big_cost = P.big_cost_stay = 0; P.planned_stride = 0;
-    if (two) {
+    // (not in an overlapped tick: a long pole no longer sets a span there -- a tick has two periods to finish -- and the reserved CUs are for the
+    //  robots that cannot run anywhere else; with the cost rule on, time spent WAITING counts as cost, the list grows and the reserved CUs fall behind)
+    if (two && !ov16) {
         // the long poles: a robot whose solve takes most of the tick's span two to a CU (a large working set over the spilled S^-1: 600-800 us
         // against a mean of 200) is planned onto a whole CU, and stays there while its solve costs more than QRGPU_H16_BIG_STAY_US there
         static const int big_us = [] { const char *e = getenv("QRGPU_H16_BIG_US"); return e ? atoi(e) : 450; }();
@@ -758,17 +772,26 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     static const int planned_mode = [] { const char *e = lab_env("QRGPU_PLANNED_MODE"); return e ? atoi(e) : 0; }();
     bool poll_join = false;
     P.planned_done = nullptr; P.planned_expect = 0;
-    if (have_plan) {
+    { static const bool dbg = lab_env("QRGPU_OV16_DEBUG") != nullptr;
+      if (dbg && ov16) fprintf(stderr, "ov16 tick epoch %u lane %d chained %d: planned %d plan_n %d hint[%d] %d (other %d) rescue hint %d young %d have_plan %d\n", ov->epoch, lane_id, (int)ov->chained,
+                               (int)planned, LN.plan_n, LN.rescue_parity, LN.h_pre_count[LN.rescue_parity], LN.h_pre_count[LN.rescue_parity ^ 1], LN.h_pre_count[3], LN.rescue_young, (int)have_plan); }
+    P.main_done = nullptr; P.main_done_expect = 0; P.rescue_taken = nullptr;
+    if (ov16 && rescue) {
+        // (h > 11 overlapped: the planned launch is also the tick's rescuer, plan or no plan -- MpcLaunch::main_done)
+        LN.main_done_total += main_grid;
+        P.main_done = LN.d_main_done; P.main_done_expect = LN.main_done_total; P.rescue_taken = LN.d_rescue_taken;
+    }
+    if (have_plan || (ov16 && rescue)) {
         // whole CU's LDS, 96 positions, workgroup b takes entries b, b + grid, ... of the list the last call's planning left
-        P.skip = LN.d_skip;
+        P.skip = have_plan ? LN.d_skip : nullptr;
         MpcLaunch L = P;
         L.persist = 0; L.qhead = nullptr; L.qhead_next = nullptr;
         L.rescue_mode = 2; L.order = nullptr; L.rescue_count = nullptr; L.rescue_list = nullptr;
         L.lds_bytes = list_lds;                       // (the one-robot-per-workgroup form below: one_lds)
         L.sinv_spill = c->d_sinv_spill;               // (null at h <= 11; the whole-CU kernels of h > 11 put S^-1 there when an all-stance robot's M leaves no room)
         static const int gate_on = [] { const char *e = lab_env("QRGPU_PLANNED_GATE"); return e ? atoi(e) : 1; }();
-        const bool gate = gate_on && planned_mode != 1;
-        L.started = gate ? LN.d_started : nullptr;
+        const bool gate = gate_on && planned_mode != 1 && !ov16;       // (reserved CUs: nothing to race the main pass for)
+        L.started = (gate || ov16) ? LN.d_started : nullptr;
         int gate_expect = 0;
         int pgrid = n / 16;                            // a list of the all-stance twentieth of a batch gets a workgroup per robot
         pgrid = pgrid < 16 ? 16 : (pgrid > c->num_cu ? c->num_cu : pgrid);
@@ -779,7 +802,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // from the main pass, and a stale short count would send most of the list to the trailing launch: 4.54 against 4.72 M ticks/s)
         // (h > 11 two to a CU: always the whole-CU kernel, on at most three quarters of the CUs -- a longer list is strided over, MpcLaunch::planned_stride)
         // (... unless most of the batch is listed -- a shard of standing robots: then the list is the launch, and it gets every CU)
-        const int g3_cap = (two && 2 * LN.h_pre_count[LN.rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu;
+        const int g3_cap = ov16 ? c->ov16_side_cus : ((two && 2 * LN.h_pre_count[LN.rescue_parity] <= n) ? 3 * c->num_cu / 4 : c->num_cu);
         const bool one_per_wg = planned_waves == 8 && (two || (n <= 2048 && LN.h_pre_count[LN.rescue_parity] <= (small ? c->num_cu / 4 : 3 * c->num_cu / 4)));
         // How the side stream learns that the context's stream has reached this call.  An event (QRGPU_PLANNED_FORK=1, and always for the
         // striding kernel and the ungated forms) costs ~10 us before the listed workgroups even launch -- 20 us between a tick's trailing launch and
@@ -798,8 +821,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         //  robot handed to the trailing launch is a whole solve BEHIND the main pass: 1.10 M ticks/s with eight spare workgroups, 1.43 M with 24 or 48)
         static const int g3_extra = [] { const char *e = lab_env("QRGPU_PLANNED_EXTRA"); return e ? atoi(e) : -1; }();
         int g3 = LN.h_pre_count[LN.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
-        L.planned_stride = (two && g3 > g3_cap) ? 1 : 0;
+        L.planned_stride = ov16 ? (have_plan ? 1 : 2) : ((two && g3 > g3_cap) ? 1 : 0);      // (2: no list, rescue only)
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
+        if (ov16) g3 = g3_cap;                         // (the reserved CUs are this launch's whatever the list's length: it is also the tick's rescuer)
         bool main_gate_queued = false;
         if (poll_fork) {
             static const long long go_ticks = [] { const char *e = getenv("QRGPU_PLAN_GO_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
@@ -821,6 +845,14 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         } else if (planned_mode != 1) {
             HIPCHK(c, hipEventRecord(LN.ev_fork, LN.stream));
             HIPCHK(c, hipStreamWaitEvent(LN.side_stream, LN.ev_fork, 0));
+            if (ov16 && ov->chained && ov->prev_started) {
+                // This tick's planned workgroups share the reserved CUs with its predecessor's, and each waits -- per robot -- for that robot's previous
+                // solve: not one of them may start before EVERY planned workgroup of the predecessor has (a waiting workgroup holds its CU; one that
+                // waits for a robot in the share of a workgroup that cannot start for lack of a CU never sees it: 144 robots timed out a tick, 5.8 ms).
+                hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.side_stream, ov->prev_started, (int)ov->prev_started_total, (long long)5000000, (int *)nullptr, 0,
+                                   (int *)nullptr);
+                HIPCHK(c, hipGetLastError());
+            }
         }
         if (one_per_wg) {
             // one robot per workgroup of the eight-wave whole-CU kernel; the grid is the list's length as the host last saw it (the kernel
@@ -856,7 +888,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         HIPCHK(c, hipExtLaunchKernel(main_fn, grid, dim3(threads), kargs, (size_t)P.lds_bytes, LN.stream, nullptr, nullptr, flags));
     }
     HIPCHK(c, hipGetLastError());
-    if (have_plan && planned_mode != 1 && !poll_join) HIPCHK(c, hipStreamWaitEvent(LN.stream, LN.ev_join, 0));
+    if (have_plan && planned_mode != 1 && !poll_join && !ov16) HIPCHK(c, hipStreamWaitEvent(LN.stream, LN.ev_join, 0));
+    // (h > 11 overlapped: the trailing launch only sorts and plans -- eight small workgroups on the lane's stream, MpcLaunch::plan_only -- and the
+    //  tick's planned launch takes the robots the main pass hands on, MpcLaunch::main_done.  A whole-CU trailing launch on the reserved CUs was
+    //  measured first: it queues behind the NEXT tick's planned workgroups, 200-350 us instead of 8 -- and those may be waiting for the very
+    //  robot it has yet to solve.)
+    hipStream_t trail_stream = LN.stream;
+    const bool plan_only = ov16 && rescue;
     if (rescue) {
         // trailing list launch: the robots whose working set outgrew the main pass (normally none: the workgroups sort the next call's
         // dispatch order, plan its list and exit) are re-solved with the whole CU's LDS and 96 working-set positions
@@ -873,11 +911,15 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         R.sinv_spill = c->d_sinv_spill;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
         // empty pass at 4096 robots)
-        int rgrid = half_lists ? 16 : (64 < n ? 64 : n);          // (chained ticks: every workgroup of this launch waits for a freed half CU)
+        int rgrid = (half_lists || plan_only) ? 16 : (64 < n ? 64 : n);          // (chained ticks: every workgroup of this launch waits for a freed half CU)
+        R.plan_only = plan_only ? 2 : 0;
+        R.rescue_hint = nullptr;
+        R.main_done = nullptr; R.rescue_taken = nullptr;
+        if (plan_only) R.lds_bytes = 16384;          // (the sort's histogram; MpcLaunch::lds_main still says what the main pass holds)
         if (rgrid < 8 && lpt) rgrid = 8;
         io.dbgH = nullptr; io.dbgG = nullptr; io.dbgT = nullptr;
         void *rargs[2] = {(void *)&R, (void *)&io};
-        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, LN.stream, nullptr, nullptr, 0));
+        HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(rgrid), dim3(256), rargs, (size_t)R.lds_bytes, trail_stream, nullptr, nullptr, 0));
         HIPCHK(c, hipGetLastError());
         // (the length of the list just planned reaches h_pre_count by itself).  A trailing launch that does not plan still flips the parity the
         // counters ping-pong on: whatever plan there was now sits under the wrong parity and is forgotten (the next planned call starts afresh)
@@ -1243,8 +1285,21 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // and fills the slots that tick's drain leaves empty; every robot waits for its own previous solve / WBC pass (MpcLaunch::solved,
     // WbcPipe::wbc_done).  Otherwise the lane waits for everything queued on the context's stream so far (an event): no overlap, same results.
     const bool was_chain = c->ov_chain;
-    bool ovl = piped && c->overlap && pipe_join && 4 * c->mpc.horizon <= 44 && !c->flops_on && c->lane[1].d_order && c->lane[2].d_order;
-    if (ovl) {
+    const bool small_h = 4 * c->mpc.horizon <= 44;
+    bool ovl = piped && c->overlap && pipe_join && !c->flops_on && c->lane[1].d_order && c->lane[2].d_order;
+    // h > 11: only the two-workgroups-per-CU form of the main pass (3.5 robots per CU and more, list launches and cost words on) overlaps, on the
+    // CU-masked lanes; a shard in which most robots stand (the planned list beyond 45 % of the batch) goes back to the plain tick for 31 calls
+    if (ovl && !small_h) {
+        static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
+        static const int hold16 = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
+        ovl = c->lane[3].d_order && c->lane[4].d_order && h16_two != 0 && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && c->lpt;
+        if (ovl) {
+            const Lane &NL = c->lane[3 + c->ov_next];
+            if (c->ov_hold > 0) { --c->ov_hold; ovl = false; }
+            else if (hold16 > 0 && NL.plan_n == n && 20 * (long long)NL.h_pre_count[NL.rescue_parity] > 9 * (long long)n) { c->ov_hold = hold16; ovl = false; }
+        }
+    }
+    if (ovl && small_h) {
         // A population with a PLAN -- robots that want a whole CU on a list launch beside the main pass -- is not for overlapped ticks: on a machine
         // that is never empty a whole-CU workgroup waits until both halves of some CU happen to be free at once, and the half-CU list kernel that
         // needs no such luck (S^-1 in the global scratch) takes 300 us and more for such a robot, which the pipeline then waits for: 3.0-3.3 against
@@ -1255,7 +1310,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
         if (c->ov_hold > 0) { --c->ov_hold; ovl = false; }
         else if (hold_calls > 0 && c->planned && c->rescue && c->lpt && NL.plan_n == n && NL.h_pre_count[NL.rescue_parity] > 0) { c->ov_hold = hold_calls; ovl = false; }
     }
-    const int lane_id = ovl ? 1 + c->ov_next : 0;
+    const int lane_id = ovl ? (small_h ? 1 : 3) + c->ov_next : 0;
     Lane &LN = c->lane[lane_id];
     // wbcData.Fr_des = f (:408): the WBC kernel takes its Fr_des rows from the force array the MPC kernel has just written.
     // The K14 tail, when switched on, is applied by the WBC kernel after the stance / swing merge (the MPC launch leaves d_tau raw).
@@ -1277,8 +1332,8 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (the give-up word of this tick's WBC gate: a ring indexed by the epoch -- several ticks may be queued behind a backlog)
     int *const gate_abort = c->d_gate_abort + (epoch & (QR_ABORT_RING - 1));
     // (QRGPU_OV_FAULT=1, the give-up tests: chained ticks wait for an epoch nobody ever writes, so that every per-robot wait runs into its bound)
-    static const unsigned ov_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return (e && atoi(e)) ? 0x40000000u : 0u; }();
-    OvLaunch ov{epoch, false, prev_epoch ^ ov_fault, false};
+    static const unsigned ov_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return (e && atoi(e)) ? 0x10000000u : 0u; }();      // (a quarter of the epochs' range ahead: "not reached yet")
+    OvLaunch ov{epoch, false, (prev_epoch + ov_fault) & 0x3fffffffu, false, nullptr, 0u};
     if (ovl) {
         c->ov_next ^= 1;
         const void *outs[4] = {(const void *)d_force, (const void *)d_tau, (const void *)d_qdes, (const void *)d_status};
@@ -1288,7 +1343,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
         // a machine that is never empty a whole-CU workgroup waits until both halves of some CU happen to be free at once (the half-CU list kernel
         // that needs no such luck takes 300 us and more for such a robot, and the pipeline then waits for it: 3.0 against 4.2 M ticks/s on the
         // populations that hold an all-stance robot at a degenerate vertex).
-        ov.plan_tick = c->planned && c->rescue && c->lpt && LN.plan_n == n && LN.h_pre_count[LN.rescue_parity] > 0;       // (only with QRGPU_OV_PLAN_HOLD=0)
+        ov.plan_tick = small_h && c->planned && c->rescue && c->lpt && LN.plan_n == n && LN.h_pre_count[LN.rescue_parity] > 0;       // (only with QRGPU_OV_PLAN_HOLD=0)
         ov.chained = was_chain && c->ov_n == n && c->ov_epoch == prev_epoch && c->ov_prev_ori == (const void *)d_prev_ori && distinct && !ov.plan_tick && !c->ov_prev_plan;
         c->ov_prev_plan = ov.plan_tick;
         // What the caller had queued on the context's stream when it made the PREVIOUS tick call -- the join of the tick before that one and whatever
@@ -1302,7 +1357,8 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
             HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_prev], 0));
             // ... and not before every workgroup of the previous tick's main pass and planned launch has started (bounded: 50 ms; harmless if it gives up)
             Lane &PL = c->lane[c->ov_lane_last];
-            hipLaunchKernelGGL(qr_gate2_kernel, dim3(1), dim3(64), 0, LN.stream, c->d_main_started, (int)c->ov_main_total, PL.d_started, (int)PL.started_total, (long long)5000000,
+            // (h > 11: the planned launches live on reserved CUs, the main pass cannot keep them from starting)
+            hipLaunchKernelGGL(qr_gate2_kernel, dim3(1), dim3(64), 0, LN.stream, c->d_main_started, (int)c->ov_main_total, small_h ? PL.d_started : (int *)nullptr, (int)PL.started_total, (long long)5000000,
                                c->d_timeline ? c->d_timeline + 512 + (epoch & 63u) * 2 : (long long *)nullptr);      // (diagnostic: qrgpu_debug_gate2)
             HIPCHK(c, hipGetLastError());
         } else {
@@ -1310,6 +1366,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
             HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_now], 0));
         }
         c->ev_call_last = ev_now;
+        if (ov.chained) { ov.prev_started = c->lane[c->ov_lane_last].d_started; ov.prev_started_total = c->lane[c->ov_lane_last].started_total; }
         // (the all-gathers the caller fenced since the last tick -- qrgpu_allgather_fence -- still read output arrays this tick overwrites)
         for (int sl = 0; sl < 2; ++sl)
             if (((c->ov_fence_slots >> sl) & 1) && c->ev_gather[sl]) HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_gather[sl], 0));
@@ -1335,7 +1392,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (bounded at 50 ms; QRGPU_PIPE_GATE_MS for the tests.  A gate that gives up -- the caller had that much work of its own queued in front of
     //  this tick -- turns the tick into the serial one: WbcPipe::gate_abort)
     static const long long gate_ticks = [] { const char *e = getenv("QRGPU_PIPE_GATE_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-    const hipStream_t wbc_stream = ovl ? c->wbc_stream_hi : c->wbc_stream;
+    const hipStream_t wbc_stream = ovl ? (small_h ? c->wbc_stream_hi : c->wbc_stream_16) : c->wbc_stream;
     // (an overlapped tick has no second pass to fall back on: its gate is patient -- 2 s -- and one that gives up just lets the launch go: every wait
     //  of a WBC workgroup for its robot's forces is bounded and flagged.  What the serial fall-back protects against -- inputs that the caller's stream
     //  has not produced yet -- cannot happen: a chained tick's inputs are ready by contract, an unchained one makes this stream wait for the event too)
@@ -1345,7 +1402,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     HIPCHK(c, hipGetLastError());
     static const long long flag_ticks = [] { const char *e = getenv("QRGPU_PIPE_WAIT_US"); return e ? 100LL * atoll(e) : 400000LL; }();
     unsigned *const wbc_done = ovl ? c->d_wbc_done : nullptr;
-    const unsigned wait_epoch = (ovl && ov.chained) ? (prev_epoch ^ ov_fault) : 0u;
+    const unsigned wait_epoch = (ovl && ov.chained) ? ((prev_epoch + ov_fault) & 0x3fffffffu) : 0u;
     WbcPipe wp{LN.d_done_flag, epoch, nullptr, nullptr, ovl ? (int *)nullptr : gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in, wbc_done, wait_epoch, ov_wait_ticks(),
                ovl ? 1 : 0, flag_ticks};
     rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
@@ -1393,9 +1450,21 @@ int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
         if (hi) HIPCHK(c, create_side_stream(&c->wbc_stream_hi));
         else HIPCHK(c, hipStreamCreateWithFlags(&c->wbc_stream_hi, hipStreamNonBlocking));
     }
-    for (int l = 1; l < QR_LANES; ++l) {
+    for (int l = 1; l <= 2; ++l) {
         if (lane_create(c, c->lane[l], true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a lane failed"; return QRGPU_ERR_ALLOC; }
         c->lane[l].side_stream = c->lane[0].side_stream;         // (planned launches of consecutive ticks: one stream, in tick order)
+    }
+    if (!c->ov16_side_cus && c->horizon_max > 11) {
+        // h > 11: the machine split in space (qrgpu_ctx.h).  QRGPU_OV16_SIDE_CUS (32, 64, 96 of 256; default 64): the whole-CU launches' share.
+        static const int side_env = [] { const char *e = getenv("QRGPU_OV16_SIDE_CUS"); return e ? atoi(e) : 64; }();
+        int k = (side_env * c->num_cu / 256) & ~31;
+        if (k < 32) k = 32;
+        if (k > c->num_cu / 2) k = (c->num_cu / 2) & ~31;
+        c->ov16_side_cus = k;
+        for (int b = 0; b < c->num_cu && b < 512; ++b) { if (b < c->num_cu - k) c->mask16_main[b >> 5] |= 1u << (b & 31); else c->mask16_side[b >> 5] |= 1u << (b & 31); }
+        HIPCHK(c, hipExtStreamCreateWithCUMask(&c->wbc_stream_16, (uint32_t)((c->num_cu + 31) / 32), c->mask16_main));
+        for (int l = 3; l <= 4; ++l)
+            if (lane_create(c, c->lane[l], true, true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a CU-masked lane failed"; return QRGPU_ERR_ALLOC; }
     }
     // probe, both ways round, and each lane's stream against the WBC stream and the context's
     int *d_probe = nullptr;
@@ -1621,7 +1690,7 @@ int qrgpu_debug_counters(qrgpu_ctx *c, int *host_out /* [12]: device count / hos
     HIPCHK(c, hipMemcpy(host_out + 0, c->d_main_started, sizeof(int), hipMemcpyDeviceToHost)); host_out[1] = (int)c->main_started_total;
     HIPCHK(c, hipMemcpy(host_out + 2, c->d_wbc_finished, sizeof(int), hipMemcpyDeviceToHost)); host_out[3] = (int)c->wbc_finished_total;
     HIPCHK(c, hipMemcpy(host_out + 4, c->d_tick_done, sizeof(int), hipMemcpyDeviceToHost)); host_out[5] = (int)c->tick_done_total;
-    for (int l = 1; l < QR_LANES; ++l)
+    for (int l = 1; l <= 2; ++l)
         if (c->lane[l].d_lane_done) { HIPCHK(c, hipMemcpy(host_out + 4 + 2 * l, c->lane[l].d_lane_done, sizeof(int), hipMemcpyDeviceToHost)); host_out[5 + 2 * l] = (int)c->lane[l].lane_done_total; }
     host_out[10] = (int)c->tick_epoch;
     if (!c->d_join_dbg) { HIPCHK(c, hipMalloc(&c->d_join_dbg, 16 * 8 * sizeof(long long))); HIPCHK(c, hipMemset(c->d_join_dbg, 0, 16 * 8 * sizeof(long long))); }
@@ -1637,7 +1706,31 @@ int qrgpu_debug_gate2(qrgpu_ctx *c, long long *host_out /* [64][2]: when the gat
 {
     if (!c || !c->d_timeline || !host_out) return QRGPU_ERR_BAD_ARG;
     (void)hipDeviceSynchronize();
-    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 512, sizeof(long long) * 128, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 512, sizeof(long long) * 256, hipMemcpyDeviceToHost));      // [64][2] gate up / open, then [64][2] planned launch first start / last end
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_timeline_solves(qrgpu_ctx *c, long long *host_out /* [2][16][1024]: per epoch & 15 and robot: (publish time << 8 | launch kind), (cross-tick wait << 8 | kind | 8 gave up) */)
+{
+    if (!c || !c->d_timeline || !host_out) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 768, sizeof(long long) * 2 * 16 * 1024, hipMemcpyDeviceToHost));
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_timeline_plans(qrgpu_ctx *c, long long *host_out /* [64][64] list length each planned workgroup read, then [64] the length each tick's planning left */)
+{
+    if (!c || !c->d_timeline || !host_out) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 768 + 32768, sizeof(long long) * (4096 + 64), hipMemcpyDeviceToHost));
+    return QRGPU_OK;
+}
+
+int qrgpu_debug_timeline_trace(qrgpu_ctx *c, long long *host_out /* [16][1024] what happened to each robot in each epoch & 15 (QR_TRACE bits) */)
+{
+    if (!c || !c->d_timeline || !host_out) return QRGPU_ERR_BAD_ARG;
+    (void)hipDeviceSynchronize();
+    HIPCHK(c, hipMemcpy(host_out, c->d_timeline + 768 + 32768 + 4096 + 64, sizeof(long long) * 16384, hipMemcpyDeviceToHost));
     return QRGPU_OK;
 }
 
@@ -1661,7 +1754,12 @@ int qrgpu_debug_timeline(qrgpu_ctx *c, long long *host_out /* [65][8] (row 64, e
 #endif
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->wbc_stream));
-    if (!c->d_timeline) { HIPCHK(c, hipMalloc(&c->d_timeline, sizeof(long long) * 640)); HIPCHK(c, hipMemset(c->d_timeline, 0, sizeof(long long) * 640)); }
+    if (!c->d_timeline) { HIPCHK(c, hipMalloc(&c->d_timeline, sizeof(long long) * (768 + 2 * 16 * 1024 + 4096 + 64 + 16384))); HIPCHK(c, hipMemset(c->d_timeline, 0, sizeof(long long) * (768 + 2 * 16 * 1024 + 4096 + 64 + 16384))); }
+    {   // (the planned launch's first start is an atomicMin)
+        long long ext[128];
+        for (int e = 0; e < 64; ++e) { ext[2 * e] = 0x7fffffffffffffffLL; ext[2 * e + 1] = 0; }
+        HIPCHK(c, hipMemcpy(c->d_timeline + 640, ext, sizeof(ext), hipMemcpyHostToDevice));
+    }
     if (!c->d_tlr) HIPCHK(c, hipMalloc(&c->d_tlr, sizeof(int) * 4 * (size_t)c->max_batch));
     if (host_out) HIPCHK(c, hipMemcpy(host_out, c->d_timeline, sizeof(long long) * 512, hipMemcpyDeviceToHost));
     long long init[512];

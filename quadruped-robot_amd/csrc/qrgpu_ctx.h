@@ -17,7 +17,7 @@ using namespace qrgpu;
 // tick).  Lanes 1 and 2 have streams of their own and alternate between consecutive OVERLAPPED ticks (qrgpu_set_tick_overlap): tick t + 1's
 // launches are queued on the other lane and start filling the slots tick t's drain leaves empty; what a robot carries from tick to tick
 // (warm-start words, cost word, the orientation task's memory) is handed over per robot (MpcLaunch::solved, WbcPipe::wbc_done).
-#define QR_LANES 3
+#define QR_LANES 5                 // 0: the context's stream; 1, 2: overlapped ticks at h <= 11; 3, 4: overlapped ticks at h > 11 (CU-masked streams)
 #define QR_ABORT_RING 8            // give-up words are rings indexed by epoch: several ticks may be in flight behind a backlog
 struct Lane {
     hipStream_t stream = nullptr;             // (lane 0: mirrors qrgpu_ctx::stream)
@@ -50,8 +50,13 @@ struct Lane {
     bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
     unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by this lane's solves for the WBC launch
     float *d_cmd_tick = nullptr;              // [12][max_batch] force scratch of a tick whose caller passes no force array
-    hipEvent_t ev_tail = nullptr;             // the lane's MPC launches of a tick are through (the tail stream waits for it)
+    hipEvent_t ev_tail = nullptr;             // lanes 3, 4: the lane's main pass of a tick is queued (its trailing launch, on the side stream, waits for it)
+    hipEvent_t ev_trail = nullptr;            // lanes 3, 4: ... and that trailing launch is through (the lane's next tick waits for it)
+    int rescue_young = 0;                     // lanes 3, 4: calls since the history was reset (the first ones carry the whole-CU rescue launch: nobody is planned yet)
+    bool masked = false;                      // lanes 3, 4: stream = all CUs but the reserved ones, side_stream = the reserved ones (both owned)
     int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
+    int *d_main_done = nullptr; int main_done_total = 0;   // h > 11 overlapped: workgroups of the lane's main passes that have left (cumulative), MpcLaunch::main_done
+    int *d_rescue_taken = nullptr;                      // ... and the rescue list's second head, per parity (MpcLaunch::rescue_taken)
     unsigned lane_done_total = 0;
 };
 
@@ -128,6 +133,13 @@ struct qrgpu_ctx {
     // slots; at equal priority the solves get most of them, tick k's WBC launch lasts until tick k + 1's main pass is dispatched (tick duration: two
     // periods) and tick k + 2, which waits for tick k's join, starts late every other tick
     hipStream_t wbc_stream_hi = nullptr;
+    // overlapped ticks at h > 11: a tenth of a mixed shard wants a whole CU per robot, which a machine that is never empty does not offer -- so the
+    // machine is split in space: ov16_side_cus CUs (a multiple of 32 on 256: every XCD's share a multiple of four, or the LDS a queue may use per CU
+    // drops to ~100 KB) are reserved for the whole-CU launches (planned list, trailing launch), the main passes run on the others
+    hipStream_t wbc_stream_16 = nullptr;      // ... and the WBC launches too (a WBC workgroup waiting on a reserved CU for a planned robot's forces would keep
+                                              //     the whole-CU workgroup that computes them from ever starting there)
+    int ov16_side_cus = 0;
+    uint32_t mask16_main[16] = {}, mask16_side[16] = {};
     // a chained tick waits for what the caller had queued on the context's stream when it made the PREVIOUS tick call (its predecessor's predecessor's
     // join and whatever consumed that tick's outputs: the arrays this tick overwrites), recorded at that call: ring of two
     hipEvent_t ev_call[2] = {nullptr, nullptr};
@@ -186,7 +198,7 @@ inline const char *lab_env(const char *name)
 #define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", \
                             "QRGPU_COMM_EVENTS", "QRGPU_SINGLE_COPIES", "QRGPU_PERSIST", "QRGPU_H16_TWO", "QRGPU_H16_TWO_HOLD", "QRGPU_H16_BIG_US", "QRGPU_H16_BIG_STAY_US", \
                             "QRGPU_LIB", "QRGPU_EXTRA_FLAGS", "QRGPU_LAB"
-#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN"
+#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16_DEBUG"
 
 #define HIPCHK(ctx, call)                                                                    \
     do {                                                                                     \
