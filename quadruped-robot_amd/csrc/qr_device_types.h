@@ -147,7 +147,8 @@ struct MpcLaunch {
     // the trailing launch that the rescue list is not its business.
     int *main_done;
     int main_done_expect;
-    int *rescue_taken;
+    int *rescue_taken;          // [0..1] the rescue list's second head, [2..3] the planned list's head, by parity
+    int linger;                 // planned launch: its first `linger` workgroups stay for the hand-overs, the others leave when the planned list is empty
 };
 #define QRGPU_ST_PIPE_TIMEOUT_D 0x02000000   // pipelined tick: the WBC gave up waiting for this robot's MPC forces (never seen; never silent)
 

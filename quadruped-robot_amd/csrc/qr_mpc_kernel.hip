@@ -196,9 +196,10 @@ __device__ __forceinline__ void mpc_outputs(int lane, int rid, int n, const doub
 // dispatch follows blockIdx, so each XCD chunk [x*chunk, (x+1)*chunk) is counting-sorted by the cost the robots had in
 // the previous launch, descending (control ticks are temporally coherent; a stale cost only costs speed).  Robots never
 // leave their XCD chunk, so the L2 locality of xcd_robot_index() is kept.  grid = 8, one workgroup per chunk.
-// Overlapped ticks: words one tick's launches leave for the lane's next tick (plan, lists, counters) are read while OTHER ticks' kernels run on the
-// same XCDs and keep lines of the same arrays in that XCD's L2 -- a plain load may hit a line fetched before the writer's kernel ended (measured:
-// a planned launch that read the list length of two ticks ago and left the list's tail to nobody).  xt: read it from memory (agent scope).
+// Overlapped ticks: the words one tick's launches leave for the lane's next tick (plan, lists, counters) and the hand-overs INSIDE a tick (rescue
+// list: written by the main pass while the planned launch's workgroups read it) are written through and read from memory (agent scope) when xt
+// is set -- nothing here may depend on which XCD's L2 holds a line of these arrays.  (The one failure measured on the way was not a cache's: the
+// planned list rewritten by the trailing launch while the tick's planned launch was still going down it, MpcLaunch::pre_list_next.)
 template <typename T> __device__ __forceinline__ T ld_xt(const T *p, bool xt)
 {
     return xt ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
@@ -1857,56 +1858,74 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
             if constexpr (MAXB == 5) {
                 // (QRGPU_H16_TWO: a tenth of a mixed h = 16 batch is listed -- more robots than the launch may take CUs.  The workgroup keeps its CU
                 //  and goes down the list; the waves its sweep no longer needs are parked as in the persistent main pass.)
-                if (P.planned_stride) {
+                if (P.planned_stride && P.main_done && P.rescue_taken && P.rescue_list) {
+                    // Overlapped tick at h > 11 (MpcLaunch::main_done): the workgroups take the list's entries off a head (they start as the last
+                    // tick's leave their CUs, not together: no fixed shares), and the first `linger` of them stay for the main pass's hand-overs.
                     if (P.planned_stride == 2) cnt = 0;            // (no plan on the host's side: the main pass skips nobody, this launch only rescues)
+                    volatile int *sNext = (volatile int *)smem;        // (the head of the dynamic LDS, dead between two solves)
+                    int *const phead = P.rescue_taken + 2 + P.rescue_parity;
+                    int *const head = P.rescue_taken + P.rescue_parity;
+                    const int *const tail = P.rescue_count + P.rescue_parity;
+                    const bool lingers = (int)blockIdx.x < P.linger;
+                    const long long t0 = wall_clock64();
+                    for (;;) {
+                        if (threadIdx.x == 0) {
+                            int got = -2;
+                            for (;;) {
+                                int ph = cnt > 0 ? __hip_atomic_load(phead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                                if (ph < cnt) {
+                                    if (!__hip_atomic_compare_exchange_strong(phead, &ph, ph + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                                    got = ld_xt(P.pre_list + ph, true);
+                                    QR_TRACE(got, 8);
+                                    break;
+                                }
+                                // (a workgroup that does not stay still takes a hand-over that is there when it looks: a whole class arriving unannounced --
+                                //  a new population -- is spread over every workgroup of the launch, not queued for the eight that stay)
+                                int taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                int avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (!lingers && !(taken < avail && taken < P.n)) break;
+                                if (taken < avail && taken < P.n) {
+                                    if (!__hip_atomic_compare_exchange_strong(head, &taken, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                                    // (the entry's store follows its writer's bump of the tail: a few hundred nanoseconds at most)
+                                    int r = -1;
+                                    const long long t1 = wall_clock64();
+                                    while ((r = __hip_atomic_load(P.rescue_list + taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t1 < 100000)
+                                        __builtin_amdgcn_s_sleep(4);
+                                    if (r < 0 || r >= P.n) continue;           // (cannot happen: the robot's WBC workgroup then reports it, QRGPU_ST_PIPE_TIMEOUT)
+                                    __hip_atomic_store(P.rescue_list + taken, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    got = r;
+                                    QR_TRACE(r, 16);
+                                    break;
+                                }
+                                if ((int)((unsigned)__hip_atomic_load(P.main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)P.main_done_expect) >= 0) {
+                                    avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (taken < avail && taken < P.n) continue;
+                                    break;                                     // the main pass is through and the list is empty
+                                }
+                                if (wall_clock64() - t0 > 5 * P.xtick_wait) break;          // (100 ms: a main pass that never ends)
+                                __builtin_amdgcn_s_sleep(32);
+                            }
+                            *sNext = got;
+                        }
+                        __syncthreads();
+                        const int rid = *sNext;
+                        __syncthreads();
+                        if (rid < 0) break;
+                        mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, rid, smem);
+                        __syncthreads();
+                    }
+                    tell_done();
+                    return;
+                }
+                if (P.planned_stride) {
                     for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
                         if (threadIdx.x == 0) QR_TRACE(ld_xt(P.pre_list + e, P.solved != nullptr), 8);
                         mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, ld_xt(P.pre_list + e, P.solved != nullptr), smem);
                         __syncthreads();
                     }
                     if (P.main_done && P.rescue_taken && P.rescue_list) {
-                        // stay for the main pass's hand-overs (MpcLaunch::main_done)
-                        volatile int *sNext = (volatile int *)smem;        // (the head of the dynamic LDS, dead between two solves)
-                        int *const head = P.rescue_taken + P.rescue_parity;
-                        const int *const tail = P.rescue_count + P.rescue_parity;
-                        const long long t0 = wall_clock64();
-                        for (;;) {
-                            if (threadIdx.x == 0) {
-                                int got = -2;
-                                for (;;) {
-                                    int taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    int avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (taken < avail && taken < P.n) {
-                                        if (!__hip_atomic_compare_exchange_strong(head, &taken, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                                        // (the entry's store follows its writer's bump of the tail: a few hundred nanoseconds at most)
-                                        int r = -1;
-                                        const long long t1 = wall_clock64();
-                                        while ((r = __hip_atomic_load(P.rescue_list + taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t1 < 100000)
-                                            __builtin_amdgcn_s_sleep(4);
-                                        if (r < 0 || r >= P.n) continue;           // (cannot happen: the robot's WBC workgroup then reports it, QRGPU_ST_PIPE_TIMEOUT)
-                                        __hip_atomic_store(P.rescue_list + taken, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        got = r;
-                                        QR_TRACE(r, 16);
-                                        break;
-                                    }
-                                    if ((int)((unsigned)__hip_atomic_load(P.main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)P.main_done_expect) >= 0) {
-                                        avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        if (taken < avail && taken < P.n) continue;
-                                        break;                                     // the main pass is through and the list is empty
-                                    }
-                                    if (wall_clock64() - t0 > 5 * P.xtick_wait) break;          // (100 ms: a main pass that never ends)
-                                    __builtin_amdgcn_s_sleep(32);
-                                }
-                                *sNext = got;
-                            }
-                            __syncthreads();
-                            const int rid = *sNext;
-                            __syncthreads();
-                            if (rid < 0) break;
-                            mpc_solve_robot<MAXB, BIG, NTHR, true>(P, io, rid, smem);
-                            __syncthreads();
-                        }
+                        // (cannot happen: a launch with main_done set takes its entries off the list's head, below)
                     }
                     tell_done();
                     return;
@@ -1929,15 +1948,15 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {     // the next call's counters
             if (P.rescue_count) st_xt(P.rescue_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr);
-            if (P.rescue_taken) st_xt(P.rescue_taken + (P.rescue_parity ^ 1), 0, true);
+            if (P.rescue_taken) { st_xt(P.rescue_taken + (P.rescue_parity ^ 1), 0, true); st_xt(P.rescue_taken + 2 + (P.rescue_parity ^ 1), 0, true); }
             if (P.pre_count) { st_xt(P.pre_count + (P.rescue_parity ^ 1), 0, P.solved != nullptr); st_xt(P.pre_count + 2, 0, P.solved != nullptr); }
         }
         const int slot = xcd_robot_index(blockIdx.x, P.n);
         if (slot >= 0) {
-            const int rid = P.order ? ld_xt(P.order + slot, P.solved != nullptr) : slot;       // same XCD chunk either way (the order permutes inside a chunk)
+            const int rid = P.order ? ld_xt(P.order + slot, P.main_done != nullptr) : slot;       // same XCD chunk either way (the order permutes inside a chunk)
             // solved by the planned list launch, beside this one -- unless that launch's gate gave up waiting for this one's stream (plan_abort)
             if (threadIdx.x == 0) QR_TRACE(rid, 1);
-            if (!(P.skip && ld_xt(P.skip + rid, P.solved != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)))
+            if (!(P.skip && ld_xt(P.skip + rid, P.main_done != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)))
                 mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, rid, smem);
             else if (threadIdx.x == 0) QR_TRACE(rid, 2);
         }
@@ -1977,8 +1996,8 @@ void qr_mpc_persist_kernel(MpcLaunch P, MpcIO io)
                     const int k = atomicAdd(P.qhead + y, 1);
                     if (k >= len) break;
                     if (P.main_started) atomicAdd(P.main_started, 1);
-                    const int r = P.order ? ld_xt(P.order + lo + k, P.solved != nullptr) : lo + k;
-                    if (P.skip && ld_xt(P.skip + r, P.solved != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) continue;         // solved by the planned list launch, beside this one
+                    const int r = P.order ? ld_xt(P.order + lo + k, P.main_done != nullptr) : lo + k;
+                    if (P.skip && ld_xt(P.skip + r, P.main_done != nullptr) && !(P.plan_abort && *P.plan_abort == P.plan_epoch)) continue;         // solved by the planned list launch, beside this one
                     got = r;
                     if (QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 1, wall_clock64());
                     break;

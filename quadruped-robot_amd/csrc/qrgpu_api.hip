@@ -275,7 +275,7 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream, bool masked = fal
               zalloc(&L.d_skip, nb) && hipHostMalloc((void **)&L.h_pre_count, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer((void **)&L.d_pre_hint, L.h_pre_count, 0) == hipSuccess && zalloc(&L.d_started, sizeof(int)) &&
               ((own_stream && !masked) || masked || create_side_stream(&L.side_stream) == hipSuccess) && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
-              zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) && zalloc(&L.d_main_done, sizeof(int)) && zalloc(&L.d_rescue_taken, 2 * sizeof(int)) &&
+              zalloc(&L.d_planned_done, sizeof(int)) && zalloc(&L.d_go, (1 + QR_ABORT_RING) * sizeof(int)) && zalloc(&L.d_lane_done, sizeof(int)) && zalloc(&L.d_main_done, sizeof(int)) && zalloc(&L.d_rescue_taken, 4 * sizeof(int)) &&
               hipMalloc(&L.d_cmd_tick, sizeof(float) * 12 * nb) == hipSuccess &&
               hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok && own_stream) {
@@ -775,7 +775,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     { static const bool dbg = lab_env("QRGPU_OV16_DEBUG") != nullptr;
       if (dbg && ov16) fprintf(stderr, "ov16 tick epoch %u lane %d chained %d: planned %d plan_n %d hint[%d] %d (other %d) rescue hint %d young %d have_plan %d\n", ov->epoch, lane_id, (int)ov->chained,
                                (int)planned, LN.plan_n, LN.rescue_parity, LN.h_pre_count[LN.rescue_parity], LN.h_pre_count[LN.rescue_parity ^ 1], LN.h_pre_count[3], LN.rescue_young, (int)have_plan); }
-    P.main_done = nullptr; P.main_done_expect = 0; P.rescue_taken = nullptr;
+    P.main_done = nullptr; P.main_done_expect = 0; P.rescue_taken = nullptr; P.linger = 0;
     if (ov16 && rescue) {
         // (h > 11 overlapped: the planned launch is also the tick's rescuer, plan or no plan -- MpcLaunch::main_done)
         LN.main_done_total += main_grid;
@@ -823,6 +823,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         int g3 = LN.h_pre_count[LN.rescue_parity] + (g3_extra >= 0 ? g3_extra : (two ? 24 : 2));
         L.planned_stride = ov16 ? (have_plan ? 1 : 2) : ((two && g3 > g3_cap) ? 1 : 0);      // (2: no list, rescue only)
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
+        // (how many of its workgroups stay for the hand-overs: all of them while there is no plan -- the whole big class arrives unannounced --
+        //  then a few: one or two robots a tick change class, and a workgroup that stays keeps its CU from the next tick's planned launch)
+        static const int linger_n = [] { const char *e = lab_env("QRGPU_OV16_LINGER"); return e ? atoi(e) : 8; }();
+        LN.last_linger = ov16 ? (have_plan ? (linger_n < g3_cap ? linger_n : g3_cap) : g3_cap) : 0;
+        L.linger = LN.last_linger;
         if (ov16) g3 = g3_cap;                         // (the reserved CUs are this launch's whatever the list's length: it is also the tick's rescuer)
         bool main_gate_queued = false;
         if (poll_fork) {
@@ -1366,7 +1371,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
             HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_call[ev_now], 0));
         }
         c->ev_call_last = ev_now;
-        if (ov.chained) { ov.prev_started = c->lane[c->ov_lane_last].d_started; ov.prev_started_total = c->lane[c->ov_lane_last].started_total; }
+        if (ov.chained) { ov.prev_started = c->lane[c->ov_lane_last].d_started; ov.prev_started_total = c->lane[c->ov_lane_last].started_total - (c->lane[c->ov_lane_last].last_linger < 8 ? c->lane[c->ov_lane_last].last_linger : 8); }      // (all but the ones that wait for a CU held by the tick before's rescuers)
         // (the all-gathers the caller fenced since the last tick -- qrgpu_allgather_fence -- still read output arrays this tick overwrites)
         for (int sl = 0; sl < 2; ++sl)
             if (((c->ov_fence_slots >> sl) & 1) && c->ev_gather[sl]) HIPCHK(c, hipStreamWaitEvent(LN.stream, c->ev_gather[sl], 0));
@@ -1454,9 +1459,13 @@ int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
         if (lane_create(c, c->lane[l], true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a lane failed"; return QRGPU_ERR_ALLOC; }
         c->lane[l].side_stream = c->lane[0].side_stream;         // (planned launches of consecutive ticks: one stream, in tick order)
     }
-    if (!c->ov16_side_cus && c->horizon_max > 11) {
-        // h > 11: the machine split in space (qrgpu_ctx.h).  QRGPU_OV16_SIDE_CUS (32, 64, 96 of 256; default 64): the whole-CU launches' share.
-        static const int side_env = [] { const char *e = getenv("QRGPU_OV16_SIDE_CUS"); return e ? atoi(e) : 64; }();
+    // h > 11: LABORATORY (QRGPU_LAB=1 QRGPU_OV16=1; LAB_NOTES.md A.3).  Overlapped ticks there need the machine split in space -- the big class's
+    // whole-CU workgroups on reserved CUs (CU-masked streams), everything else on the rest -- and the split costs what the overlap gains: 1.46-1.51
+    // against 1.53-1.56 M ticks/s on the mixed h = 16 shard.  Without the switch a context whose horizon is beyond 11 runs the plain pipelined tick.
+    static const bool ov16_on = [] { const char *e = lab_env("QRGPU_OV16"); return e && atoi(e) != 0; }();
+    if (ov16_on && !c->ov16_side_cus && c->horizon_max > 11) {
+        // QRGPU_OV16_SIDE_CUS (32 or 64 of 256; default 64): the whole-CU launches' share
+        static const int side_env = [] { const char *e = lab_env("QRGPU_OV16_SIDE_CUS"); return e ? atoi(e) : 64; }();
         int k = (side_env * c->num_cu / 256) & ~31;
         if (k < 32) k = 32;
         if (k > c->num_cu / 2) k = (c->num_cu / 2) & ~31;

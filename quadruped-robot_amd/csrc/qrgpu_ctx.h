@@ -56,6 +56,7 @@ struct Lane {
     bool masked = false;                      // lanes 3, 4: stream = all CUs but the reserved ones, side_stream = the reserved ones (both owned)
     int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
     int *d_main_done = nullptr; int main_done_total = 0;   // h > 11 overlapped: workgroups of the lane's main passes that have left (cumulative), MpcLaunch::main_done
+    int last_linger = 0;                                // how many workgroups of the lane's last planned launch stay until its main pass is through
     int *d_rescue_taken = nullptr;                      // ... and the rescue list's second head, per parity (MpcLaunch::rescue_taken)
     unsigned lane_done_total = 0;
 };
@@ -198,7 +199,7 @@ inline const char *lab_env(const char *name)
 #define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", \
                             "QRGPU_COMM_EVENTS", "QRGPU_SINGLE_COPIES", "QRGPU_PERSIST", "QRGPU_H16_TWO", "QRGPU_H16_TWO_HOLD", "QRGPU_H16_BIG_US", "QRGPU_H16_BIG_STAY_US", \
                             "QRGPU_LIB", "QRGPU_EXTRA_FLAGS", "QRGPU_LAB"
-#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16_DEBUG"
+#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16", "QRGPU_OV16_SIDE_CUS", "QRGPU_OV16_DEBUG", "QRGPU_OV16_LINGER"
 
 #define HIPCHK(ctx, call)                                                                    \
     do {                                                                                     \

@@ -222,3 +222,44 @@ def test_overlap_is_refused_when_streams_share_a_hardware_queue():
     r = subprocess.run([sys.executable, "-c", _SHARED_QUEUE % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "OVERLAP False" in r.stdout and "hardware queue" in r.stdout
+
+
+_OV16 = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import conftest, gpu_helpers as G
+import test_gpu_overlap as T
+pkg = conftest.load_pkg()
+h, n = 16, 1024
+seq = pkg.make_batch_sequence(n, h, "a1", seed=0x16AB, steps=8, excite=1.0)
+ser, prevs, prev_s, _ = T._run_sequence(pkg, seq, h, n, "piped", True)
+ovl, _, prev_o, stats = T._run_sequence(pkg, seq, h, n, "overlap", False)
+print("STATS", stats)
+assert stats[0] >= 5, stats
+listed = 0
+for k, (x, y) in enumerate(zip(ser, ovl)):
+    assert np.all(np.isfinite(y["tau"])) and np.all(np.isfinite(y["force"])), k
+    assert np.all(G.flags(y["status"]) & 0x02000000 == 0), (k, int((G.flags(y["status"]) & 0x02000000 != 0).sum()))
+    ok = (G.flags(x["status"]) == 0) & (G.flags(y["status"]) == 0)
+    assert ok.mean() > 0.97, (k, ok.mean())
+    ef = np.abs(x["force"] - y["force"]).max(1) / np.maximum(1.0, np.abs(x["force"]).max(1))
+    et = (np.abs(x["tau"] - y["tau"]) / np.maximum(1.0, np.abs(x["tau"]))).max(1)
+    assert ef[ok].max() <= 1e-6 and et[ok].max() <= 1e-5, (k, ef[ok].max(), et[ok].max())
+    listed += int((np.asarray(seq[k]["gait"]).reshape(n, -1).sum(1) >= 43).sum())
+assert listed > 0
+assert np.abs(prev_s - prev_o).max() <= 1e-6
+print("OV16_OK")
+"""
+
+
+def test_h16_overlap_of_the_laboratory_matches_the_plain_tick():
+    """LABORATORY (QRGPU_LAB=1 QRGPU_OV16=1; LAB_NOTES.md A.3; a process of its own: the switch is read once).  Overlapped ticks at h = 16 on the
+    machine split by CU masks: the main pass two to a CU on 192 CUs, the big class (>= 43 stance leg-steps: no room for its inverse Hessian in half
+    a CU) on 64 reserved ones, where the tick's planned launch also takes what the main pass hands on (robots that changed class since the lane's
+    plan, working sets that outgrew the main pass).  Eight ticks queued without a sync against the plain pipelined tick one at a time: chained,
+    nobody timed out, nobody unsolved, every robot within the solver's tolerance."""
+    env = dict(os.environ, QRGPU_LAB="1", QRGPU_OV16="1", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _OV16 % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OV16_OK" in r.stdout
