@@ -223,6 +223,7 @@ int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
  *       context, is simply not chained -- it waits for the context's stream (an event) and runs as the pipelined tick always did.
  * Throughput, not latency: a chained tick completes LATER after its call than an unchained one (its join waits for a launch that shares the
  * machine with the next tick); bench.py prints both beside `value` (config.tick_latency_ms, config.ticks_per_s_no_tick_overlap).
+ * Horizons beyond 11 are not overlapped: the call succeeds, the ticks run as plain pipelined ticks (LAB_NOTES.md A.3: measured, slower).
  * Needs the context's streams on hardware queues of their own: qrgpu_set_tick_overlap(1) probes that and returns QRGPU_ERR_NOT_SETUP (mode
  * stays off, qrgpu_last_error says why) when two of them share one -- set GPU_MAX_HW_QUEUES=8 in the environment before the process's
  * first HIP call (the HIP runtime's default of 4 is fewer than the streams a context owns). */

@@ -130,21 +130,16 @@ struct MpcLaunch {
     const unsigned *prev_solved;
     unsigned prev_epoch;
     long long xtick_wait;       // bound of that wait, in ticks of the 100 MHz clock (20 ms; QRGPU_OV_WAIT_US for the give-up tests)
-    // Overlapped ticks at h > 11: the trailing launch normally only sorts and plans (eight small workgroups on the lane's stream: a whole-CU
-    // workgroup would queue behind the NEXT tick's planned launch on the reserved CUs for a third of a tick).  plan_only = 1: it does that and,
-    // should the rescue list not be empty after all -- a robot that changed class this very tick, with no rescue launch queued for it -- gives
-    // each listed robot QRGPU_ST_MPC_OVERFLOW and raises its flag (never silent, never a hang); rescue_hint (pinned) tells the host, whose next
-    // ticks on this lane then carry the whole-CU rescue launch again.
+    // Overlapped ticks at h > 11 (laboratory: QRGPU_OV16): the trailing launch only sorts and plans -- eight small workgroups on the lane's stream
+    // (plan_only = 1); a whole-CU workgroup would queue behind the NEXT tick's planned launch on the reserved CUs for a third of a tick.
     int plan_only;
-    int *rescue_hint;
     // ... and who solves a robot that turns up on the rescue list of such a tick -- one that changed class since the lane's plan was made, or whose
     // working set outgrew the main pass: the tick's PLANNED launch.  Its workgroups hold the reserved CUs anyway; when their share of the list is
     // done they stay and take rescue-list entries as the main pass appends them (rescue_taken: the list's second head, a compare-and-swap per
     // entry; an entry reads -1 until its writer's store has landed, and is set back to -1 by whoever takes it), until every workgroup of the main
     // pass has left (main_done, cumulative like `started`, against main_done_expect) and the list is empty.  Not the trailing launch on the
     // reserved CUs: the NEXT tick's planned workgroups hold those by then, each waiting for its robot's previous solve -- one of which would be
-    // the robot the trailing launch cannot start to solve (measured: every listed robot 20 ms late, tick after tick).  plan_only = 2 tells
-    // the trailing launch that the rescue list is not its business.
+    // the robot the trailing launch cannot start to solve (measured: every listed robot 20 ms late, tick after tick).
     int *main_done;
     int main_done_expect;
     int *rescue_taken;          // [0..1] the rescue list's second head, [2..3] the planned list's head, by parity

@@ -1817,19 +1817,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
         const int *list = planned ? P.pre_list : P.rescue_list;
         int cnt = ld_xt((planned ? P.pre_count : P.rescue_count) + P.rescue_parity, P.solved != nullptr);
         cnt = cnt < P.n ? cnt : P.n;
-        if (P.rescue_mode == 1 && P.rescue_hint && blockIdx.x == 0 && threadIdx.x == 0) { P.rescue_hint[0] = cnt; __threadfence_system(); }
-        if (P.plan_only == 2) return;            // (the tick's planned launch empties the rescue list: MpcLaunch::main_done)
-        if (P.plan_only) {
-            // (no solves here: this launch has neither the LDS nor the CUs for them.  A robot on the list after all is flagged, and its WBC workgroup told)
-            for (int e = blockIdx.x * NTHR + threadIdx.x; e < cnt; e += gridDim.x * NTHR) {
-                const int r = ld_xt(list + e, true);
-                if (io.g_status) __hip_atomic_store(io.g_status + r, QRGPU_ST_MPC_OVERFLOW_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (P.solved) qr_epoch_raise(P.solved + r, P.solved_epoch);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (P.done_flag) __hip_atomic_store(P.done_flag + r, P.done_epoch << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
+        if (P.plan_only) return;                 // (overlapped tick at h > 11: the tick's planned launch empties the rescue list, MpcLaunch::main_done)
         for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
             mpc_solve_robot<MAXB, BIG, NTHR, false, H16>(P, io, ld_xt(list + e, P.solved != nullptr), smem);
             __syncthreads();                           // every wave is out of the solve before the LDS is carved again
@@ -2053,6 +2041,24 @@ __global__ void qr_gate_kernel(int *counter, int expected_total, long long max_t
     if (timed_out) { *timed_out = timed_out_value; __threadfence_system(); }
 }
 
+// The gate in front of an OVERLAPPED tick's launches (qrgpu_set_tick_overlap): tick t + 1 is queued on another stream set and may start in the
+// slots tick t's drain leaves empty -- but not before every workgroup of tick t's main pass has started (c0 / e0: the count the WBC launch's
+// gate polls too) and every workgroup of its planned launch (c1 / e1, or null): a workgroup of tick t + 1 waits, per robot, for that robot's
+// tick-t solve, and must never hold a slot that solve still needs to START.  Bounded; giving up is harmless (the per-robot waits are bounded
+// too, and a solve whose wait gives up starts cold and is flagged).
+__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp)
+{
+    if (threadIdx.x != 0) return;
+    auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
+    const long long t0 = wall_clock64();
+    if (stamp) stamp[0] = t0;                   // (diagnostic: when the gate came up / opened)
+    while (!reached(c0, e0) || (c1 && !reached(c1, e1))) {
+        if (wall_clock64() - t0 >= max_ticks) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (stamp) stamp[1] = wall_clock64();
+}
+
 // The join of a pipelined tick: waits for the WBC launch's waves (counter / expected_total, as qr_gate_kernel) and, while it is at it, for the
 // all-gathers queued before the tick (g0 / e0, g1 / e1: the counts qrgpu_allgather_tau's one-thread launches bump behind each gather, per
 // source-buffer slot; null when the context has no communicator) -- they were queued a whole tick ago, so this costs the tick nothing, and the
@@ -2082,29 +2088,6 @@ __global__ void qr_join_kernel(int *counter, int expected_total, long long max_t
     }
     if (tick_done) __hip_atomic_fetch_add(tick_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dbg) { dbg[1] = wall_clock64(); dbg[6] = 0; }
-}
-
-// The gate in front of an OVERLAPPED tick's launches (qrgpu_set_tick_overlap): tick t + 1 is queued on another stream set and may start in the
-// slots tick t's drain leaves empty -- but not before every workgroup of tick t's main pass has started (c0 / e0: the count the WBC launch's
-// gate polls too) and every workgroup of its planned launch (c1 / e1, or null): a workgroup of tick t + 1 waits, per robot, for that robot's
-// tick-t solve, and must never hold a slot that solve still needs to START.  Bounded; giving up is harmless (the per-robot waits are bounded
-// too, and a solve whose wait gives up starts cold and is flagged).
-__global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp)
-{
-    if (threadIdx.x != 0) return;
-    auto reached = [](int *p, int e) { return (int)((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)e) >= 0; };
-    const long long t0 = wall_clock64();
-    if (stamp) stamp[0] = t0;                   // (diagnostic: when the gate came up / opened)
-    while (!reached(c0, e0) || (c1 && !reached(c1, e1))) {
-        if (wall_clock64() - t0 >= max_ticks) return;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (stamp) stamp[1] = wall_clock64();
-}
-// ... and the count its join polls: everything queued before this launch on the lane's stream is through.
-__global__ void qr_bump_kernel(int *counter)
-{
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Probe of qrgpu_set_tick_overlap: do two streams of this process run side by side?  `wait` spins until `flag` is set (by `set`, queued
 // afterwards on the other stream) or the bound passes, and says which in out[0].

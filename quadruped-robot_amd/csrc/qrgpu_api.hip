@@ -56,7 +56,6 @@ extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, 
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
                                int *lane_done, int lane_expect, long long *dbg);
 __global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp);
-__global__ void qr_bump_kernel(int *counter);
 __global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks);
 __global__ void qr_probe_set_kernel(int *flag);
 __global__ void qr_selftest_kernel(double *out);
@@ -281,8 +280,7 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream, bool masked = fal
     if (ok && own_stream) {
         const uint32_t words = (uint32_t)((c->num_cu + 31) / 32);
         ok = (masked ? (hipExtStreamCreateWithCUMask(&L.stream, words, c->mask16_main) == hipSuccess && hipExtStreamCreateWithCUMask(&L.side_stream, words, c->mask16_side) == hipSuccess)
-                     : hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess) &&
-             hipEventCreateWithFlags(&L.ev_tail, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&L.ev_trail, hipEventDisableTiming) == hipSuccess;
+                     : hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess);
         L.own_stream = ok; L.masked = ok && masked;
     }
     if (ok && masked) ok = hipMemset(L.d_rescue + 2, 0xff, sizeof(int) * nb) == hipSuccess;      // (an entry reads -1 until it is written: MpcLaunch::rescue_taken)
@@ -294,8 +292,6 @@ static void lane_destroy(Lane &L)
 {
     if (L.stream && L.own_stream) { (void)hipStreamSynchronize(L.stream); }
     if (L.side_stream && (!L.own_stream || L.masked)) { (void)hipStreamSynchronize(L.side_stream); hipStreamDestroy(L.side_stream); }     // (lanes 1, 2 borrow lane 0's)
-    if (L.ev_tail) hipEventDestroy(L.ev_tail);
-    if (L.ev_trail) hipEventDestroy(L.ev_trail);
     if (L.stream && L.own_stream) hipStreamDestroy(L.stream);
     if (L.d_order) hipFree(L.d_order);
     if (L.d_rescue) hipFree(L.d_rescue);
@@ -383,7 +379,6 @@ int qrgpu_create(int device_id, int max_batch, int horizon_max, qrgpu_ctx **out)
     ok = ok && zalloc(&c->d_cost[0], sizeof(int) * nb) && zalloc(&c->d_cost[1], sizeof(int) * nb) && hipMalloc(&c->d_warm, (size_t)QR_WARM_STRIDE * nb) == hipSuccess &&
          hipStreamCreateWithFlags(&c->wbc_stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_wbc_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_wbc_join, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_ov_fence, hipEventDisableTiming) == hipSuccess &&
          zalloc(&c->d_main_started, sizeof(int)) && zalloc(&c->d_tick_done, sizeof(int)) && zalloc(&c->d_gate_abort, QR_ABORT_RING * sizeof(int)) &&
          zalloc(&c->d_wbc_finished, sizeof(int)) && zalloc(&c->d_solved, sizeof(unsigned) * nb) && zalloc(&c->d_wbc_done, sizeof(unsigned) * nb) &&
          hipMalloc(&c->d_ftime, sizeof(int) * nb) == hipSuccess && hipMalloc(&c->d_wbc_order, 2 * sizeof(int) * nb) == hipSuccess;
@@ -429,13 +424,11 @@ void qrgpu_destroy(qrgpu_ctx *c)
     if (c->d_warm) hipFree(c->d_warm);
     if (c->d_flops) hipFree(c->d_flops);
     if (c->wbc_stream) hipStreamDestroy(c->wbc_stream);
-    if (c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); hipStreamDestroy(c->tail_stream); }
     if (c->wbc_stream_hi) { (void)hipStreamSynchronize(c->wbc_stream_hi); hipStreamDestroy(c->wbc_stream_hi); }
     if (c->wbc_stream_16) { (void)hipStreamSynchronize(c->wbc_stream_16); hipStreamDestroy(c->wbc_stream_16); }
     for (int k = 0; k < 2; ++k) if (c->ev_call[k]) hipEventDestroy(c->ev_call[k]);
     if (c->ev_wbc_fork) hipEventDestroy(c->ev_wbc_fork);
     if (c->ev_wbc_join) hipEventDestroy(c->ev_wbc_join);
-    if (c->ev_ov_fence) hipEventDestroy(c->ev_ov_fence);
     if (c->d_main_started) hipFree(c->d_main_started);
     if (c->d_ftime) hipFree(c->d_ftime);
     if (c->d_wbc_finished) hipFree(c->d_wbc_finished);
@@ -773,8 +766,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     bool poll_join = false;
     P.planned_done = nullptr; P.planned_expect = 0;
     { static const bool dbg = lab_env("QRGPU_OV16_DEBUG") != nullptr;
-      if (dbg && ov16) fprintf(stderr, "ov16 tick epoch %u lane %d chained %d: planned %d plan_n %d hint[%d] %d (other %d) rescue hint %d young %d have_plan %d\n", ov->epoch, lane_id, (int)ov->chained,
-                               (int)planned, LN.plan_n, LN.rescue_parity, LN.h_pre_count[LN.rescue_parity], LN.h_pre_count[LN.rescue_parity ^ 1], LN.h_pre_count[3], LN.rescue_young, (int)have_plan); }
+      if (dbg && ov16) fprintf(stderr, "ov16 tick epoch %u lane %d chained %d: plan_n %d hint[%d] %d (other %d) have_plan %d\n", ov->epoch, lane_id, (int)ov->chained, LN.plan_n, LN.rescue_parity,
+                               LN.h_pre_count[LN.rescue_parity], LN.h_pre_count[LN.rescue_parity ^ 1], (int)have_plan); }
     P.main_done = nullptr; P.main_done_expect = 0; P.rescue_taken = nullptr; P.linger = 0;
     if (ov16 && rescue) {
         // (h > 11 overlapped: the planned launch is also the tick's rescuer, plan or no plan -- MpcLaunch::main_done)
@@ -917,8 +910,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
         // empty pass at 4096 robots)
         int rgrid = (half_lists || plan_only) ? 16 : (64 < n ? 64 : n);          // (chained ticks: every workgroup of this launch waits for a freed half CU)
-        R.plan_only = plan_only ? 2 : 0;
-        R.rescue_hint = nullptr;
+        R.plan_only = plan_only ? 1 : 0;
         R.main_done = nullptr; R.rescue_taken = nullptr;
         if (plan_only) R.lds_bytes = 16384;          // (the sort's histogram; MpcLaunch::lds_main still says what the main pass holds)
         if (rgrid < 8 && lpt) rgrid = 8;

@@ -50,9 +50,6 @@ struct Lane {
     bool two_probe = false;                   //   ... and the call after them runs two to a CU whatever the count says, to get a fresh plan
     unsigned *d_done_flag = nullptr;          // [max_batch] (tick epoch << 1) | on-the-rescue-list, raised by this lane's solves for the WBC launch
     float *d_cmd_tick = nullptr;              // [12][max_batch] force scratch of a tick whose caller passes no force array
-    hipEvent_t ev_tail = nullptr;             // lanes 3, 4: the lane's main pass of a tick is queued (its trailing launch, on the side stream, waits for it)
-    hipEvent_t ev_trail = nullptr;            // lanes 3, 4: ... and that trailing launch is through (the lane's next tick waits for it)
-    int rescue_young = 0;                     // lanes 3, 4: calls since the history was reset (the first ones carry the whole-CU rescue launch: nobody is planned yet)
     bool masked = false;                      // lanes 3, 4: stream = all CUs but the reserved ones, side_stream = the reserved ones (both owned)
     int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
     int *d_main_done = nullptr; int main_done_total = 0;   // h > 11 overlapped: workgroups of the lane's main passes that have left (cumulative), MpcLaunch::main_done
@@ -125,11 +122,9 @@ struct qrgpu_ctx {
     int ov_fence_slots = 0;                   // bit s: qrgpu_allgather_fence(s) was called since the last overlapped tick (that tick's lane waits for the gather too)
     int ov_hold = 0;                          // calls left on the plain pipelined tick after a lane found a plan (a population with whole-CU robots)
     bool ov_prev_plan = false;                // ... with a planned launch (its successor is not chained either)
-    hipEvent_t ev_ov_fence = nullptr;
     // the tail of an overlapped tick -- its second WBC pass and the count its join polls -- runs on a stream of its own behind an event of the lane's
     // stream: on the lane's stream those thousand (empty) workgroups, dispatched one freed slot at a time on a machine that is never empty, stood
     // between the lane's next tick and its gate (60 us per tick)
-    hipStream_t tail_stream = nullptr;
     // the WBC launches of overlapped ticks: a stream of the highest priority.  Tick k's WBC workgroups and tick k + 1's solves want the same freed
     // slots; at equal priority the solves get most of them, tick k's WBC launch lasts until tick k + 1's main pass is dispatched (tick duration: two
     // periods) and tick k + 2, which waits for tick k's join, starts late every other tick
