@@ -1612,7 +1612,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
                 if (QR_PFLOPS) fl_as += 3.0 * (double)q * (double)q + 6.0 * (double)nls * (double)q + 21.0 * (double)nls + 12.0 * (double)q;
                 if (full) {
                     if (fastz) {
-                        if (q < qW) { if (own) { double *wq = Wc + q * nsp + 3 * kme; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
+                        // (the address from the lane number, behind an opaque copy: hoisted out of the loop as `Wc + 3 * kme` it is spilled under 128
+                        //  registers and reloaded from scratch here, once per change, in front of a wait for the load)
+                        if (q < qW) { if (own) { int kl = lane; asm volatile("" : "+v"(kl)); double *wq = Wc + q * nsp + 3 * kl; wq[0] = w0; wq[1] = w1; wq[2] = w2_; } }
                         else fastz = false;
                     }
                     if (lane == q) { uq = up; ck = kp; ct = tp; }
