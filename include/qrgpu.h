@@ -185,14 +185,18 @@ int  qrgpu_set_warm_start(qrgpu_ctx *ctx, int on);
  * rows of the main pass's LDS allotment -- is solved in the NEXT call with the same n by a list launch of its own (whole CU's LDS, 96
  * working-set positions), issued at the start of the call on a second stream of the context beside the main launch, which skips it: the
  * batch no longer waits for a re-solve after the main launch.  big_nls > 0 additionally sends every robot with at least that many stance
- * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling only: which launch solves a robot does not change its result.
+ * leg-steps (4h = all feet down over the whole horizon) there.  Scheduling -- with two things a caller may see: the list launches are other
+ * instantiations of the kernel than the main pass (whole CU's LDS, 96 working-set positions), so a robot's forces agree between the two to the
+ * solver's tolerance (1e-6 of the largest force; the QP has one optimum), not bit for bit; and a robot at the very edge of what a launch can
+ * hold may carry QRGPU_ST_MPC_OVERFLOW under one schedule and not under the other (tests/test_gpu_wbc.py allows two such robots in 1024 between
+ * the serial and the pipelined tick).  A robot the main pass solves under both schedules has the same bits.
  * The host learns the list's length through pinned memory without a sync; so that a caller which queues calls faster than the GPU runs
  * them still gets its first plans, the first two batched calls after the history was reset (a new n, qrgpu_set_lpt_schedule) end with a
  * hipStreamSynchronize on the context's stream.  Every later call stays asynchronous.
  * At h > 11 and 3.5 robots per CU or more the main pass runs two workgroups per CU on half the LDS each, and the list is also where the robots
  * go whose inverse Hessian does not fit half a CU (43 stance leg-steps and more at h = 16; a smaller big_nls of the caller's stands) and those
  * whose solves are the longest of the tick; with the planned list, the rescue pass or the longest-first schedule switched off such batches
- * run one workgroup per CU.  Scheduling only, here too. */
+ * run one workgroup per CU.  The same two caveats apply. */
 int  qrgpu_set_planned_list(qrgpu_ctx *ctx, int on, int big_nls);
 /* Rescue pass of the batched MPC solve (default on).  A working set that outgrows the 64 lanes of the four-wave loop is handed over
  * in place to the single-wave loop (up to 96 rows) -- that needs no switch.  What remains are robots limited by LDS (an all-stance inverse
