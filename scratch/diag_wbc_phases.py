@@ -11,8 +11,12 @@ lib = ctx._lib
 lib.qrgpu_debug_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.qrgpu_debug_cycles(ctx._h, None, 0)
 n = 1024
-b = pkg.make_batch(n, 10, "a1", seed=0xA3)
-out = G.run_tick(ctx, pkg, b, want_qdes=True); out = G.run_tick(ctx, pkg, b, want_qdes=True)
+if os.environ.get("SEQ") == "1":        # a coherent sequence: the last tick's stamps, every tick warm from its predecessor
+    for b in pkg.make_batch_sequence(n, 10, "a1", seed=0xA3, steps=6, excite=1.0):
+        out = G.run_tick(ctx, pkg, b, want_qdes=True)
+else:
+    b = pkg.make_batch(n, 10, "a1", seed=0xA3)
+    out = G.run_tick(ctx, pkg, b, want_qdes=True); out = G.run_tick(ctx, pkg, b, want_qdes=True)
 buf = np.zeros((n, 16), np.int64)
 lib.qrgpu_debug_cycles(ctx._h, buf.ctypes.data, -n)
 buf[:, 6] = buf[:, 5]
