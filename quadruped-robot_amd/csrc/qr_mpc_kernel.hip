@@ -1099,7 +1099,9 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             for (int m = 0; m < NER; ++m) {
                 el[m] = 0.0; eij[m] = 0;
                 if (QR_AS_THREADS * m < ne) {                                  // (uniform)
-                    const int e = tid + QR_AS_THREADS * m;
+                    int te = tid;
+                    asm volatile("" : "+v"(te));                               // (opaque: the (i, j) of this thread's first element is otherwise hoisted out of the solve's loop and spilled)
+                    const int e = te + QR_AS_THREADS * m;
                     if (e < ne) {
                         int i = (int)((__builtin_sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
                         while (tri(i + 1) <= e) ++i;
