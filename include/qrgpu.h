@@ -79,6 +79,7 @@
  *   QRGPU_PIPE_WAIT_US      4000     bound of a WBC workgroup's wait for its robot's forces (then QRGPU_ST_PIPE_TIMEOUT)
  *   QRGPU_OV_WAIT_US        20000    overlapped ticks: bound of a robot's waits for its previous solve / WBC pass (then QRGPU_ST_PIPE_TIMEOUT)
  *   QRGPU_OV_PLAN_HOLD      31       overlapped ticks: calls on the plain pipelined tick after a lane found a planned list (0: never go back)
+ *   QRGPU_OV16              1        overlapped ticks: 0 keeps contexts with a horizon beyond 11 on the plain pipelined tick
  *   QRGPU_OV_FAULT          0        test hook: 1 makes every chained tick wait for an epoch nobody writes (the give-up paths, tests/test_gpu_overlap.py)
  *   QRGPU_COMM_EVENTS       unset    the all-gather's hand-overs: unset = stream events when the communicator has more than one rank, polled counts
  *                                    with one; 1 = events always; 0 = polled counts always
@@ -211,7 +212,7 @@ int  qrgpu_set_rescue_pass(qrgpu_ctx *ctx, int on);
  * only: results are those of the serial form bit for bit.  A WBC workgroup that waits longer than 4 ms for its robot (never observed)
  * gives the robot QRGPU_ST_PIPE_TIMEOUT. */
 int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
-/* Overlapped ticks (default OFF; pipelined ticks at h <= 11): a caller that queues qrgpu_tick_batch calls without waiting for them may let
+/* Overlapped ticks (default OFF; pipelined ticks): a caller that queues qrgpu_tick_batch calls without waiting for them may let
  * tick t + 1's solves start in the slots tick t's drain leaves empty -- a quarter of a 1024-robot tick's slot-time -- instead of behind tick
  * t's last workgroup.  With the mode on, a tick's launches go on stream sets of the context's own (two, alternating) and the context's stream
  * carries only the tick's join: OUTPUTS ARE COMPLETE IN CALL ORDER ON THE CONTEXT'S STREAM exactly as before (whatever is queued there behind
@@ -227,7 +228,11 @@ int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
  *       context, is simply not chained -- it waits for the context's stream (an event) and runs as the pipelined tick always did.
  * Throughput, not latency: a chained tick completes LATER after its call than an unchained one (its join waits for a launch that shares the
  * machine with the next tick); bench.py prints both beside `value` (config.tick_latency_ms, config.ticks_per_s_no_tick_overlap).
- * Horizons beyond 11 are not overlapped: the call succeeds, the ticks run as plain pipelined ticks (LAB_NOTES.md A.3: measured, slower).
+ * Call it AFTER the context's types are set up: the stream sets are made for the horizon the context has at the call (h <= 11: two lanes on the
+ * whole machine; h > 11, from 3.5 robots per CU on: two lanes on a machine split by CU masks -- the main pass two to a CU on 192 CUs, the robots
+ * that need a whole CU on 64 reserved ones); a context whose horizon changes class afterwards runs plain pipelined ticks until
+ * the call is made again.  Throughput of the h > 11 form shows on sequences, not on a handful of ticks: a tick completes about 1.7 periods after
+ * its call (1.74 against 1.51 M ticks/s on the mixed h = 16 shard over 25-tick windows, par over 5-tick windows).
  * Needs the context's streams on hardware queues of their own: qrgpu_set_tick_overlap(1) probes that and returns QRGPU_ERR_NOT_SETUP (mode
  * stays off, qrgpu_last_error says why) when two of them share one -- set GPU_MAX_HW_QUEUES=8 in the environment before the process's
  * first HIP call (the HIP runtime's default of 4 is fewer than the streams a context owns). */

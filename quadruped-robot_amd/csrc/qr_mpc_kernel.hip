@@ -1325,12 +1325,15 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
         // robot carries QRGPU_ST_PIPE_TIMEOUT) and read the words with loads of the same kind.  Only this wave reads them.
         const bool xtick = P.prev_solved != nullptr;
         bool warm_ok = true;
+        long long t_waited = 0;                           // (shader-clock cycles spent in that wait: not part of what the robot COST, below)
         if (xtick) {
+            const long long c0_ = clock64();
             const long long t0 = wall_clock64();
             while (!qr_epoch_reached(__hip_atomic_load(P.prev_solved + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.prev_epoch)) {
                 if (wall_clock64() - t0 > P.xtick_wait) { st |= QRGPU_ST_PIPE_TIMEOUT_D; warm_ok = false; break; }
                 __builtin_amdgcn_s_sleep(32);
             }
+            t_waited = clock64() - c0_;
             if (lane == 0) QR_TRACE(rid, 32);
             if (lane == 0 && QR_P_TL) QR_P_TL[768 + 1024 * 16 + (P.solved_epoch & 15u) * 1024 + (rid & 1023)] = ((wall_clock64() - t0) << 8) | (long long)(P.rescue_mode & 7) | (warm_ok ? 0 : 8);
         }
@@ -1720,7 +1723,7 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // what this robot cost, in units of 256 cycles -- smoothed over ticks when there is a history: half of a robot's tick-to-tick variation is
             // the change count of its active set, which does not persist (correlation 0.47 between consecutive ticks), and a longest-first
             // order from last tick's cost alone ends 10 us later than one from the running mean (scratch/analyze_predict.py)
-            long long c = (clock64() - t_begin) >> 8;
+            long long c = (clock64() - t_begin - t_waited) >> 8;
             if (c > 0xffff) c = 0xffff;
             if (P.cost_ema) {
                 const int prevc = P.prev_solved ? __hip_atomic_load(P.cost_in + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.cost_in[rid];

@@ -689,7 +689,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.big_cost = P.big_cost_stay = 0; P.planned_stride = 0;
     // (not in an overlapped tick: a long pole no longer sets a span there -- a tick has two periods to finish -- and the reserved CUs are for the
     //  robots that cannot run anywhere else; with the cost rule on, time spent WAITING counts as cost, the list grows and the reserved CUs fall behind)
-    if (two && !ov16) {
+    static const int ov16_cost = [] { const char *e = lab_env("QRGPU_OV16_COST"); return e ? atoi(e) : 1; }();
+    if (two && (!ov16 || ov16_cost)) {
         // the long poles: a robot whose solve takes most of the tick's span two to a CU (a large working set over the spilled S^-1: 600-800 us
         // against a mean of 200) is planned onto a whole CU, and stays there while its solve costs more than QRGPU_H16_BIG_STAY_US there
         static const int big_us = [] { const char *e = getenv("QRGPU_H16_BIG_US"); return e ? atoi(e) : 450; }();
@@ -1283,13 +1284,13 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // WbcPipe::wbc_done).  Otherwise the lane waits for everything queued on the context's stream so far (an event): no overlap, same results.
     const bool was_chain = c->ov_chain;
     const bool small_h = 4 * c->mpc.horizon <= 44;
-    bool ovl = piped && c->overlap && pipe_join && !c->flops_on && c->lane[1].d_order && c->lane[2].d_order;
+    bool ovl = piped && c->overlap && pipe_join && !c->flops_on && (small_h ? (c->lane[1].d_order && c->lane[2].d_order) : (c->lane[3].d_order && c->lane[4].d_order));
     // h > 11: only the two-workgroups-per-CU form of the main pass (3.5 robots per CU and more, list launches and cost words on) overlaps, on the
     // CU-masked lanes; a shard in which most robots stand (the planned list beyond 45 % of the batch) goes back to the plain tick for 31 calls
     if (ovl && !small_h) {
         static const int h16_two = [] { const char *e = getenv("QRGPU_H16_TWO"); return e ? atoi(e) : 1; }();
         static const int hold16 = [] { const char *e = getenv("QRGPU_H16_TWO_HOLD"); return e ? atoi(e) : 31; }();
-        ovl = c->lane[3].d_order && c->lane[4].d_order && h16_two != 0 && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && c->lpt;
+        ovl = h16_two != 0 && n >= (h16_two >= 2 ? 64 : 7 * c->num_cu / 2) && c->rescue && c->planned && c->lpt;
         if (ovl) {
             const Lane &NL = c->lane[3 + c->ov_next];
             if (c->ov_hold > 0) { --c->ov_hold; ovl = false; }
@@ -1389,7 +1390,10 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (bounded at 50 ms; QRGPU_PIPE_GATE_MS for the tests.  A gate that gives up -- the caller had that much work of its own queued in front of
     //  this tick -- turns the tick into the serial one: WbcPipe::gate_abort)
     static const long long gate_ticks = [] { const char *e = getenv("QRGPU_PIPE_GATE_MS"); return 100000LL * (e ? atoll(e) : 50LL); }();
-    const hipStream_t wbc_stream = ovl ? (small_h ? c->wbc_stream_hi : c->wbc_stream_16) : c->wbc_stream;
+    // (h > 11, laboratory: QRGPU_OV16_WBC_MASK=1 keeps the WBC launches off the reserved CUs -- a masked stream has no priority, and without it tick t's
+    //  WBC workgroups lose the freed slots to tick t + 1's solves: LAB_NOTES A.2 item 4)
+    static const int wbc16_masked = [] { const char *e = lab_env("QRGPU_OV16_WBC_MASK"); return e ? atoi(e) : 0; }();
+    const hipStream_t wbc_stream = ovl ? ((small_h || !wbc16_masked) ? c->wbc_stream_hi : c->wbc_stream_16) : c->wbc_stream;
     // (an overlapped tick has no second pass to fall back on: its gate is patient -- 2 s -- and one that gives up just lets the launch go: every wait
     //  of a WBC workgroup for its robot's forces is bounded and flagged.  What the serial fall-back protects against -- inputs that the caller's stream
     //  has not produced yet -- cannot happen: a chained tick's inputs are ready by contract, an unchained one makes this stream wait for the event too)
@@ -1447,36 +1451,46 @@ int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
         if (hi) HIPCHK(c, create_side_stream(&c->wbc_stream_hi));
         else HIPCHK(c, hipStreamCreateWithFlags(&c->wbc_stream_hi, hipStreamNonBlocking));
     }
-    for (int l = 1; l <= 2; ++l) {
-        if (lane_create(c, c->lane[l], true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a lane failed"; return QRGPU_ERR_ALLOC; }
-        c->lane[l].side_stream = c->lane[0].side_stream;         // (planned launches of consecutive ticks: one stream, in tick order)
-    }
-    // h > 11: LABORATORY (QRGPU_LAB=1 QRGPU_OV16=1; LAB_NOTES.md A.3).  Overlapped ticks there need the machine split in space -- the big class's
-    // whole-CU workgroups on reserved CUs (CU-masked streams), everything else on the rest -- and the split costs what the overlap gains: 1.46-1.51
-    // against 1.53-1.56 M ticks/s on the mixed h = 16 shard.  Without the switch a context whose horizon is beyond 11 runs the plain pipelined tick.
-    static const bool ov16_on = [] { const char *e = lab_env("QRGPU_OV16"); return e && atoi(e) != 0; }();
-    if (ov16_on && !c->ov16_side_cus && c->horizon_max > 11) {
-        // QRGPU_OV16_SIDE_CUS (32 or 64 of 256; default 64): the whole-CU launches' share
-        static const int side_env = [] { const char *e = lab_env("QRGPU_OV16_SIDE_CUS"); return e ? atoi(e) : 64; }();
-        int k = (side_env * c->num_cu / 256) & ~31;
-        if (k < 32) k = 32;
-        if (k > c->num_cu / 2) k = (c->num_cu / 2) & ~31;
-        c->ov16_side_cus = k;
-        for (int b = 0; b < c->num_cu && b < 512; ++b) { if (b < c->num_cu - k) c->mask16_main[b >> 5] |= 1u << (b & 31); else c->mask16_side[b >> 5] |= 1u << (b & 31); }
-        HIPCHK(c, hipExtStreamCreateWithCUMask(&c->wbc_stream_16, (uint32_t)((c->num_cu + 31) / 32), c->mask16_main));
+    // The stream sets are made for the horizon the context is set up with at this call (a context whose horizon changes class afterwards calls this
+    // again; until then its ticks are plain pipelined ticks): every stream wants a hardware queue of its own, and a context that made both sets
+    // would own eleven streams against GPU_MAX_HW_QUEUES = 8.
+    //   h <= 11: lanes 1 and 2 (a stream each; the planned launches of consecutive ticks share lane 0's side stream, in tick order).
+    //   h > 11 (QRGPU_OV16=0 keeps such contexts on the plain tick): lanes 3 and 4 on a machine split in space by CU masks -- the main pass two to a
+    //     CU on 192 CUs, the big class's whole-CU workgroups (and whatever the main pass hands on) on 64 reserved ones, eight of every XCD
+    //     (the per-XCD count has to be a multiple of four, LAB_NOTES A.2 item 2; QRGPU_OV16_SIDE_CUS = 32 for the A/B).
+    static const bool ov16_on = [] { const char *e = getenv("QRGPU_OV16"); return !e || atoi(e) != 0; }();
+    const bool want16 = 4 * c->mpc.horizon > 44;
+    hipStream_t st[6]; int nst = 0, npair = 0;
+    if (!want16) {
+        for (int l = 1; l <= 2; ++l) {
+            if (lane_create(c, c->lane[l], true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a lane failed"; return QRGPU_ERR_ALLOC; }
+            c->lane[l].side_stream = c->lane[0].side_stream;
+        }
+        st[0] = c->lane[1].stream; st[1] = c->lane[2].stream; st[2] = c->wbc_stream_hi; st[3] = c->stream; nst = 4; npair = 2;
+    } else if (ov16_on) {
+        if (!c->ov16_side_cus) {
+            static const int side_env = [] { const char *e = lab_env("QRGPU_OV16_SIDE_CUS"); return e ? atoi(e) : 64; }();
+            int k = (side_env * c->num_cu / 256) & ~31;
+            if (k < 32) k = 32;
+            if (k > c->num_cu / 2) k = (c->num_cu / 2) & ~31;
+            c->ov16_side_cus = k;
+            for (int b = 0; b < c->num_cu && b < 512; ++b) { if (b < c->num_cu - k) c->mask16_main[b >> 5] |= 1u << (b & 31); else c->mask16_side[b >> 5] |= 1u << (b & 31); }
+            static const int wbc16_masked = [] { const char *e = lab_env("QRGPU_OV16_WBC_MASK"); return e ? atoi(e) : 0; }();
+            if (wbc16_masked) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->wbc_stream_16, (uint32_t)((c->num_cu + 31) / 32), c->mask16_main));
+        }
         for (int l = 3; l <= 4; ++l)
             if (lane_create(c, c->lane[l], true, true) != QRGPU_OK) { c->err = "qrgpu_set_tick_overlap: allocation of a CU-masked lane failed"; return QRGPU_ERR_ALLOC; }
-    }
-    // probe, both ways round, and each lane's stream against the WBC stream and the context's
+        st[0] = c->lane[3].stream; st[1] = c->lane[4].stream; st[2] = c->lane[3].side_stream; st[3] = c->lane[4].side_stream; st[4] = c->wbc_stream_hi; st[5] = c->stream; nst = 6; npair = 4;
+    } else { c->overlap = 1; return QRGPU_OK; }          // (h > 11 with QRGPU_OV16=0: the mode is on, the ticks stay plain)
+    // probe, both ways round: the lanes' streams against each other, and each of them against the WBC stream and the context's
     int *d_probe = nullptr;
     HIPCHK(c, hipMalloc(&d_probe, 16 * sizeof(int)));
     HIPCHK(c, hipMemset(d_probe, 0, 16 * sizeof(int)));
     HIPCHK(c, hipDeviceSynchronize());
-    hipStream_t st[4] = {c->lane[1].stream, c->lane[2].stream, c->wbc_stream_hi, c->stream};
     int k = 0;
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) {
-            if (a == b || (a >= 2 && b >= 2)) continue;
+    for (int a = 0; a < nst; ++a)
+        for (int b = 0; b < nst; ++b) {
+            if (a == b || (a >= npair && b >= npair)) continue;
             hipLaunchKernelGGL(qr_probe_wait_kernel, dim3(1), dim3(64), 0, st[a], d_probe + k, d_probe + 8, (long long)200000);      // 2 ms
             hipLaunchKernelGGL(qr_probe_set_kernel, dim3(1), dim3(64), 0, st[b], d_probe + k);
             HIPCHK(c, hipStreamSynchronize(st[a]));

@@ -191,10 +191,10 @@ inline const char *lab_env(const char *name)
     static const bool lab = [] { const char *e = getenv("QRGPU_LAB"); return e && atoi(e) != 0; }();
     return lab ? getenv(name) : nullptr;
 }
-#define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", \
+#define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", "QRGPU_OV16", \
                             "QRGPU_COMM_EVENTS", "QRGPU_SINGLE_COPIES", "QRGPU_PERSIST", "QRGPU_H16_TWO", "QRGPU_H16_TWO_HOLD", "QRGPU_H16_BIG_US", "QRGPU_H16_BIG_STAY_US", \
                             "QRGPU_LIB", "QRGPU_EXTRA_FLAGS", "QRGPU_LAB"
-#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16", "QRGPU_OV16_SIDE_CUS", "QRGPU_OV16_DEBUG", "QRGPU_OV16_LINGER"
+#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16_SIDE_CUS", "QRGPU_OV16_DEBUG", "QRGPU_OV16_LINGER", "QRGPU_OV16_WBC_MASK", "QRGPU_OV16_COST"
 
 #define HIPCHK(ctx, call)                                                                    \
     do {                                                                                     \

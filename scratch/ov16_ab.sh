@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/ov16; rm -f gpurun_out/ov16/*
 for rep in 1 2; do
   for K in ${SIDES:-64}; do
-    QRGPU_LAB=1 QRGPU_OV16=1 QRGPU_OV16_SIDE_CUS=$K timeout -k 10 300 python bench.py --mixed --horizon 16 --steps ${STEPS:-40} --warmup 8 --no-cpu-baseline --no-side $EXTRA > gpurun_out/ov16/on${K}_$rep.json 2> gpurun_out/ov16/on${K}_$rep.err || echo "on $K failed"
+    QRGPU_LAB=1 QRGPU_OV16_SIDE_CUS=$K timeout -k 10 300 python bench.py --mixed --horizon 16 --steps ${STEPS:-40} --warmup 8 --no-cpu-baseline --no-side $EXTRA > gpurun_out/ov16/on${K}_$rep.json 2> gpurun_out/ov16/on${K}_$rep.err || echo "on $K failed"
   done
   QRGPU_BENCH_OVERLAP=0 timeout -k 10 300 python bench.py --mixed --horizon 16 --steps ${STEPS:-40} --warmup 8 --no-cpu-baseline --no-side $EXTRA > gpurun_out/ov16/off_$rep.json 2> gpurun_out/ov16/off_$rep.err || echo "off failed"
 done

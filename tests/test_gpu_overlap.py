@@ -253,13 +253,80 @@ print("OV16_OK")
 """
 
 
-def test_h16_overlap_of_the_laboratory_matches_the_plain_tick():
-    """LABORATORY (QRGPU_LAB=1 QRGPU_OV16=1; LAB_NOTES.md A.3; a process of its own: the switch is read once).  Overlapped ticks at h = 16 on the
-    machine split by CU masks: the main pass two to a CU on 192 CUs, the big class (>= 43 stance leg-steps: no room for its inverse Hessian in half
-    a CU) on 64 reserved ones, where the tick's planned launch also takes what the main pass hands on (robots that changed class since the lane's
-    plan, working sets that outgrew the main pass).  Eight ticks queued without a sync against the plain pipelined tick one at a time: chained,
-    nobody timed out, nobody unsolved, every robot within the solver's tolerance."""
-    env = dict(os.environ, QRGPU_LAB="1", QRGPU_OV16="1", GPU_MAX_HW_QUEUES="8")
+def test_h16_overlapped_ticks_match_the_plain_tick():
+    """Overlapped ticks at h = 16 on the machine split by CU masks (a process of its own: it owns another stream set than the tests above): the main
+    pass two to a CU on 192 CUs, the big class (>= 43 stance leg-steps: no room for its inverse Hessian in half a CU) on 64 reserved ones, where the
+    tick's planned launch also takes what the main pass hands on (robots that changed class since the lane's plan, working sets that outgrew the
+    main pass).  Eight ticks queued without a sync against the plain pipelined tick one at a time: chained, nobody timed out, nobody unsolved,
+    every robot within the solver's tolerance."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
     r = subprocess.run([sys.executable, "-c", _OV16 % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "OV16_OK" in r.stdout
+
+
+_OV16_MIXED = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import conftest, gpu_helpers as G
+pkg = conftest.load_pkg()
+sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import oracle_py as O
+O.build()
+h, n, K = 16, 1024, 10
+sa = pkg.make_batch_sequence(n // 2, h, "a1", seed=0xC4A1, steps=K, excite=1.0)
+sl = pkg.make_batch_sequence(n // 2, h, "lite3", seed=0xC4D2, steps=K, excite=1.0)
+seq = []
+for ba, bl in zip(sa, sl):
+    b = dict(ba); b["n"] = n
+    for k in ("mpc_state", "traj", "gait", "fb_state", "wbc_cmd", "prev_ori_vel"):
+        b[k] = np.empty((n,) + ba[k].shape[1:], ba[k].dtype); b[k][0::2] = ba[k]; b[k][1::2] = bl[k]
+    seq.append(b)
+tid = pkg.shard.interleave_types(n, 2)
+ctx = pkg.Context(0, n, 16)
+ctx.mpc_setup_packed(0, pkg.mpc_cfg("a1"), h); ctx.wbc_setup_packed(0, pkg.model_desc("a1"))
+ctx.mpc_setup_packed(1, pkg.mpc_cfg("lite3"), h); ctx.wbc_setup_packed(1, pkg.model_desc("lite3"))
+ctx.set_torque_epilogue(True, True)
+assert ctx.set_tick_overlap(True)
+S = pkg.to_soa
+d_type = ctx.alloc((n,), np.int32).upload(tid)
+prev = ctx.alloc((3, n)).upload(S(seq[0]["prev_ori_vel"]))
+bufs = [dict(state=ctx.alloc((28, n)).upload(S(b["mpc_state"])), traj=ctx.alloc((12 * h, n)).upload(S(b["traj"])), gait=ctx.alloc((4 * h, n)).upload(S(b["gait"])),
+             fb=ctx.alloc((37, n)).upload(S(b["fb_state"])), cmd=ctx.alloc((67, n)).upload(S(b["wbc_cmd"])),
+             force=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)), tau=ctx.alloc((12, n)).upload(np.full((12, n), np.nan, np.float32)),
+             status=ctx.alloc((n,), np.int32).upload(np.full((n,), 0x7f0000ff, np.int32))) for b in seq]
+ctx.sync()
+for d in bufs:
+    ctx.tick_batch(n, d["state"], d["traj"], d["gait"], d["fb"], d["cmd"], prev, d["force"], d["tau"], d["status"], d_type)
+ctx.sync()
+stats = ctx.tick_overlap_stats()
+print("STATS", stats)
+assert stats[0] >= K - 3, stats
+desc = {0: pkg.model_desc("a1"), 1: pkg.model_desc("lite3")}
+cfg = {0: pkg.mpc_cfg("a1"), 1: pkg.mpc_cfg("lite3")}
+for k in (K - 2, K - 1):
+    d, b = bufs[k], seq[k]
+    status = d["status"].download(); to = d["tau"].download().T; fo = d["force"].download().T
+    assert np.all(np.isfinite(to)) and np.all(np.isfinite(fo)), k
+    assert np.all(G.flags(status) & 0x02000000 == 0), (k, int((G.flags(status) & 0x02000000 != 0).sum()))
+    prev_in = seq[k - 1]["wbc_cmd"][:, 12:15]
+    for t in (0, 1):
+        sel = np.nonzero(tid == t)[0]
+        f, tau, st, sec, pv = O.tick_batch(1, cfg[t], h, desc[t][:3], desc[t], b["mpc_state"][sel], b["traj"][sel], b["gait"][sel], b["fb_state"][sel], b["wbc_cmd"][sel],
+                                           np.ascontiguousarray(prev_in[sel], np.float32).copy(), nthreads=16, epilogue=3)
+        ok = (G.flags(status[sel]) == 0) & (st == 0)
+        assert ok.mean() > 0.98, (k, t, ok.mean())
+        assert np.all(np.abs(to[sel][ok] - tau[ok]) <= G.tau_tol(tau[ok], 1e-4)), (k, t, np.abs(to[sel][ok] - tau[ok]).max())
+        assert np.abs(fo[sel][ok] - f[ok]).max() <= 1e-5 * max(1.0, np.abs(f[ok]).max()), (k, t)
+print("OV16_MIXED_OK")
+"""
+
+
+def test_configs4_shard_overlapped_ticks_against_the_oracle():
+    """BASELINE configs[4]'s per-GPU shard (512 A1 + 512 Lite3, h = 16), ten ticks of a coherent sequence queued without a sync on the overlapped
+    form: chained, no robot timed out or unsolved, the last two ticks -- every robot, both types -- against the oracle at the metric's tolerance."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _OV16_MIXED % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OV16_MIXED_OK" in r.stdout
