@@ -11,13 +11,14 @@ O.build()
 pkg = load_pkg()
 n, K = 1024, 12
 worst_f = worst_t = 0.0; nflag = nto = nbad = total = chained = unchained = 0
-for robot, h in (("a1", 10), ("lite3", 10), ("a1", 5)):
+CASES = [(c.split(":")[0], int(c.split(":")[1])) for c in os.environ["CASES"].split(",")] if os.environ.get("CASES") else [("a1", 10), ("lite3", 10), ("a1", 5)]
+for robot, h in CASES:
     for seed in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (11, 12, 13)):
         for ex in (0.3, 1.0, 2.0):
             ctx = pkg.Context(0, n, 16)
             ctx.mpc_setup_packed(0, pkg.mpc_cfg(robot), h); ctx.wbc_setup_packed(0, pkg.model_desc(robot))
             ctx.set_torque_epilogue(True, True)
-            assert ctx.set_tick_overlap(True)
+            if os.environ.get("OV", "1") == "1": assert ctx.set_tick_overlap(True)
             seq = pkg.make_batch_sequence(n, h, robot, seed=seed * 100 + int(ex * 10), steps=K, excite=ex)
             S = pkg.to_soa
             prev = ctx.alloc((3, n)).upload(S(seq[0]["prev_ori_vel"]))
@@ -40,6 +41,7 @@ for robot, h in (("a1", 10), ("lite3", 10), ("a1", 5)):
                 ok = ~flags & (st == 0)
                 ef = (np.abs(fo - f).max(1) / np.maximum(1.0, np.abs(f).max(1)))[ok]
                 et = (np.abs(to - tau) / np.maximum(1.0, np.abs(tau))).max(1)[ok]
+                if os.environ.get("KINDS") == "1" and flags.any(): print("      tick %d flag kinds:" % k, {hex(int(v)): int((G.flags(status) == v).sum()) for v in np.unique(G.flags(status)) if v})
                 sf += int(flags.sum()); sto += int(((G.flags(status) & 0x02000000) != 0).sum()); sb += int((ef > 1e-5).sum() + (et > 1e-4).sum() + (~np.isfinite(to)).any(1).sum())
                 wf = max(wf, float(ef.max())); wt = max(wt, float(et.max()))
             nflag += sf; nto += sto; nbad += sb; total += n * K; worst_f = max(worst_f, wf); worst_t = max(worst_t, wt)
