@@ -80,7 +80,8 @@
  *   QRGPU_OV_WAIT_US        20000    overlapped ticks: bound of a robot's waits for its previous solve / WBC pass (then QRGPU_ST_PIPE_TIMEOUT)
  *   QRGPU_OV_PLAN_HOLD      31       overlapped ticks: calls on the plain pipelined tick after a lane found a planned list (0: never go back)
  *   QRGPU_OV16              1        overlapped ticks: 0 keeps contexts with a horizon beyond 11 on the plain pipelined tick
- *   QRGPU_OV_FAULT          0        test hook: 1 makes every chained tick wait for an epoch nobody writes (the give-up paths, tests/test_gpu_overlap.py)
+ *   QRGPU_OV_FAULT          0        test hooks of the give-up paths (tests/test_gpu_overlap.py): 1 makes every chained tick wait for an epoch nobody writes;
+ *                                    2 (h > 11) sends the planned launch's workgroups home without the robots the main pass hands on
  *   QRGPU_COMM_EVENTS       unset    the all-gather's hand-overs: unset = stream events when the communicator has more than one rank, polled counts
  *                                    with one; 1 = events always; 0 = polled counts always
  *   QRGPU_SINGLE_COPIES     0        1: the single-robot calls stage through device buffers and three copies instead of one mapped pinned block

@@ -1709,11 +1709,22 @@ __device__ __forceinline__ void mpc_solve_robot(const MpcLaunch &P, const MpcIO 
             // list pass, tell that workgroup to leave it to the WBC pass behind the list launch)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
-                // (an exchange, not a store: a WBC workgroup that gave up waiting for this robot leaves 0x80000000 | epoch << 1 here -- its own status
-                //  word, written before ours, is gone, so the time-out is recorded again behind ours: never silent)
-                const unsigned old = __hip_atomic_exchange(P.done_flag + rid, (P.done_epoch << 1) | (to_rescue ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (0x80000000u | (P.done_epoch << 1)) && io.g_status)
-                    __hip_atomic_fetch_or(io.g_status + rid, QRGPU_ST_PIPE_TIMEOUT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (a compare-and-swap, not a store.  A WBC workgroup that gave up waiting for this robot leaves 0x80000000 | epoch << 1 here -- its own
+                //  status word, written before ours, is gone, so the time-out is recorded again behind ours.  And in an overlapped tick the word may
+                //  already carry a LATER epoch: the lane's next tick, which waits for this tick's WBC launch but not for a solve that launch gave up
+                //  on, has been here.  Then the word is left alone and the robot flagged all the same: never silent.)
+                const unsigned mine = (P.done_epoch << 1) | (to_rescue ? 1u : 0u);
+                unsigned cur = __hip_atomic_load(P.done_flag + rid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool late = false;
+                for (int tries = 0; tries < 64; ++tries) {
+                    const unsigned ce = (cur >> 1) & 0x3fffffffu;
+                    late = cur == (0x80000000u | (P.done_epoch << 1));
+                    if (ce != P.done_epoch && qr_epoch_reached(ce, P.done_epoch)) { late = true; break; }
+                    const unsigned seen = atomicCAS(P.done_flag + rid, cur, mine);
+                    if (seen == cur) break;
+                    cur = seen;
+                }
+                if (late && io.g_status) __hip_atomic_fetch_or(io.g_status + rid, QRGPU_ST_PIPE_TIMEOUT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (lane == 0 && QR_P_FTIME) QR_P_FTIME[rid] = (int)wall_clock64();
             if (lane == 0 && QR_P_TL) atomicMax(QR_P_TL + (P.done_epoch & 63u) * 8 + 2, wall_clock64());
@@ -1878,7 +1889,7 @@ void qr_mpc_kernel(MpcLaunch P, MpcIO io)
                                 //  a new population -- is spread over every workgroup of the launch, not queued for the eight that stay)
                                 int taken = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 int avail = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (!lingers && !(taken < avail && taken < P.n)) break;
+                                if (!lingers && (P.linger == 0 || !(taken < avail && taken < P.n))) break;          // (linger = 0: the give-up test, nobody takes a hand-over)
                                 if (taken < avail && taken < P.n) {
                                     if (!__hip_atomic_compare_exchange_strong(head, &taken, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
                                     // (the entry's store follows its writer's bump of the tail: a few hundred nanoseconds at most)

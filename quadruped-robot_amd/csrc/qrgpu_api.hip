@@ -821,6 +821,10 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         //  then a few: one or two robots a tick change class, and a workgroup that stays keeps its CU from the next tick's planned launch)
         static const int linger_n = [] { const char *e = lab_env("QRGPU_OV16_LINGER"); return e ? atoi(e) : 8; }();
         LN.last_linger = ov16 ? (have_plan ? (linger_n < g3_cap ? linger_n : g3_cap) : g3_cap) : 0;
+        // (QRGPU_OV_FAULT=2, the give-up test of MpcLaunch::main_done: nobody stays, as if every lingering workgroup had run into its bound -- a robot the
+        //  main pass hands on afterwards is solved by nobody in that tick, and must carry QRGPU_ST_PIPE_TIMEOUT)
+        static const bool linger_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return e && atoi(e) == 2; }();
+        if (linger_fault) LN.last_linger = 0;
         L.linger = LN.last_linger;
         if (ov16) g3 = g3_cap;                         // (the reserved CUs are this launch's whatever the list's length: it is also the tick's rescuer)
         bool main_gate_queued = false;
@@ -842,6 +846,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.side_stream, LN.d_go, LN.go_total, go_ticks, abort_word, LN.plan_epoch, (int *)nullptr);
             HIPCHK(c, hipGetLastError());
         } else if (planned_mode != 1) {
+            // (h > 11 overlapped: the lane's previous planned launch is through before anything of this tick runs -- it normally ended a tick ago, the tick's
+            //  join having waited for the WBC workgroups of its robots; but a WBC workgroup that GAVE UP on a robot lets the join pass while the robot's
+            //  solve is still going, and this tick's main pass clears the counters that launch's workgroups take their work from.  Found by fault injection:
+            //  tests/test_gpu_overlap.py::test_h16_hand_overs_nobody_takes_are_never_silent)
+            if (ov16 && LN.join_recorded) HIPCHK(c, hipStreamWaitEvent(LN.stream, LN.ev_join, 0));
             HIPCHK(c, hipEventRecord(LN.ev_fork, LN.stream));
             HIPCHK(c, hipStreamWaitEvent(LN.side_stream, LN.ev_fork, 0));
             if (ov16 && ov->chained && ov->prev_started) {
@@ -871,7 +880,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
             HIPCHK(c, hipExtLaunchKernel(mpc_fn(list_var, fl), dim3(pgrid), dim3(256), largs, (size_t)L.lds_bytes, ls, nullptr, nullptr, 0));
         }
         HIPCHK(c, hipGetLastError());
-        if (planned_mode != 1 && !poll_join) HIPCHK(c, hipEventRecord(LN.ev_join, LN.side_stream));
+        if (planned_mode != 1 && !poll_join) { HIPCHK(c, hipEventRecord(LN.ev_join, LN.side_stream)); LN.join_recorded = true; }
         // the main pass waits (at most 30 us) until the listed robots' workgroups sit on their CUs
         if (gate && gate_expect > 0 && !main_gate_queued) {
             hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, LN.stream, LN.d_started, LN.started_total, (long long)3000, (int *)nullptr, 0, (int *)nullptr);
@@ -1330,7 +1339,7 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     // (the give-up word of this tick's WBC gate: a ring indexed by the epoch -- several ticks may be queued behind a backlog)
     int *const gate_abort = c->d_gate_abort + (epoch & (QR_ABORT_RING - 1));
     // (QRGPU_OV_FAULT=1, the give-up tests: chained ticks wait for an epoch nobody ever writes, so that every per-robot wait runs into its bound)
-    static const unsigned ov_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return (e && atoi(e)) ? 0x10000000u : 0u; }();      // (a quarter of the epochs' range ahead: "not reached yet")
+    static const unsigned ov_fault = [] { const char *e = getenv("QRGPU_OV_FAULT"); return (e && atoi(e) == 1) ? 0x10000000u : 0u; }();      // (a quarter of the epochs' range ahead: "not reached yet")
     OvLaunch ov{epoch, false, (prev_epoch + ov_fault) & 0x3fffffffu, false, nullptr, 0u};
     if (ovl) {
         c->ov_next ^= 1;

@@ -53,6 +53,7 @@ struct Lane {
     bool masked = false;                      // lanes 3, 4: stream = all CUs but the reserved ones, side_stream = the reserved ones (both owned)
     int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
     int *d_main_done = nullptr; int main_done_total = 0;   // h > 11 overlapped: workgroups of the lane's main passes that have left (cumulative), MpcLaunch::main_done
+    bool join_recorded = false;                         // ev_join has been recorded at least once (the lane's next overlapped tick at h > 11 waits for it)
     int last_linger = 0;                                // how many workgroups of the lane's last planned launch stay until its main pass is through
     int *d_rescue_taken = nullptr;                      // ... and the rescue list's second head, per parity (MpcLaunch::rescue_taken)
     unsigned lane_done_total = 0;

@@ -330,3 +330,48 @@ def test_configs4_shard_overlapped_ticks_against_the_oracle():
     r = subprocess.run([sys.executable, "-c", _OV16_MIXED % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "OV16_MIXED_OK" in r.stdout
+
+
+_OV16_GIVE_UP = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import conftest, gpu_helpers as G
+import test_gpu_overlap as T
+pkg = conftest.load_pkg()
+h, n = 16, 1024
+seq = pkg.make_batch_sequence(n, h, "a1", seed=0x16AC, steps=6, excite=1.0)
+ser, prevs, prev_s, _ = T._run_sequence(pkg, seq, h, n, "piped", True)
+ovl, _, prev_o, stats = T._run_sequence(pkg, seq, h, n, "overlap", False)
+print("STATS", stats)
+lost = 0
+for k, (x, y) in enumerate(zip(ser, ovl)):
+    fl = G.flags(y["status"])
+    silent = (fl & 0x02000000) == 0
+    # a robot without the time-out flag was solved: its torque is the plain tick's
+    ok = silent & (G.flags(x["status"]) == 0) & (fl == 0)
+    et = (np.abs(x["tau"] - y["tau"]) / np.maximum(1.0, np.abs(x["tau"]))).max(1)
+    assert np.all(np.isfinite(y["tau"][silent])), k
+    big = np.asarray(seq[k]["gait"]).reshape(n, -1).sum(1) >= 43
+    bad = np.nonzero(ok & (et > 1e-5))[0]
+    assert bad.size == 0, (k, bad[:8].tolist(), et[bad[:8]].tolist(), big[bad[:8]].tolist(), [int(np.asarray(seq[j]["gait"]).reshape(n, -1).sum(1)[bad[0]]) for j in range(len(seq))] if bad.size else None,
+                           [hex(int(G.flags(ovl[j]["status"])[bad[0]])) for j in range(len(seq))] if bad.size else None, G.iterations(y["status"])[bad[:8]].tolist(), G.iterations(x["status"])[bad[:8]].tolist())
+    assert (silent & (fl != 0) & (G.flags(x["status"]) == 0)).sum() <= 2, k          # (nobody is flagged otherwise who is not flagged on the plain tick)
+    if k < 2:
+        # the lanes' first ticks have no plan: the whole big class arrives unannounced, is handed on, and nobody takes it
+        assert (~silent)[big].all(), (k, int((~silent)[big].sum()), int(big.sum()))
+    lost += int((~silent).sum())
+print("LOST", lost)
+assert lost > 0
+"""
+
+
+def test_h16_hand_overs_nobody_takes_are_never_silent():
+    """Fault injection (QRGPU_OV_FAULT=2, a process of its own): the planned launch's workgroups go home without waiting for the main pass, as if every
+    lingering workgroup had run into its bound (MpcLaunch::main_done).  A robot the main pass hands on then -- in the lanes' first ticks the whole
+    big class, later a robot that changed class -- is solved by nobody in that tick: its WBC workgroup's wait for the "on the list" flag gives up
+    (QRGPU_OV_WAIT_US), the robot carries QRGPU_ST_PIPE_TIMEOUT, and every robot that does NOT carry it has the plain tick's torque."""
+    env = dict(os.environ, QRGPU_OV_FAULT="2", QRGPU_OV_WAIT_US="3000", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _OV16_GIVE_UP % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "LOST" in r.stdout
