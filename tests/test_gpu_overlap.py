@@ -166,9 +166,9 @@ sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, os.path.
 import conftest, gpu_helpers as G, oracle_py as oracle
 pkg = conftest.load_pkg()
 from test_gpu_overlap import _run_sequence
-h, n = 10, 1024
+h, n = int(os.environ.get("QR_TEST_H", 10)), 1024
 seq = pkg.make_batch_sequence(n, h, "a1", seed=0x0E1C, steps=6, excite=1.0)
-ovl, _, prev_o, stats = _run_sequence(pkg, seq, h, n, "overlap", False, planned=False)
+ovl, _, prev_o, stats = _run_sequence(pkg, seq, h, n, "overlap", False, planned=(h > 11))        # (h > 11 overlaps only with the list launches on)
 assert stats == (5, 1), stats
 timed_out = 0
 for k, (y, b) in enumerate(zip(ovl, seq)):
@@ -194,6 +194,15 @@ def test_per_robot_waits_that_give_up_flag_their_robots_and_start_cold():
     wait for the robot's previous pass gives up and flags the robot likewise.  (With the real epochs and a bound of 1 us no robot of this
     sequence ever runs into it: a robot's previous solve has long ended when its next one reaches the warm-start words.)"""
     env = dict(os.environ, QRGPU_OV_WAIT_US="50", QRGPU_OV_FAULT="1", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", _GIVE_UP % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "TIMED_OUT" in r.stdout
+
+
+def test_per_robot_waits_that_give_up_at_h16():
+    """The same fault injection on the split machine of h > 11 (lanes 3 / 4): every solve of a chained tick gives up its wait, starts cold and is
+    flagged; forces still the optimum."""
+    env = dict(os.environ, QRGPU_OV_WAIT_US="50", QRGPU_OV_FAULT="1", GPU_MAX_HW_QUEUES="8", QR_TEST_H="16")
     r = subprocess.run([sys.executable, "-c", _GIVE_UP % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "TIMED_OUT" in r.stdout
