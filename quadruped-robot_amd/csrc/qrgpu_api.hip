@@ -819,7 +819,9 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         g3 = g3 < 1 ? 1 : (g3 > g3_cap ? g3_cap : g3);
         // (how many of its workgroups stay for the hand-overs: all of them while there is no plan -- the whole big class arrives unannounced --
         //  then a few: one or two robots a tick change class, and a workgroup that stays keeps its CU from the next tick's planned launch)
-        static const int linger_n = [] { const char *e = lab_env("QRGPU_OV16_LINGER"); return e ? atoi(e) : 8; }();
+        // (measured on the default configs[4] run, twice each: 16 stay 1.686 M ticks/s, 8: 1.698, 4: 1.715, 2: 1.720, 1: 1.729 -- a workgroup that stays keeps its CU
+        //  from the next tick's planned launch; four is what is left of the margin for a tick in which a handful of robots change class at once)
+        static const int linger_n = [] { const char *e = lab_env("QRGPU_OV16_LINGER"); return e ? atoi(e) : 4; }();
         LN.last_linger = ov16 ? (have_plan ? (linger_n < g3_cap ? linger_n : g3_cap) : g3_cap) : 0;
         // (QRGPU_OV_FAULT=2, the give-up test of MpcLaunch::main_done: nobody stays, as if every lingering workgroup had run into its bound -- a robot the
         //  main pass hands on afterwards is solved by nobody in that tick, and must carry QRGPU_ST_PIPE_TIMEOUT)
