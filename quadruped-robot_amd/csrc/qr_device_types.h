@@ -254,6 +254,12 @@ struct WbcPipe {
     // "on the list pass" value for that (bounded by wait_ticks, flagged).
     int wait_list;
     long long flag_ticks;       // bound of the wait for the robot's forces (100 MHz clock; 4 ms, QRGPU_PIPE_WAIT_US for the tests)
+    // Large batches, LABORATORY (QRGPU_WBC_CHUNKS; measured slower, LAB_NOTES A.7): the WBC launch is cut into launches of 1024 workgroups, each behind a gate of its own that
+    // opens when the main pass has started that many workgroups more -- workgroup b of launch k stands for workgroup k * 1024 + b of ONE launch
+    // (slot_base), through the main pass's own dispatch order (`order`: the longest-first order of THIS tick), so the robots of launch k are exactly
+    // the robots whose solves the main pass has started by then.  One launch behind one gate starts when the main pass's LAST workgroup has: at 8192
+    // robots that is 1.2 ms into a 1.65 ms tick, and 0.34 ms of WBC trail the last solve.
+    int slot_base;
 };
 
 // WBC per-type constants (device buffer): BuildDynamicModel (QS/robots/qr_robot_a1_sim.cpp:176-343)

@@ -680,7 +680,7 @@ void qr_wbc_kernel(int n, const WbcConst *__restrict__ types, const int *__restr
 #define QW_TS1(i) do { if (dbgT && threadIdx.x == 64) dbgT[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
     QW_TS(0);
     int qp_iters = 0;
-    int rid = xcd_robot_index(blockIdx.x, n);
+    int rid = xcd_robot_index((int)blockIdx.x + pipe.slot_base, n);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const bool gate_gave_up = pipe.gate_abort && __builtin_amdgcn_readfirstlane(*pipe.gate_abort) == (int)pipe.epoch;

@@ -270,7 +270,7 @@ static int lane_create(qrgpu_ctx *c, Lane &L, bool own_stream, bool masked = fal
     if (L.d_order) return QRGPU_OK;
     const size_t nb = (size_t)c->max_batch;
     auto zalloc = [](auto **p, size_t bytes) { return hipMalloc((void **)p, bytes) == hipSuccess && hipMemset(*p, 0, bytes) == hipSuccess; };
-    bool ok = hipMalloc(&L.d_order, sizeof(int) * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (2 * nb + 4)) &&
+    bool ok = hipMalloc(&L.d_order, sizeof(int) * 2 * nb) == hipSuccess && zalloc(&L.d_rescue, sizeof(int) * (nb + 2)) && zalloc(&L.d_pre, sizeof(int) * (2 * nb + 4)) &&
               zalloc(&L.d_skip, nb) && hipHostMalloc((void **)&L.h_pre_count, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer((void **)&L.d_pre_hint, L.h_pre_count, 0) == hipSuccess && zalloc(&L.d_started, sizeof(int)) &&
               ((own_stream && !masked) || masked || create_side_stream(&L.side_stream) == hipSuccess) && zalloc(&L.d_done_flag, sizeof(unsigned) * nb) && zalloc(&L.d_qhead, 16 * sizeof(int)) &&
@@ -606,7 +606,11 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     P.lds_bytes = mpc_lds_bytes(c, P.horizon, dH != nullptr);      // (inspection launches have no list pass behind them)
     // longest-first dispatch from the previous launch's per-robot cost; inspection launches (dH) and tiny batches keep slot order
     const bool lpt = c->lpt && n >= 64 && !dH;
-    P.order = (lpt && LN.lpt_n == n) ? LN.d_order : nullptr;
+    // (the order is two arrays: this tick's trailing launch sorts the next one into the half this tick's launches -- the chunked WBC launches of a large
+    //  batch among them, WbcPipe::slot_base -- do not read)
+    int *const order_next = LN.d_order + (size_t)(LN.order_parity ^ 1) * (size_t)c->max_batch;
+    P.order = (lpt && LN.lpt_n == n) ? LN.d_order + (size_t)LN.order_parity * (size_t)c->max_batch : nullptr;
+    LN.order_used = P.order;
     P.cost = lpt ? cost_out : nullptr;
     P.cost_in = cost_prev;
     { static const int ema = [] { const char *e = lab_env("QRGPU_COST_EMA"); return e ? atoi(e) : 1; }(); P.cost_ema = (lpt && ema && (ovl ? c->cost_n[(ov->epoch & 1u) ^ 1u] == n : LN.lpt_n == n)) ? 1 : 0; }
@@ -916,7 +920,7 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         //  second pass: there the robot's WBC workgroup waits for the flag this launch raises, WbcPipe::wait_list)
         R.done_flag = ovl ? LN.d_done_flag : nullptr; R.main_started = nullptr;
         R.skip = planned ? LN.d_skip : nullptr;          // (written by the planning workgroups; only the main pass reads it)
-        R.lpt_cost_in = lpt ? cost_out : nullptr; R.lpt_order_out = lpt ? LN.d_order : nullptr;
+        R.lpt_cost_in = lpt ? cost_out : nullptr; R.lpt_order_out = lpt ? order_next : nullptr;
         R.lds_bytes = list_lds;
         R.sinv_spill = c->d_sinv_spill;
         // (a grid growing with the batch was tried: workgroups that ask for a whole CU's LDS are dispatched one every ~2 us, 0.55 ms for an
@@ -937,12 +941,13 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
         LN.rescue_parity ^= 1;
     }
     LN.last_rescue_active = rescue;
+    c->last_main_persist = P.persist != 0;
     if (piped) c->main_started_total += P.persist ? n : (int)(8 * ((n + 7) / 8));      // (persistent: one count per robot taken off a queue)
-    if (lpt && rescue) LN.lpt_n = n;               // sorted by workgroups 0-7 of the rescue launch
+    if (lpt && rescue) { LN.lpt_n = n; LN.order_parity ^= 1; }               // sorted by workgroups 0-7 of the rescue launch
     else if (lpt) {
-        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, LN.stream, n, cost_out, LN.d_order, (const int *)P.ftime, P.wbc_order_out);
+        hipLaunchKernelGGL(qr_lpt_order_kernel, dim3(8), dim3(256), 0, LN.stream, n, cost_out, order_next, (const int *)P.ftime, P.wbc_order_out);
         HIPCHK(c, hipGetLastError());
-        LN.lpt_n = n;
+        LN.lpt_n = n; LN.order_parity ^= 1;
     }
     // (the WBC order is sorted by the launch behind the main pass -- the trailing list launch or qr_lpt_order_kernel; any other MPC launch on
     //  this context in between leaves the halves as they are and the next pipelined tick starts from slot order)
@@ -964,7 +969,8 @@ static int launch_mpc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
 
 static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_state, const float *d_cmd, float *d_prev,
                       float *d_tau, float *d_qdes, int *d_status, float *d_dbg, int merge, int status_or, const float *d_fr = nullptr, int epilogue = 0,
-                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0})
+                      float *d_qp = nullptr, hipStream_t stream_override = nullptr, WbcPipe pipe = WbcPipe{nullptr, 0u, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, 0, 0, 0},
+                      int grid_wgs = 0 /* > 0: one of the launches a large batch's WBC launch is cut into (WbcPipe::slot_base) */, bool timed = true)
 {
     if (!c || n <= 0 || n > c->max_batch || !d_state) return QRGPU_ERR_BAD_ARG;
     if (!d_dbg && (!d_cmd || !d_prev || !d_tau)) return QRGPU_ERR_BAD_ARG;
@@ -975,9 +981,9 @@ static int launch_wbc(qrgpu_ctx *c, int n, const int *d_type, const float *d_sta
     const hipStream_t ws = stream_override ? stream_override : c->stream;
     if (!pipe.wbc_done) c->ov_chain = false;        // (any WBC launch but an overlapped tick's: the next overlapped tick waits for the context's stream)
     {
-        TimerScope ts(c, 1, ws, !pipe.second);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
+        TimerScope ts(c, 1, ws, !pipe.second && timed);          // (the second pass of a pipelined tick is not "the WBC launch" of the timing API)
         // (inspection outputs and cycle stamps are compiled into qr_wbc_kernel_dbg only)
-        hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(8 * ((n + 7) / 8)), dim3(128), 0, ws, n, c->d_wbc, d_type, d_state,
+        hipLaunchKernelGGL((d_dbg || d_qp || c->d_dbg_cycles_wbc) ? qr_wbc_kernel_dbg : qr_wbc_kernel, dim3(grid_wgs > 0 ? grid_wgs : 8 * ((n + 7) / 8)), dim3(128), 0, ws, n, c->d_wbc, d_type, d_state,
                            d_cmd ? d_cmd : d_state, d_prev, d_tau, d_qdes, d_status, d_dbg, merge, status_or, (long long *)c->d_dbg_cycles_wbc, d_fr,
                            ready_mask(c->wbc_ready), epilogue, d_qp, pipe);
     }
@@ -1409,17 +1415,29 @@ int qrgpu_tick_batch(qrgpu_ctx *c, int n, const int *d_type_id, const float *d_m
     //  of a WBC workgroup for its robot's forces is bounded and flagged.  What the serial fall-back protects against -- inputs that the caller's stream
     //  has not produced yet -- cannot happen: a chained tick's inputs are ready by contract, an unchained one makes this stream wait for the event too)
     if (ovl && !ov.chained) HIPCHK(c, hipStreamWaitEvent(wbc_stream, c->ev_call[c->ev_call_last], 0));
-    hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, wbc_stream, c->d_main_started, expect, ovl ? 200000000LL : gate_ticks, ovl ? (int *)nullptr : gate_abort, (int)epoch,
-                       (int *)nullptr);
-    HIPCHK(c, hipGetLastError());
     static const long long flag_ticks = [] { const char *e = getenv("QRGPU_PIPE_WAIT_US"); return e ? 100LL * atoll(e) : 400000LL; }();
     unsigned *const wbc_done = ovl ? c->d_wbc_done : nullptr;
     const unsigned wait_epoch = (ovl && ov.chained) ? ((prev_epoch + ov_fault) & 0x3fffffffu) : 0u;
-    WbcPipe wp{LN.d_done_flag, epoch, nullptr, nullptr, ovl ? (int *)nullptr : gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, wbc_order_in, wbc_done, wait_epoch, ov_wait_ticks(),
-               ovl ? 1 : 0, flag_ticks};
-    rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
-                    wbc_stream, wp);
-    if (rc) return rc;
+    // Large batches, LABORATORY (QRGPU_LAB=1 QRGPU_WBC_CHUNKS=1; LAB_NOTES A.7: bit-identical, 5 % slower at 8192 robots): the WBC launch in launches of
+    // 1024 workgroups, each behind its own gate (WbcPipe::slot_base).  The main pass is not persistent at h <= 11, so "started" counts workgroups
+    // in dispatch order.
+    static const int wbc_chunks_on = [] { const char *e = lab_env("QRGPU_WBC_CHUNKS"); return e ? atoi(e) : 0; }();
+    const int total_wgs = 8 * ((n + 7) / 8);
+    const bool chunked = wbc_chunks_on && !ovl && n >= 4096 && small_h && !c->last_main_persist && !wbc_order_in && !pipe_early;
+    const int chunk_wgs = chunked ? 1024 : total_wgs;
+    const int main_before = (int)(c->main_started_total - (unsigned)total_wgs);         // (what the counter stood at before this tick's main pass)
+    for (int base = 0; base < total_wgs; base += chunk_wgs) {
+        const int wgs = (total_wgs - base < chunk_wgs) ? total_wgs - base : chunk_wgs;
+        const int expect_k = chunked ? main_before + base + wgs : expect;
+        hipLaunchKernelGGL(qr_gate_kernel, dim3(1), dim3(64), 0, wbc_stream, c->d_main_started, expect_k, ovl ? 200000000LL : gate_ticks, ovl ? (int *)nullptr : gate_abort, (int)epoch,
+                           (int *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        WbcPipe wp{LN.d_done_flag, epoch, nullptr, nullptr, ovl ? (int *)nullptr : gate_abort, 0, pipe_join ? c->d_wbc_finished : nullptr, c->d_tlr, c->d_timeline, chunked ? LN.order_used : wbc_order_in, wbc_done, wait_epoch,
+                   ov_wait_ticks(), ovl ? 1 : 0, flag_ticks, chunked ? base : 0};
+        rc = launch_wbc(c, n, d_type_id, d_fb_state, d_wbc_cmd, d_prev_ori, d_tau, d_qdes, d_status, nullptr, 1, d_status ? 1 : 0, force, c->epilogue, nullptr,
+                        wbc_stream, wp, chunked ? wgs : 0, base == 0);
+        if (rc) return rc;
+    }
     if (!pipe_join) HIPCHK(c, hipEventRecord(c->ev_wbc_join, c->wbc_stream));
     if (!ovl) {   // the second pass: the robots of the trailing launch's list (there is one at h <= 11) -- or every robot, should the gate have given up
         const bool have_list = LN.last_rescue_active;

@@ -53,6 +53,8 @@ struct Lane {
     bool masked = false;                      // lanes 3, 4: stream = all CUs but the reserved ones, side_stream = the reserved ones (both owned)
     int *d_lane_done = nullptr;               // overlapped ticks of this lane whose tail (second WBC pass) is through, ever (the tick's join polls it)
     int *d_main_done = nullptr; int main_done_total = 0;   // h > 11 overlapped: workgroups of the lane's main passes that have left (cumulative), MpcLaunch::main_done
+    int order_parity = 0;                               // which half of d_order the lane's next main pass reads (the trailing launch writes the other)
+    const int *order_used = nullptr;                    // ... and what the last main pass read (the chunked WBC launches of that tick read it too)
     bool join_recorded = false;                         // ev_join has been recorded at least once (the lane's next overlapped tick at h > 11 waits for it)
     int last_linger = 0;                                // how many workgroups of the lane's last planned launch stay until its main pass is through
     int *d_rescue_taken = nullptr;                      // ... and the rescue list's second head, per parity (MpcLaunch::rescue_taken)
@@ -160,6 +162,7 @@ struct qrgpu_ctx {
     bool warm = true;             // warm start of the MPC active set from the slot's previous solve
     unsigned char *d_warm = nullptr;   // [max_batch][QR_WARM_STRIDE]
     int warm_n = 0;               // batch size d_warm is valid for (0 = nothing yet)
+    bool last_main_persist = false;  // the last main pass took robots off queues (its "started" count is per robot, in no fixed order: no chunked WBC launches)
     void *d_dbg_cycles_wbc = nullptr;
     void *d_dbg_cycles = nullptr; // optional [max_batch][8] int64 phase stamps of the MPC kernel (qrgpu_debug_cycles)
     int lds_per_cu = 0, num_cu = 0;
@@ -195,7 +198,7 @@ inline const char *lab_env(const char *name)
 #define QRGPU_SUPPORTED_ENV "QRGPU_TICK_PIPELINE", "QRGPU_PIPE_GATE_MS", "QRGPU_PLAN_GO_MS", "QRGPU_PIPE_WAIT_US", "QRGPU_OV_WAIT_US", "QRGPU_OV_FAULT", "QRGPU_OV_PLAN_HOLD", "QRGPU_OV16", \
                             "QRGPU_COMM_EVENTS", "QRGPU_SINGLE_COPIES", "QRGPU_PERSIST", "QRGPU_H16_TWO", "QRGPU_H16_TWO_HOLD", "QRGPU_H16_BIG_US", "QRGPU_H16_BIG_STAY_US", \
                             "QRGPU_LIB", "QRGPU_EXTRA_FLAGS", "QRGPU_LAB"
-#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16_SIDE_CUS", "QRGPU_OV16_DEBUG", "QRGPU_OV16_LINGER", "QRGPU_OV16_WBC_MASK", "QRGPU_OV16_COST"
+#define QRGPU_LAB_ENV "QRGPU_WBC_ORDER", "QRGPU_WARM_UTHR", "QRGPU_TINY_WHOLE_CU", "QRGPU_SIDE_PRIORITY", "QRGPU_PLAN_SYNC", "QRGPU_PLANNED_WAVES", "QRGPU_PLANNED_MODE", "QRGPU_PLANNED_JOIN", "QRGPU_PLANNED_GATE", "QRGPU_PLANNED_FORK", "QRGPU_PLANNED_EXTRA", "QRGPU_PIPE_JOIN", "QRGPU_PIPE_FORK", "QRGPU_PIPE_EARLY", "QRGPU_OWN_STREAM", "QRGPU_OV_WBC_PRIORITY", "QRGPU_NO_WCACHE", "QRGPU_NO_BLOCK_DROP", "QRGPU_MAIN_WGS", "QRGPU_MAIN_THREADS", "QRGPU_H16_TWO_WAVES", "QRGPU_H16_THREADS", "QRGPU_COST_EMA", "QRGPU_BIG_MARGIN", "QRGPU_OV16_SIDE_CUS", "QRGPU_OV16_DEBUG", "QRGPU_OV16_LINGER", "QRGPU_OV16_WBC_MASK", "QRGPU_OV16_COST", "QRGPU_WBC_CHUNKS"
 
 #define HIPCHK(ctx, call)                                                                    \
     do {                                                                                     \
