@@ -2109,17 +2109,17 @@ __global__ void qr_join_kernel(int *counter, int expected_total, long long max_t
 }
 // Probe of qrgpu_set_tick_overlap: do two streams of this process run side by side?  `wait` spins until `flag` is set (by `set`, queued
 // afterwards on the other stream) or the bound passes, and says which in out[0].
-__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks)
+__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks, int token)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    int ok = 0;
-    while (!(ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+    bool ok = false;
+    while (!(ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
     out[0] = ok ? 1 : 2;
 }
-__global__ void qr_probe_set_kernel(int *flag)
+__global__ void qr_probe_set_kernel(int *flag, int token)          // (a token per probe: the flag words are used again and again)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Self-test of the cross-lane helpers (qrgpu_selftest): a permutation's minimum, a sum, first_lane, readlane.

@@ -56,8 +56,8 @@ extern template __global__ void qr_mpc_kernel_fl<9, true, true, 256>(MpcLaunch, 
 __global__ void qr_join_kernel(int *counter, int expected_total, long long max_ticks, int *timed_out, int *g0, int e0, int *g1, int e1, int *tick_done,
                                int *lane_done, int lane_expect, long long *dbg);
 __global__ void qr_gate2_kernel(int *c0, int e0, int *c1, int e1, long long max_ticks, long long *stamp);
-__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks);
-__global__ void qr_probe_set_kernel(int *flag);
+__global__ void qr_probe_wait_kernel(int *flag, int *out, long long max_ticks, int token);
+__global__ void qr_probe_set_kernel(int *flag, int token);
 __global__ void qr_selftest_kernel(double *out);
 __global__ void qr_lpt_order_kernel(int n, const int *cost, int *order, const int *ftime, int *wbc_order);
 __global__ void qr_gait_kernel(int n, GaitDesc D, float currentTime, int stop, int fresh, const float *g_contact, float *st, float *g_out, float *g_fe);
@@ -1516,23 +1516,31 @@ int qrgpu_set_tick_overlap(qrgpu_ctx *c, int on)
     HIPCHK(c, hipMalloc(&d_probe, 16 * sizeof(int)));
     HIPCHK(c, hipMemset(d_probe, 0, 16 * sizeof(int)));
     HIPCHK(c, hipDeviceSynchronize());
-    int k = 0;
+    int k = 0, token = 0;
     for (int a = 0; a < nst; ++a)
         for (int b = 0; b < nst; ++b) {
             if (a == b || (a >= npair && b >= npair)) continue;
-            hipLaunchKernelGGL(qr_probe_wait_kernel, dim3(1), dim3(64), 0, st[a], d_probe + k, d_probe + 8, (long long)200000);      // 2 ms
-            hipLaunchKernelGGL(qr_probe_set_kernel, dim3(1), dim3(64), 0, st[b], d_probe + k);
-            HIPCHK(c, hipStreamSynchronize(st[a]));
-            HIPCHK(c, hipStreamSynchronize(st[b]));
+            // (20 ms, and a pair that fails is asked once more: the waiting launch runs from the moment it is queued, the other one is queued by this
+            //  thread right behind it -- on a host busy with something else "right behind" has been seen to take longer than the 2 ms this bound was)
             int res = 0;
-            HIPCHK(c, hipMemcpy(&res, d_probe + 8, sizeof(int), hipMemcpyDeviceToHost));
+            for (int attempt = 0; attempt < 2 && res != 1; ++attempt) {
+                ++token;                                   // (the eight flag words go round: every probe has a value of its own)
+                hipLaunchKernelGGL(qr_probe_wait_kernel, dim3(1), dim3(64), 0, st[a], d_probe + k, d_probe + 8, (long long)2000000, token);
+                hipLaunchKernelGGL(qr_probe_set_kernel, dim3(1), dim3(64), 0, st[b], d_probe + k, token);
+                HIPCHK(c, hipStreamSynchronize(st[a]));
+                HIPCHK(c, hipStreamSynchronize(st[b]));
+                HIPCHK(c, hipMemcpy(&res, d_probe + 8, sizeof(int), hipMemcpyDeviceToHost));
+                k = (k + 1) & 7;
+            }
             if (res != 1) {
                 hipFree(d_probe);
-                c->err = "qrgpu_set_tick_overlap: two of the context's streams share a hardware queue in this process (set GPU_MAX_HW_QUEUES=8 before the first HIP call); overlapped ticks stay off";
+                static char msg[320];
+                snprintf(msg, sizeof(msg), "qrgpu_set_tick_overlap: two of the context's streams share a hardware queue in this process (set GPU_MAX_HW_QUEUES=8 before the first HIP call); "
+                         "overlapped ticks stay off [a launch on stream %d of the set waited for one queued behind it on stream %d]", a, b);
+                c->err = msg;
                 c->overlap = 0;
                 return QRGPU_ERR_NOT_SETUP;
             }
-            k = (k + 1) & 7;
         }
     hipFree(d_probe);
     c->overlap = 1;
