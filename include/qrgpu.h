@@ -217,7 +217,8 @@ int  qrgpu_set_tick_pipeline(qrgpu_ctx *ctx, int on);
  * tick t + 1's solves start in the slots tick t's drain leaves empty -- a quarter of a 1024-robot tick's slot-time -- instead of behind tick
  * t's last workgroup.  With the mode on, a tick's launches go on stream sets of the context's own (two, alternating) and the context's stream
  * carries only the tick's join: OUTPUTS ARE COMPLETE IN CALL ORDER ON THE CONTEXT'S STREAM exactly as before (whatever is queued there behind
- * the call sees them), and results are those of the serial tick bit for bit -- what a robot carries from tick to tick (warm-start words,
+ * the call sees them), and results are those of the serial tick bit for bit (a robot that goes through a list launch under one schedule and not
+ * under the other: to the solver's tolerance, qrgpu_set_planned_list) -- what a robot carries from tick to tick (warm-start words,
  * smoothed cost, the orientation task's memory prev_ori) is handed from its tick-t workgroup to its tick-(t + 1) workgroup behind per-robot
  * epoch words with bounded waits (20 ms; a robot whose wait gives up starts cold and carries QRGPU_ST_PIPE_TIMEOUT).
  * What the caller promises in exchange -- the mode is another contract than "stream order" for the INPUTS:
