@@ -2,7 +2,7 @@
 # default bench (1024 A1, h = 10, 200 steps = 25 per population): overlapped ticks with the plan hold (31 calls on the plain tick after a lane found a plan) against none
 mkdir -p gpurun_out/planhold; rm -f gpurun_out/planhold/*
 for rep in 1 2; do
-  for H in 31 0; do
+  for H in ${HOLDS:-31 0}; do
     QRGPU_OV_PLAN_HOLD=$H timeout -k 10 300 python bench.py --no-cpu-baseline --no-side > gpurun_out/planhold/hold${H}_$rep.json 2> gpurun_out/planhold/hold${H}_$rep.err || echo "hold $H failed"
   done
 done
