@@ -130,7 +130,7 @@ struct MpcLaunch {
     const unsigned *prev_solved;
     unsigned prev_epoch;
     long long xtick_wait;       // bound of that wait, in ticks of the 100 MHz clock (20 ms; QRGPU_OV_WAIT_US for the give-up tests)
-    // Overlapped ticks at h > 11 (laboratory: QRGPU_OV16): the trailing launch only sorts and plans -- eight small workgroups on the lane's stream
+    // Overlapped ticks at h > 11: the trailing launch only sorts and plans -- eight small workgroups on the lane's stream
     // (plan_only = 1); a whole-CU workgroup would queue behind the NEXT tick's planned launch on the reserved CUs for a third of a tick.
     int plan_only;
     // ... and who solves a robot that turns up on the rescue list of such a tick -- one that changed class since the lane's plan was made, or whose
